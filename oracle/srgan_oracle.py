@@ -1,0 +1,362 @@
+"""CPU oracle for the SR-GAN-FD hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch-CPU tensor ops, fp32 or fp64) of the reference's
+generator / discriminator / loss / optimizer arithmetic.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the product
+path (``sr-gan-fd_amd``) never does and fails loudly when its HIP library is missing.
+
+Pinned by: ``tests/golden/*.npz`` -- vectors captured by importing the reference's own
+``BSRGAN/model.py`` / ``ESRGAN/model.py`` in the build container (``tests/golden/make_golden.py``,
+which is the only file that touches /root/reference) and checked in ``tests/test_oracle_golden.py``.
+Not pinned: VGG-19 content-loss values (torchvision + ImageNet weights are absent from the
+reference tree and from this image) -- "parity unpinned" for that one function, see DESIGN.md.
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+Parameters are passed as ``dict[str, Tensor]`` using the reference's ``state_dict`` key names so
+the same oracle call works for a reference checkpoint and for the MI355X module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+LRELU_SLOPE = 0.2
+
+
+# ----------------------------------------------------------------------------------------------
+# Generator (RRDBNet / BSRGAN)
+# ----------------------------------------------------------------------------------------------
+def _conv(x: Tensor, P: Params, name: str, stride: int = 1, pad: int = 1) -> Tensor:
+    return F.conv2d(x, P[name + ".weight"], P.get(name + ".bias"), stride=stride, padding=pad)
+
+
+def rdb_forward(x: Tensor, P: Params, prefix: str) -> Tensor:
+    """_ResidualDenseBlock.forward -- BSRGAN/model.py:51-62 (same code ESRGAN/model.py:49-60)."""
+    feats = [x]
+    for k in range(1, 5):
+        y = _conv(torch.cat(feats, 1), P, f"{prefix}conv{k}")
+        feats.append(F.leaky_relu(y, LRELU_SLOPE))
+    out5 = _conv(torch.cat(feats, 1), P, f"{prefix}conv5")
+    return out5 * 0.2 + x
+
+
+def rrdb_forward(x: Tensor, P: Params, prefix: str) -> Tensor:
+    """_ResidualResidualDenseBlock.forward -- BSRGAN/model.py:79-88."""
+    out = x
+    for r in (1, 2, 3):
+        out = rdb_forward(out, P, f"{prefix}rdb{r}.")
+    return out * 0.2 + x
+
+
+def count_rrdb(P: Params) -> int:
+    n = 0
+    while f"trunk.{n}.rdb1.conv1.weight" in P:
+        n += 1
+    return n
+
+
+def rrdbnet_forward(x: Tensor, P: Params, upscale_factor: int = 4, clamp: bool = True) -> Tensor:
+    """BSRGAN._forward_impl -- BSRGAN/model.py:366-381; RRDBNet._forward_impl -- ESRGAN/model.py:208-229.
+
+    x: (N,3,h,w) in [0,1]  ->  (N,3,s*h,s*w), clamped to [0,1].
+    """
+    out1 = _conv(x, P, "conv1")
+    out = out1
+    for i in range(count_rrdb(P)):
+        out = rrdb_forward(out, P, f"trunk.{i}.")
+    out2 = _conv(out, P, "conv2")
+    out = out1 + out2
+    n_up = {1: 0, 2: 1, 4: 2, 8: 3}[upscale_factor]
+    for u in range(1, n_up + 1):
+        out = F.interpolate(out, scale_factor=2, mode="nearest")
+        out = F.leaky_relu(_conv(out, P, f"upsampling{u}.0"), LRELU_SLOPE)
+    out = F.leaky_relu(_conv(out, P, "conv3.0"), LRELU_SLOPE)
+    out = _conv(out, P, "conv4")
+    if clamp:
+        out = torch.clamp(out, 0.0, 1.0)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Spectral norm + U-Net discriminator
+# ----------------------------------------------------------------------------------------------
+def _normalize(v: Tensor, eps: float) -> Tensor:
+    return v / torch.clamp(v.norm(), min=eps)
+
+
+def spectral_norm_weight(w_orig: Tensor, u: Tensor, v: Tensor, training: bool,
+                         eps: float = 1e-12, n_power_iterations: int = 1
+                         ) -> Tuple[Tensor, Tensor, Tensor]:
+    """torch/nn/utils/spectral_norm.py:62-114 as applied at BSRGAN/model.py:104-132.
+
+    Returns (weight = w_orig / sigma, u_new, v_new).  u, v are treated as constants for autograd;
+    gradient reaches w_orig through both the numerator and sigma = u^T W v.
+    """
+    w_mat = w_orig.reshape(w_orig.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            for _ in range(n_power_iterations):
+                v = _normalize(torch.mv(w_mat.t(), u), eps)
+                u = _normalize(torch.mv(w_mat, v), eps)
+            u = u.clone()
+            v = v.clone()
+    sigma = torch.dot(u, torch.mv(w_mat, v))
+    return w_orig / sigma, u, v
+
+
+D_SN_LAYERS = ("down_block1", "down_block2", "down_block3", "up_block1", "up_block2", "up_block3",
+               "conv2", "conv3")
+
+
+def discriminator_unet_forward(x: Tensor, P: Params, training: bool = True,
+                               update_state: bool = True) -> Tensor:
+    """DiscriminatorUNet._forward_impl -- BSRGAN/model.py:141-167 (identical Real_ESRGAN/model.py:79-105).
+
+    P holds conv1/conv4 weight+bias and, per SN layer L, ``L.0.weight_orig``, ``L.0.weight_u``,
+    ``L.0.weight_v``.  In training mode the u/v entries of P are advanced in place (one power
+    iteration per forward) exactly like the reference's forward-pre-hook does.
+    """
+    def sn_conv(inp: Tensor, layer: str, stride: int) -> Tensor:
+        w, u, v = spectral_norm_weight(P[f"{layer}.0.weight_orig"], P[f"{layer}.0.weight_u"],
+                                       P[f"{layer}.0.weight_v"], training)
+        if training and update_state:
+            P[f"{layer}.0.weight_u"] = u
+            P[f"{layer}.0.weight_v"] = v
+        return F.leaky_relu(F.conv2d(inp, w, None, stride=stride, padding=1), LRELU_SLOPE)
+
+    out1 = _conv(x, P, "conv1")
+    down1 = sn_conv(out1, "down_block1", 2)
+    down2 = sn_conv(down1, "down_block2", 2)
+    down3 = sn_conv(down2, "down_block3", 2)
+    down3 = F.interpolate(down3, scale_factor=2, mode="bilinear", align_corners=False)
+    up1 = sn_conv(down3, "up_block1", 1) + down2
+    up1 = F.interpolate(up1, scale_factor=2, mode="bilinear", align_corners=False)
+    up2 = sn_conv(up1, "up_block2", 1) + down1
+    up2 = F.interpolate(up2, scale_factor=2, mode="bilinear", align_corners=False)
+    up3 = sn_conv(up2, "up_block3", 1) + out1
+    out = sn_conv(up3, "conv2", 1)
+    out = sn_conv(out, "conv3", 1)
+    return _conv(out, P, "conv4")
+
+
+# ----------------------------------------------------------------------------------------------
+# VGG-19 feature taps / content loss  (parity unpinned -- third-party torchvision, see header)
+# ----------------------------------------------------------------------------------------------
+VGG19_CFG: Sequence = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M",
+                       512, 512, 512, 512, "M", 512, 512, 512, 512)  # features[0:35]
+
+
+def vgg19_feature_layers() -> List[Tuple[str, int, int]]:
+    """(kind, index-in-features, channels) list of torchvision vgg19().features[0:36]."""
+    layers, idx, cin = [], 0, 3
+    for v in VGG19_CFG:
+        if v == "M":
+            layers.append(("pool", idx, cin))
+            idx += 1
+        else:
+            layers.append(("conv", idx, v))
+            layers.append(("relu", idx + 1, v))
+            idx += 2
+            cin = v
+    return layers
+
+
+def vgg19_taps(x: Tensor, P: Params, nodes: Sequence[str], taps_post_relu: bool = True
+               ) -> Dict[str, Tensor]:
+    """torchvision vgg19().features cut at ``features.N`` conv nodes -- BSRGAN/model.py:522-524,545-546.
+
+    With ``taps_post_relu`` the tap of a conv that is followed by ``ReLU(inplace=True)`` is
+    observed after the in-place ReLU (the graph keeps executing until the last requested node),
+    while the last requested node is observed pre-ReLU (later nodes are pruned) -- SURVEY 8a/A7.
+    P keys: ``features.{idx}.weight`` / ``.bias``.
+    """
+    want = [int(n.split(".")[1]) for n in nodes]
+    last = max(want)
+    out: Dict[str, Tensor] = {}
+    h = x
+    for kind, idx, _ in vgg19_feature_layers():
+        if idx > last:
+            break
+        if kind == "conv":
+            h = F.conv2d(h, P[f"features.{idx}.weight"], P[f"features.{idx}.bias"], padding=1)
+            if idx in want:
+                if idx == last or not taps_post_relu:
+                    out[f"features.{idx}"] = h
+                else:
+                    out[f"features.{idx}"] = F.relu(h)
+        elif kind == "relu":
+            h = F.relu(h)
+        else:
+            h = F.max_pool2d(h, 2, 2)
+    return out
+
+
+def content_loss(sr: Tensor, gt: Tensor, P: Params, nodes: Sequence[str], mean: Sequence[float],
+                 std: Sequence[float], taps_post_relu: bool = True) -> Tensor:
+    """ContentLoss.forward -- BSRGAN/model.py:536-554.  Returns a DETACHED (1, len(nodes)) tensor
+    (``torch.Tensor([losses])`` at :552 builds a fresh leaf)."""
+    m = torch.tensor(mean, dtype=sr.dtype).view(1, -1, 1, 1)
+    s = torch.tensor(std, dtype=sr.dtype).view(1, -1, 1, 1)
+    with torch.no_grad():
+        fs = vgg19_taps((sr - m) / s, P, nodes, taps_post_relu)
+        fg = vgg19_taps((gt - m) / s, P, nodes, taps_post_relu)
+        losses = [float(F.l1_loss(fs[n], fg[n])) for n in nodes]
+    return torch.tensor([losses], dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Losses, PSNR
+# ----------------------------------------------------------------------------------------------
+def l1_mean(a: Tensor, b: Tensor) -> Tensor:
+    """nn.L1Loss() mean -- BSRGAN/train_bsrgan.py:297,450."""
+    return (a - b).abs().mean()
+
+
+def bce_with_logits_mean(logits: Tensor, target: float) -> Tensor:
+    """nn.BCEWithLogitsLoss() mean against a constant label map -- train_bsrgan.py:301,403-404,417,427,452.
+    loss = max(x,0) - x*t + log(1+exp(-|x|))."""
+    x = logits
+    return (torch.clamp(x, min=0) - x * target + torch.log1p(torch.exp(-x.abs()))).mean()
+
+
+def psnr_y(raw: Tensor, dst: Tensor, crop_border: int = 0, only_test_y_channel: bool = True) -> Tensor:
+    """_psnr_torch -- BSRGAN/image_quality_assessment.py:361-395 with rgb_to_ycbcr_torch
+    (BSRGAN/imgproc.py:742-770, only_use_y_channel=True branch).  Inputs (N,3,H,W) in [0,1], RGB."""
+    if crop_border > 0:
+        raw = raw[:, :, crop_border:-crop_border, crop_border:-crop_border]
+        dst = dst[:, :, crop_border:-crop_border, crop_border:-crop_border]
+    if only_test_y_channel:
+        w = torch.tensor([[65.481], [128.553], [24.966]], dtype=raw.dtype)
+
+        def to_y(t: Tensor) -> Tensor:
+            y = torch.matmul(t.permute(0, 2, 3, 1), w).permute(0, 3, 1, 2) + 16.0
+            return y / 255.0
+        raw, dst = to_y(raw), to_y(dst)
+    raw = raw.to(torch.float64)
+    dst = dst.to(torch.float64)
+    mse = torch.mean((raw * 255.0 - dst * 255.0) ** 2 + 1e-8, dim=[1, 2, 3])
+    return 10 * torch.log10(255.0 ** 2 / mse)
+
+
+# ----------------------------------------------------------------------------------------------
+# Optimizer / EMA  (torch.optim.Adam single-tensor maths; swa_utils.AveragedModel)
+# ----------------------------------------------------------------------------------------------
+class AdamState:
+    def __init__(self, params: Params, names: Sequence[str]):
+        self.step = 0
+        self.m = {k: torch.zeros_like(params[k]) for k in names}
+        self.v = {k: torch.zeros_like(params[k]) for k in names}
+
+
+def adam_step(params: Params, grads: Params, st: AdamState, lr: float,
+              betas: Tuple[float, float], eps: float, weight_decay: float = 0.0) -> None:
+    """torch.optim.Adam (amsgrad=False, maximize=False) as configured at train_bsrgan.py:311-323
+    (eps=1e-4, betas=(0.9,0.999)) / train_rrdbnet.py:196-203 (eps=1e-8, betas=(0.9,0.99))."""
+    st.step += 1
+    b1, b2 = betas
+    bc1 = 1 - b1 ** st.step
+    bc2 = 1 - b2 ** st.step
+    for k, g in grads.items():
+        if g is None:
+            continue
+        p = params[k]
+        if weight_decay != 0:
+            g = g + weight_decay * p
+        st.m[k].mul_(b1).add_(g, alpha=1 - b1)
+        st.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (st.v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.data.addcdiv_(st.m[k], denom, value=-(lr / bc1))
+
+
+def ema_update(ema: Params, params: Params, n_averaged: int, decay: float) -> int:
+    """AveragedModel.update_parameters with the reference's avg_fn
+    ``(1-decay)*ema + decay*param`` -- train_bsrgan.py:290-291 (note: weight ``decay`` on the NEW
+    parameters; kept as is).  First call copies (torch/optim/swa_utils.py)."""
+    for k in params:
+        if n_averaged == 0:
+            ema[k] = params[k].detach().clone()
+        else:
+            ema[k] = (1 - decay) * ema[k] + decay * params[k].detach()
+    return n_averaged + 1
+
+
+# ----------------------------------------------------------------------------------------------
+# Training iterations
+# ----------------------------------------------------------------------------------------------
+def _leafify(P: Params, names: Sequence[str]) -> None:
+    for k in names:
+        P[k] = P[k].detach().requires_grad_(True)
+
+
+def g_param_names(P: Params) -> List[str]:
+    return [k for k in P if k.endswith(".weight") or k.endswith(".bias")]
+
+
+def d_param_names(P: Params) -> List[str]:
+    return [k for k in P if k.endswith(".weight") or k.endswith(".bias") or k.endswith("weight_orig")]
+
+
+def g_only_step(G: Params, opt: AdamState, lr_img: Tensor, gt: Tensor, *, upscale: int, lr: float,
+                betas: Tuple[float, float], eps: float, loss_weight: float = 1.0) -> Tuple[float, Tensor]:
+    """Generator-only iteration -- ESRGAN/train_rrdbnet.py:244-267, BSRGAN/train_bsrnet.py:244-272.
+    (autocast / GradScaler are inert on CPU: SURVEY 8 preamble.)  Returns (loss, sr)."""
+    names = g_param_names(G)
+    _leafify(G, names)
+    sr = rrdbnet_forward(lr_img, G, upscale)
+    loss = loss_weight * l1_mean(sr, gt)
+    grads = torch.autograd.grad(loss, [G[k] for k in names])
+    with torch.no_grad():
+        adam_step(G, dict(zip(names, grads)), opt, lr, betas, eps)
+    for k in names:
+        G[k] = G[k].detach()
+    return float(loss), sr.detach()
+
+
+def gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: Tensor, gt: Tensor, *,
+             upscale: int, g_lr: float, d_lr: float, betas: Tuple[float, float], eps: float,
+             pixel_weight: float, content_weight: float, adversarial_weight: float,
+             content_fn=None, train_generator: bool = True) -> Dict[str, float]:
+    """One GAN iteration -- BSRGAN/train_bsrgan.py:387-483, exact order:
+    D(gt) fwd+bwd, G fwd, D(sr.detach()) fwd+bwd (accumulate), D step, freeze D, pixel/content/adv
+    with the UPDATED D (SN u/v advance a third time), G bwd + step.  content_fn(sr, gt) returns the
+    detached (1,5) tensor or None (-> 0)."""
+    gn, dn = g_param_names(G), d_param_names(D)
+    _leafify(D, dn)
+    _leafify(G, gn)
+    # ---- D step ----
+    gt_out = discriminator_unet_forward(gt, D, training=True)
+    d_loss_hr = bce_with_logits_mean(gt_out, 1.0)
+    g_hr = torch.autograd.grad(d_loss_hr, [D[k] for k in dn])
+    sr = rrdbnet_forward(lr_img, G, upscale)
+    sr_out = discriminator_unet_forward(sr.detach().clone(), D, training=True)
+    d_loss_sr = bce_with_logits_mean(sr_out, 0.0)
+    g_sr = torch.autograd.grad(d_loss_sr, [D[k] for k in dn])
+    with torch.no_grad():
+        adam_step(D, {k: a + b for k, a, b in zip(dn, g_hr, g_sr)}, d_opt, d_lr, betas, eps)
+    for k in dn:
+        D[k] = D[k].detach()
+    # ---- G step ----
+    pixel = pixel_weight * l1_mean(sr, gt)
+    content = content_fn(sr.detach(), gt) if content_fn is not None else torch.zeros(1, 5)
+    content = (content_weight * content).sum()
+    adv_out = discriminator_unet_forward(sr, D, training=True)
+    adv = adversarial_weight * bce_with_logits_mean(adv_out, 1.0)
+    g_loss = pixel + content + adv
+    if train_generator:
+        grads = torch.autograd.grad(g_loss, [G[k] for k in gn])
+        with torch.no_grad():
+            adam_step(G, dict(zip(gn, grads)), g_opt, g_lr, betas, eps)
+    for k in gn:
+        G[k] = G[k].detach()
+    return {
+        "d_loss": float(d_loss_hr + d_loss_sr), "pixel_loss": float(pixel), "content_loss": float(content),
+        "adversarial_loss": float(adv),
+        "d_gt_probability": float(torch.sigmoid(gt_out.detach()).mean()),
+        "d_sr_probability": float(torch.sigmoid(sr_out.detach()).mean()),
+    }

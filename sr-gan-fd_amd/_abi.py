@@ -1,0 +1,119 @@
+"""ctypes binding of libsrganfd_hip.so (include/srganfd.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``lib()`` raises if the shared
+object has not been built (``python -c 'import __graft_entry__ as g; g.build()'``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrganfd_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("cstride", C.c_int32), ("c0", C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("up", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+        ("cout_store", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("x", View), ("y", View), ("r1", View), ("r2", View), ("mask", View),
+        ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("alpha_dev", C.c_void_p),
+        ("alpha", C.c_float), ("slope", C.c_float), ("post_scale", C.c_float), ("r1_scale", C.c_float),
+        ("r2_scale", C.c_float), ("mask_slope", C.c_float), ("act", C.c_int32), ("y_f32", C.c_int32),
+    ]
+
+
+class PackSeg(C.Structure):
+    _fields_ = [
+        ("src_off", C.c_int64), ("scale_off", C.c_int64), ("co_src", C.c_int32), ("ci_src", C.c_int32),
+        ("k_lo", C.c_int32), ("k_len", C.c_int32), ("co_off", C.c_int32), ("ci_off", C.c_int32),
+        ("transposed", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+class PackJob(C.Structure):
+    _fields_ = [
+        ("dst_off", C.c_int64), ("dtype", C.c_int32), ("ksize", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
+        ("nseg", C.c_int32), ("pad_", C.c_int32), ("seg", PackSeg * 5),
+    ]
+
+
+class WgradConv(C.Structure):
+    _fields_ = [
+        ("ci_lo", C.c_int32), ("cin", C.c_int32), ("co_lo", C.c_int32), ("cout", C.c_int32),
+        ("dw_off", C.c_int64), ("db_off", C.c_int64), ("co_dst", C.c_int32), ("ci_dst", C.c_int32),
+        ("alpha", C.c_float), ("beta", C.c_float), ("alpha_off", C.c_int64),
+    ]
+
+
+class WgradShape(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("up", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("x_channels", C.c_int32), ("dy_channels", C.c_int32), ("nconv", C.c_int32), ("splits", C.c_int32),
+    ]
+
+
+# symbol -> (restype, argtypes); tests check that the library exports every one of these
+SYMBOLS = {
+    "srganfd_last_error": (C.c_char_p, []),
+    "srganfd_abi_version": (C.c_int, []),
+    "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "srganfd_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_wgrad_plan_bytes": (C.c_size_t, [C.POINTER(WgradShape), C.POINTER(WgradConv)]),
+    "srganfd_wgrad_plan_build": (C.c_int, [C.POINTER(WgradShape), C.POINTER(WgradConv), C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_size_t)]),
+    "srganfd_conv2d_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+class SrganfdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsrganfd_hip.so (after torch, so both share torch's libamdhip64.so.7)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrganfdError(
+                f"{LIB_PATH} is missing: the HIP library is the product and has no fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        import torch  # noqa: F401  (loads the HIP runtime the extension must share)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise SrganfdError(f"{what} failed (rc={rc}): {lib().srganfd_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def view(t, cstride=None, c0=0) -> View:
+    """NHWC tensor (..., C) -> channel-slice view starting at channel c0."""
+    return View(t.data_ptr(), int(cstride if cstride is not None else t.shape[-1]), int(c0))
+
+
+NULL_VIEW = View(None, 0, 0)

@@ -1,0 +1,63 @@
+// common.hpp -- shared device helpers for the gfx950 (CDNA4) SR-GAN-FD kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/srganfd.h"
+
+namespace srganfd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+typedef unsigned short bf16_t;  // storage type for bf16
+
+// round-to-nearest-even fp32 -> bf16 (plain cast keeps NaN a NaN: MI355X guide, correctness table)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __builtin_bit_cast(float, ((unsigned int)v) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = SRGANFD_BF16;
+  static constexpr int kStep = 16;  // K per MFMA (v_mfma_f32_32x32x16_bf16)
+  __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  __device__ static __forceinline__ bf16_t from_f(float f) { return f2bf(f); }
+};
+template <> struct Elem<float> {
+  static constexpr int kDtype = SRGANFD_F32;
+  static constexpr int kStep = 2;   // K per MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain)
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float f) { return f; }
+};
+
+// MFMA 32x32 C/D layout (dtype independent on gfx950): col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mfma32_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+extern thread_local char g_err[512];
+int set_err(int code, const char* fmt, ...);
+
+#define SRGANFD_HIP_CHECK(expr)                                                          \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return srganfd::set_err(SRGANFD_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                              hipGetErrorString(_e));                                    \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace srganfd

@@ -1,0 +1,415 @@
+// wgrad.hip -- weight/bias gradients of the NHWC convolutions on the CDNA4 matrix cores.
+//
+// Replaces the weight/bias outputs of ATen convolution_backward for the reference's convs
+// (autograd of BSRGAN/model.py:42-46,102-135,325-355 as driven by train_bsrgan.py:420,430,463).
+//
+//   dW[tap][ci][co] = sum_p X[p (+) tap][ci] * dY[p][co]          (contraction over PIXELS)
+//
+// MI355X mapping: the contraction index is the pixel, but activations are stored NHWC (channel
+// fastest) for the forward/dgrad kernels.  Instead of keeping a second, transposed copy of every
+// activation, the tiles are staged NHWC into LDS and the MFMA operands are read with gfx950's
+// transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-channel block delivered channel-major),
+// so A = X^T and B = dY^T fragments cost one LDS instruction pair each and no extra HBM traffic.
+// One wavefront owns one (32 ci x 32 co) block for all taps (9 x 16 accumulator registers); four
+// wavefronts of a workgroup share the staged X / dY tiles.  Pixel tiles are split over workgroups;
+// each wave writes an fp32 partial slab and a second kernel reduces the slabs deterministically
+// (no float atomics: results are bitwise reproducible) straight into the NCHW fp32 gradient.
+// f32 mode (parity) uses v_mfma_f32_32x32x2_f32 with plain ds_read_b32 (channels on the lanes).
+#include "common.hpp"
+#include <string.h>
+#include <vector>
+
+namespace srganfd {
+
+static constexpr int kWgMagic = 0x57475244;  // 'WGRD'
+static constexpr int kTH = 4;                // output rows per pixel tile
+
+struct WgWave { int active, ci_rel, co_rel, ks_idx, ks_n, tap0, slab_base, bias_slab; };
+struct WgGroup { int x_c0, x_units, dy_c0, dy_units; WgWave w[4]; };
+struct WgTask {
+  long long dw_off, db_off, alpha_off;
+  int co_dst, ci_dst, co_base, ci_base, tap0, ntap, ksize, slab_base, nslabs, bias_slab;
+  float alpha, beta;
+};
+struct WgHeader {
+  int magic, dtype, N, Hin, Win, up, ks, stride, pad, Hout, Wout;
+  int ngroups, ntasks, S, x_upad, dy_upad, lds_bytes, ntiles, tiles_x, tiles_y, ntap_wave;
+  long long nslabs_total, bias_slab_off /* floats */, nbias_slabs;
+  long long groups_off, tasks_off, total_bytes;
+};
+
+struct WgK {
+  const void* x; const void* dy; float* slabs; float* bslabs;
+  const WgGroup* groups;
+  int xC, x_c0v, dyC, dy_c0v;
+  int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int swz_f(int upad, int pix) { return upad >= 4 ? (pix & 3) : (upad == 2 ? ((pix >> 1) & 1) : 0); }
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <typename T, int KS, int STRIDE>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(const WgK a) {
+  constexpr int NT = (KS == 4) ? 8 : KS * KS;
+  constexpr int PR = (kTH - 1) * STRIDE + KS, PC = 31 * STRIDE + KS;
+  constexpr int UB = 32 * (int)sizeof(T);   // bytes of one 32-channel unit
+  constexpr int CPU = UB / 16;              // 16-byte chunks per unit
+  constexpr int E16 = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WgGroup& G = a.groups[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WgWave W = G.w[wave];
+  const int r = lane & 31, h = lane >> 5;
+  const int xRowB = a.x_upad * UB, dyRowB = a.dy_upad * UB;
+  char* ldsX = smem;
+  char* ldsY = smem + PR * PC * xRowB;
+  const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ dyg = (const T*)a.dy;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+
+  const int xItems = PR * PC * G.x_units * CPU;
+  const int yItems = kTH * 32 * G.dy_units * CPU;
+  const int rows_per = kTH / W.ks_n;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+    int t = tile;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty * kTH, ox0 = tx * 32;
+    __syncthreads();  // previous tile's LDS reads done
+    for (int item = tid; item < xItems; item += 256) {
+      const int cpp = G.x_units * CPU;
+      const int pix = item / cpp, c16 = item - pix * cpp;
+      const int unit = c16 / CPU, w16 = c16 - unit * CPU;
+      const int py = pix / PC, px = pix - py * PC;
+      const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
+        v = *(const u32x4*)(xg + ((size_t)(n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + a.x_c0v + G.x_c0 + unit * 32 + w16 * E16);
+      const int f = sizeof(T) == 2 ? swz_f(a.x_upad, pix) : 0;
+      *(u32x4*)(ldsX + pix * xRowB + ((unit ^ f) * UB) + w16 * 16) = v;
+    }
+    for (int item = tid; item < yItems; item += 256) {
+      const int cpp = G.dy_units * CPU;
+      const int pix = item / cpp, c16 = item - pix * cpp;
+      const int unit = c16 / CPU, w16 = c16 - unit * CPU;
+      const int py = pix >> 5, px = pix & 31;
+      const int oy = oy0 + py, ox = ox0 + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oy < a.Hout && ox < a.Wout)
+        v = *(const u32x4*)(dyg + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.dyC + a.dy_c0v + G.dy_c0 + unit * 32 + w16 * E16);
+      const int f = sizeof(T) == 2 ? swz_f(a.dy_upad, pix) : 0;
+      *(u32x4*)(ldsY + pix * dyRowB + ((unit ^ f) * UB) + w16 * 16) = v;
+    }
+    __syncthreads();
+    if (W.active) {
+      for (int rr = 0; rr < rows_per; ++rr) {
+        const int ro = W.ks_idx * rows_per + rr;
+        if constexpr (sizeof(T) == 2) {
+          // lane roles of ds_read_b64_tr_b16 inside its 16-lane group: lane 4q+p supplies row q
+          // (pixel), columns 4p..4p+3 (channels); lane i receives channel i of the 4 pixels.
+          const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+          const int chb = (16 * (g & 1) + 4 * pp) * 2;  // byte offset of the 4 channels inside the unit
+#pragma unroll 1
+          for (int hh = 0; hh < 2; ++hh) {
+            const int kc0 = 16 * hh + 8 * (g >> 1) + q;  // output column of this lane's first block row
+            bf16x8 bfrag;
+            {
+              const int p0 = ro * 32 + kc0, p1 = p0 + 4;
+              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p0 * dyRowB + ((W.co_rel ^ swz_f(a.dy_upad, p0)) * UB) + chb));
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p1 * dyRowB + ((W.co_rel ^ swz_f(a.dy_upad, p1)) * UB) + chb));
+              u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                          (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+              bfrag = __builtin_bit_cast(bf16x8, pk);
+              if (W.bias_slab >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += bf2f(pk[j]);
+              }
+            }
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+              const int tap = W.tap0 + tl;
+              const int dy = tap / KS, dx = tap - dy * KS;
+              const int p0 = (ro * STRIDE + dy) * PC + kc0 * STRIDE + dx, p1 = p0 + 4 * STRIDE;
+              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p0 * xRowB + ((W.ci_rel ^ swz_f(a.x_upad, p0)) * UB) + chb));
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p1 * xRowB + ((W.ci_rel ^ swz_f(a.x_upad, p1)) * UB) + chb));
+              u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                          (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+              acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), bfrag, acc[tl], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll 1
+          for (int kk = 0; kk < 16; ++kk) {
+            const int oc = 2 * kk + h;
+            const float bv = *(const float*)(ldsY + (ro * 32 + oc) * dyRowB + (W.co_rel * 32 + r) * 4);
+            if (W.bias_slab >= 0) bsum += bv;
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+              const int tap = W.tap0 + tl;
+              const int dy = tap / KS, dx = tap - dy * KS;
+              const int p = (ro * STRIDE + dy) * PC + oc * STRIDE + dx;
+              const float av = *(const float*)(ldsX + p * xRowB + (W.ci_rel * 32 + r) * 4);
+              acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tl], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (W.active) {
+    float* slab = a.slabs + (size_t)(W.slab_base + blockIdx.x * W.ks_n + W.ks_idx) * (NT * 1024);
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) slab[(tl * 32 + mfma32_row(i, lane)) * 32 + r] = acc[tl][i];
+    if (W.bias_slab >= 0) a.bslabs[(size_t)(W.bias_slab + blockIdx.x * W.ks_n + W.ks_idx) * 64 + lane] = bsum;
+  }
+}
+
+// Deterministic slab reduction + layout change to the NCHW fp32 parameter gradient.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgTask* __restrict__ tasks, const float* __restrict__ slabs,
+                                                           const float* __restrict__ bslabs, float* __restrict__ grads,
+                                                           const float* __restrict__ scalars, int ntap_wave) {
+  const WgTask T = tasks[blockIdx.y];
+  const int KT = T.ksize * T.ksize;
+  float alpha = T.alpha;
+  if (T.alpha_off >= 0) alpha *= scalars[T.alpha_off];
+  const int total = T.ntap * 1024;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int col = e & 31, row = (e >> 5) & 31, tl = e >> 10;
+    const int co = T.co_base + col, ci = T.ci_base + row;
+    if (co < T.co_dst && ci < T.ci_dst) {
+      float s = 0.f;
+      const float* p = slabs + (size_t)T.slab_base * (ntap_wave * 1024) + e;
+      for (int k = 0; k < T.nslabs; ++k) s += p[(size_t)k * (ntap_wave * 1024)];
+      float* d = grads + T.dw_off + ((size_t)co * T.ci_dst + ci) * KT + T.tap0 + tl;
+      *d = alpha * s + (T.beta != 0.f ? T.beta * *d : 0.f);
+    }
+  }
+  if (T.bias_slab >= 0 && T.db_off >= 0 && blockIdx.x == 0 && threadIdx.x < 32) {
+    const int co = T.co_base + threadIdx.x;
+    if (co < T.co_dst) {
+      float s = 0.f;
+      const float* p = bslabs + (size_t)T.bias_slab * 64;
+      for (int k = 0; k < T.nslabs; ++k) s += p[k * 64 + threadIdx.x] + p[k * 64 + 32 + threadIdx.x];
+      float* d = grads + T.db_off + co;
+      *d = alpha * s + (T.beta != 0.f ? T.beta * *d : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: plan construction
+// ------------------------------------------------------------------------------------------------
+static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+struct PlanBuild {
+  std::vector<WgGroup> groups;
+  std::vector<WgTask> tasks;
+  WgHeader hdr;
+};
+
+static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs, PlanBuild& pb) {
+  if (!s || !convs || s->nconv <= 0) return set_err(SRGANFD_EINVAL, "wgrad: null shape/convs");
+  if (!((s->ksize == 3 && s->stride == 1) || (s->ksize == 4 && s->stride == 2) || (s->ksize == 1 && s->stride == 1)))
+    return set_err(SRGANFD_EINVAL, "wgrad: unsupported ksize=%d stride=%d", s->ksize, s->stride);
+  const int hl = s->h_in << (s->up ? 1 : 0), wl = s->w_in << (s->up ? 1 : 0);
+  if ((hl + 2 * s->pad - s->ksize) / s->stride + 1 != s->h_out || (wl + 2 * s->pad - s->ksize) / s->stride + 1 != s->w_out)
+    return set_err(SRGANFD_EINVAL, "wgrad: output dims inconsistent");
+  const int KT = s->ksize * s->ksize;
+  const int NT = s->ksize == 4 ? 8 : KT;
+  const int nth = KT / NT;
+  WgHeader& H = pb.hdr;
+  memset(&H, 0, sizeof(H));
+  H.magic = kWgMagic; H.dtype = s->dtype; H.N = s->n; H.Hin = s->h_in; H.Win = s->w_in; H.up = s->up ? 1 : 0;
+  H.ks = s->ksize; H.stride = s->stride; H.pad = s->pad; H.Hout = s->h_out; H.Wout = s->w_out; H.ntap_wave = NT;
+  H.tiles_x = ceil_div(s->w_out, 32); H.tiles_y = ceil_div(s->h_out, kTH);
+  H.ntiles = s->n * H.tiles_x * H.tiles_y;
+
+  // wave tasks grouped into workgroups of 4 waves that share the staged x / dy channel ranges
+  struct WT { int conv, cb, ob, th, task; };
+  int max_xu = 1, max_yu = 1;
+  for (int c = 0; c < s->nconv; ++c) {
+    const srganfd_wgrad_conv& cv = convs[c];
+    if (cv.cin <= 0 || cv.cin % 32 || cv.cout <= 0 || cv.cout % 32 || cv.ci_lo % 32 || cv.co_lo % 32 ||
+        cv.ci_lo + cv.cin > s->x_channels || cv.co_lo + cv.cout > s->dy_channels)
+      return set_err(SRGANFD_EINVAL, "wgrad: conv %d channel ranges invalid", c);
+    const int cib = cv.cin / 32, cob = cv.cout / 32;
+    // task table (one per 32x32 block and tap half), slab bases filled later
+    const int task0 = (int)pb.tasks.size();
+    for (int ob = 0; ob < cob; ++ob)
+      for (int cb = 0; cb < cib; ++cb)
+        for (int th = 0; th < nth; ++th) {
+          WgTask t; memset(&t, 0, sizeof(t));
+          t.dw_off = cv.dw_off; t.db_off = cv.db_off; t.alpha_off = cv.alpha_off;
+          t.co_dst = cv.co_dst; t.ci_dst = cv.ci_dst; t.co_base = ob * 32; t.ci_base = cb * 32;
+          t.tap0 = th * NT; t.ntap = NT; t.ksize = s->ksize; t.alpha = cv.alpha; t.beta = cv.beta;
+          t.bias_slab = (cb == 0 && th == 0 && cv.db_off >= 0) ? 0 : -1;  // resolved below
+          pb.tasks.push_back(t);
+        }
+    auto task_id = [&](int ob, int cb, int th) { return task0 + (ob * cib + cb) * nth + th; };
+    auto emit = [&](int cb0, int ncb, int ob0, int nob, int ks_n) {
+      // ncb * nob * nth * ks_n wave slots, packed 4 per group
+      std::vector<WgWave> ws;
+      for (int ob = 0; ob < nob; ++ob)
+        for (int cb = 0; cb < ncb; ++cb)
+          for (int th = 0; th < nth; ++th)
+            for (int k = 0; k < ks_n; ++k) {
+              WgWave w; memset(&w, 0, sizeof(w));
+              w.active = 1; w.ci_rel = cb; w.co_rel = ob; w.ks_idx = k; w.ks_n = ks_n; w.tap0 = th * NT;
+              w.slab_base = task_id(ob0 + ob, cb0 + cb, th);  // task id for now
+              ws.push_back(w);
+            }
+      for (size_t i = 0; i < ws.size(); i += 4) {
+        WgGroup g; memset(&g, 0, sizeof(g));
+        g.x_c0 = cv.ci_lo + cb0 * 32; g.x_units = ncb; g.dy_c0 = cv.co_lo + ob0 * 32; g.dy_units = nob;
+        for (int k = 0; k < 4; ++k) {
+          if (i + k < ws.size()) g.w[k] = ws[i + k];
+          else { g.w[k].active = 0; g.w[k].ks_n = 1; g.w[k].bias_slab = -1; }
+        }
+        pb.groups.push_back(g);
+      }
+      if (ncb > max_xu) max_xu = ncb;
+      if (nob > max_yu) max_yu = nob;
+    };
+    if (nth == 2) {  // 4x4 stride 2: two tap halves per block -> (1 ci x 2 co x 2 halves) per group
+      for (int cb = 0; cb < cib; ++cb) {
+        int ob = 0;
+        for (; ob + 2 <= cob; ob += 2) emit(cb, 1, ob, 2, 1);
+        if (ob < cob) emit(cb, 1, ob, 1, 2);
+      }
+    } else if (cob >= 2) {
+      int ob = 0;
+      for (; ob + 2 <= cob; ob += 2) {
+        int cb = 0;
+        for (; cb + 2 <= cib; cb += 2) emit(cb, 2, ob, 2, 1);
+        if (cb < cib) emit(cb, 1, ob, 2, 2);
+      }
+      if (ob < cob) {
+        int cb = 0;
+        for (; cb + 4 <= cib; cb += 4) emit(cb, 4, ob, 1, 1);
+        const int rem = cib - cb;
+        if (rem == 3) emit(cb, 3, ob, 1, 1);
+        else if (rem == 2) emit(cb, 2, ob, 1, 2);
+        else if (rem == 1) emit(cb, 1, ob, 1, 4);
+      }
+    } else {
+      int cb = 0;
+      for (; cb + 4 <= cib; cb += 4) emit(cb, 4, 0, 1, 1);
+      const int rem = cib - cb;
+      if (rem == 3) emit(cb, 3, 0, 1, 1);
+      else if (rem == 2) emit(cb, 2, 0, 1, 2);
+      else if (rem == 1) emit(cb, 1, 0, 1, 4);
+    }
+  }
+  H.ngroups = (int)pb.groups.size();
+  H.ntasks = (int)pb.tasks.size();
+  // pixel-tile splits: aim at ~2 workgroups per CU over the whole launch
+  int S = s->splits;
+  if (S <= 0) { S = (512 + H.ngroups - 1) / H.ngroups; if (S < 1) S = 1; }
+  if (S > H.ntiles) S = H.ntiles;
+  if (S > 4096) S = 4096;
+  H.S = S;
+  // slab allocation: per task S * ks_n slabs
+  std::vector<int> ksn(pb.tasks.size(), 1);
+  for (auto& g : pb.groups)
+    for (int k = 0; k < 4; ++k)
+      if (g.w[k].active) ksn[g.w[k].slab_base] = g.w[k].ks_n;
+  long long slab = 0, bslab = 0;
+  for (size_t t = 0; t < pb.tasks.size(); ++t) {
+    pb.tasks[t].slab_base = (int)slab; pb.tasks[t].nslabs = S * ksn[t];
+    slab += pb.tasks[t].nslabs;
+    if (pb.tasks[t].bias_slab == 0) { pb.tasks[t].bias_slab = (int)bslab; bslab += pb.tasks[t].nslabs; }
+  }
+  if (slab > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "wgrad: too many slabs");
+  for (auto& g : pb.groups)
+    for (int k = 0; k < 4; ++k)
+      if (g.w[k].active) {
+        const WgTask& t = pb.tasks[g.w[k].slab_base];
+        g.w[k].bias_slab = t.bias_slab;
+        g.w[k].slab_base = t.slab_base;
+      }
+  H.nslabs_total = slab; H.nbias_slabs = bslab;
+  H.bias_slab_off = slab * NT * 1024;
+  H.x_upad = pow2ceil(max_xu); H.dy_upad = pow2ceil(max_yu);
+  const int UB = 32 * (s->dtype == SRGANFD_BF16 ? 2 : 4);
+  const int PR = (kTH - 1) * s->stride + s->ksize, PC = 31 * s->stride + s->ksize;
+  H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
+  if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
+  H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
+  H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;
+  H.total_bytes = (H.tasks_off + (long long)sizeof(WgTask) * H.ntasks + 15) & ~15LL;
+  return SRGANFD_OK;
+}
+
+size_t wgrad_plan_bytes_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs) {
+  PlanBuild pb;
+  if (build_plan(s, convs, pb) != SRGANFD_OK) return 0;
+  return (size_t)pb.hdr.total_bytes;
+}
+
+int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs, void* plan_host, size_t plan_bytes,
+                          size_t* workspace_bytes) {
+  PlanBuild pb;
+  int rc = build_plan(s, convs, pb);
+  if (rc != SRGANFD_OK) return rc;
+  if (!plan_host || plan_bytes < (size_t)pb.hdr.total_bytes) return set_err(SRGANFD_ENOSPC, "wgrad: plan buffer too small");
+  memset(plan_host, 0, pb.hdr.total_bytes);
+  memcpy(plan_host, &pb.hdr, sizeof(WgHeader));
+  memcpy((char*)plan_host + pb.hdr.groups_off, pb.groups.data(), sizeof(WgGroup) * pb.groups.size());
+  memcpy((char*)plan_host + pb.hdr.tasks_off, pb.tasks.data(), sizeof(WgTask) * pb.tasks.size());
+  if (workspace_bytes) *workspace_bytes = (size_t)(pb.hdr.bias_slab_off + pb.hdr.nbias_slabs * 64) * sizeof(float);
+  return SRGANFD_OK;
+}
+
+template <typename T, int KS, int STRIDE>
+static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  auto kern = wgrad_kernel<T, KS, STRIDE>;
+  static int attr_lds = 0;
+  if (H.lds_bytes > attr_lds) {
+    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
+    attr_lds = H.lds_bytes;
+  }
+  hipLaunchKernelGGL(kern, dim3(H.S, H.ngroups), dim3(256), H.lds_bytes, stream, k);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads, const float* scalars,
+               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!plan_host || !plan_dev || !x.ptr || !dy.ptr || !grads || !workspace) return set_err(SRGANFD_EINVAL, "wgrad: null pointer");
+  const WgHeader& H = *(const WgHeader*)plan_host;
+  if (H.magic != kWgMagic) return set_err(SRGANFD_EINVAL, "wgrad: bad plan");
+  const size_t need = (size_t)(H.bias_slab_off + H.nbias_slabs * 64) * sizeof(float);
+  if (workspace_bytes < need) return set_err(SRGANFD_ENOSPC, "wgrad: workspace %zu < %zu", workspace_bytes, need);
+  WgK k;
+  k.x = x.ptr; k.dy = dy.ptr; k.slabs = (float*)workspace; k.bslabs = (float*)workspace + H.bias_slab_off;
+  k.groups = (const WgGroup*)((const char*)plan_dev + H.groups_off);
+  k.xC = x.cstride; k.x_c0v = x.c0; k.dyC = dy.cstride; k.dy_c0v = dy.c0;
+  k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
+  k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
+  int rc;
+  const bool bf = H.dtype == SRGANFD_BF16;
+  if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
+  else if (H.ks == 4) rc = bf ? launch_wgrad<bf16_t, 4, 2>(H, k, stream) : launch_wgrad<float, 4, 2>(H, k, stream);
+  else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
+  if (rc != SRGANFD_OK) return rc;
+  const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H.ntap_wave * 1024 + 255) / 256, H.ntasks), dim3(256), 0, stream, tasks_dev,
+                     (const float*)k.slabs, (const float*)k.bslabs, grads, scalars, H.ntap_wave);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+}  // namespace srganfd

@@ -1,0 +1,131 @@
+"""Thin host-side wrappers over the C ABI: weight packing, fused conv, weight gradients.
+
+Host code is plumbing only (device memory, streams); all arithmetic runs in libsrganfd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi as A
+
+DT = {torch.bfloat16: A.BF16, torch.float32: A.F32}
+
+
+def esize(dtype_code: int) -> int:
+    return 2 if dtype_code == A.BF16 else 4
+
+
+def struct_array_to_device(arr, device) -> torch.Tensor:
+    """Upload a ctypes array of PODs; returns the uint8 device tensor that owns the bytes."""
+    raw = bytes(memoryview(arr).cast("B"))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+class PackTable:
+    """A device-resident table of pack jobs (offset based, reusable every step)."""
+
+    def __init__(self, jobs: Sequence[A.PackJob], device):
+        self.n = len(jobs)
+        arr = (A.PackJob * self.n)(*jobs)
+        self.max_elems = max(j.ksize * j.ksize * j.k * j.n for j in jobs)
+        self.dev = struct_array_to_device(arr, device)
+
+    def run(self, params: torch.Tensor, packed: torch.Tensor, scalars: Optional[torch.Tensor] = None):
+        A.check(A.lib().srganfd_pack_weights(self.dev.data_ptr(), self.n, self.max_elems, params.data_ptr(),
+                                             scalars.data_ptr() if scalars is not None else None,
+                                             packed.data_ptr(), A.stream_ptr()), "pack_weights")
+
+
+def pack_job(dst_off: int, dtype: int, ksize: int, k: int, n: int, segs: Sequence[dict]) -> A.PackJob:
+    j = A.PackJob()
+    j.dst_off, j.dtype, j.ksize, j.k, j.n, j.nseg = dst_off, dtype, ksize, k, n, len(segs)
+    assert 1 <= len(segs) <= 5 and dst_off % 16 == 0
+    for i, s in enumerate(segs):
+        g = j.seg[i]
+        g.src_off = s["src_off"]; g.scale_off = s.get("scale_off", -1)
+        g.co_src, g.ci_src = s["co_src"], s["ci_src"]
+        g.k_lo, g.k_len = s.get("k_lo", 0), s["k_len"]
+        g.co_off, g.ci_off = s.get("co_off", 0), s.get("ci_off", 0)
+        g.transposed = s.get("transposed", 0); g.scale = s.get("scale", 1.0)
+    return j
+
+
+def packed_bytes(dtype: int, ksize: int, k: int, n: int) -> int:
+    return ksize * ksize * k * n * esize(dtype)
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def pack_single(weight: torch.Tensor, dtype: int, transposed: bool = False, scale: float = 1.0) -> torch.Tensor:
+    """Pack one (Cout, Cin, k, k) fp32 weight for conv2d (forward) or for its data gradient."""
+    co, ci, kh, kw = weight.shape
+    assert kh == kw
+    k, n = (pad32(co), pad32(ci)) if transposed else (pad32(ci), pad32(co))
+    out = torch.empty(packed_bytes(dtype, kh, k, n), dtype=torch.uint8, device=weight.device)
+    w = weight.detach().contiguous().float()
+    job = pack_job(0, dtype, kh, k, n, [dict(src_off=0, co_src=co, ci_src=ci, k_len=k, transposed=int(transposed), scale=scale)])
+    PackTable([job], weight.device).run(w, out)
+    return out
+
+
+def conv_args(dtype: int, x: A.View, y: A.View, w_packed, n: int, h_in: int, w_in: int, cin: int, cout: int, *,
+              cout_store: Optional[int] = None, ksize: int = 3, stride: int = 1, pad: int = 1, up: int = 0,
+              bias=None, act: int = A.ACT_NONE, slope: float = 0.2, alpha: float = 1.0, post_scale: float = 1.0,
+              r1: A.View = A.NULL_VIEW, r1_scale: float = 0.0, r2: A.View = A.NULL_VIEW, r2_scale: float = 0.0,
+              mask: A.View = A.NULL_VIEW, mask_slope: float = 0.2, alpha_dev=None, y_f32: bool = False) -> A.ConvArgs:
+    a = A.ConvArgs()
+    a.dtype, a.n, a.h_in, a.w_in, a.up = dtype, n, h_in, w_in, up
+    a.ksize, a.stride, a.pad, a.cin, a.cout = ksize, stride, pad, cin, cout
+    a.cout_store = cout if cout_store is None else cout_store
+    hl, wl = h_in << up, w_in << up
+    a.h_out, a.w_out = (hl + 2 * pad - ksize) // stride + 1, (wl + 2 * pad - ksize) // stride + 1
+    a.x, a.y, a.r1, a.r2, a.mask = x, y, r1, r2, mask
+    a.w_packed = w_packed if isinstance(w_packed, int) else w_packed.data_ptr()
+    a.bias = None if bias is None else (bias if isinstance(bias, int) else bias.data_ptr())
+    a.alpha_dev = None if alpha_dev is None else (alpha_dev if isinstance(alpha_dev, int) else alpha_dev.data_ptr())
+    a.alpha, a.slope, a.post_scale, a.r1_scale, a.r2_scale, a.mask_slope = alpha, slope, post_scale, r1_scale, r2_scale, mask_slope
+    a.act, a.y_f32 = act, int(y_f32)
+    return a
+
+
+def conv2d(args: A.ConvArgs) -> None:
+    A.check(A.lib().srganfd_conv2d(C.byref(args), A.stream_ptr()), "conv2d")
+
+
+class WgradPlan:
+    """Host+device plan of one weight-gradient launch (several convs sharing x and dy)."""
+
+    def __init__(self, device, dtype: int, n: int, h_in: int, w_in: int, x_channels: int, dy_channels: int,
+                 convs: Sequence[dict], ksize: int = 3, stride: int = 1, pad: int = 1, up: int = 0, splits: int = 0):
+        hl, wl = h_in << up, w_in << up
+        s = A.WgradShape(dtype, n, h_in, w_in, up, ksize, stride, pad, (hl + 2 * pad - ksize) // stride + 1,
+                         (wl + 2 * pad - ksize) // stride + 1, x_channels, dy_channels, len(convs), splits)
+        carr = (A.WgradConv * len(convs))()
+        for i, c in enumerate(convs):
+            w = carr[i]
+            w.ci_lo, w.cin, w.co_lo, w.cout = c.get("ci_lo", 0), c["cin"], c.get("co_lo", 0), c["cout"]
+            w.dw_off, w.db_off = c["dw_off"], c.get("db_off", -1)
+            w.co_dst, w.ci_dst = c["co_dst"], c["ci_dst"]
+            w.alpha, w.beta, w.alpha_off = c.get("alpha", 1.0), c.get("beta", 0.0), c.get("alpha_off", -1)
+        L = A.lib()
+        nbytes = L.srganfd_wgrad_plan_bytes(C.byref(s), carr)
+        if nbytes == 0:
+            raise A.SrganfdError("wgrad plan: " + L.srganfd_last_error().decode())
+        self.host = C.create_string_buffer(nbytes)
+        ws = C.c_size_t(0)
+        A.check(L.srganfd_wgrad_plan_build(C.byref(s), carr, self.host, nbytes, C.byref(ws)), "wgrad_plan_build")
+        self.workspace_bytes = ws.value
+        self.dev = torch.frombuffer(bytearray(self.host.raw), dtype=torch.uint8).to(device)
+
+    def run(self, x: A.View, dy: A.View, grads: torch.Tensor, workspace: torch.Tensor,
+            scalars: Optional[torch.Tensor] = None) -> None:
+        assert workspace.numel() * workspace.element_size() >= self.workspace_bytes
+        A.check(A.lib().srganfd_conv2d_wgrad(self.host, self.dev.data_ptr(), x, dy, grads.data_ptr(),
+                                             scalars.data_ptr() if scalars is not None else None,
+                                             workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                             A.stream_ptr()), "conv2d_wgrad")

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+This is the only file in the repository that reads /root/reference.  The reference needs
+``torchvision`` (absent here) only for ContentLoss, so empty stub modules are injected before the
+import; nothing of the reference is copied -- only inputs/outputs (data) are saved.
+Weights are NOT stored (too large): every fixture is built under ``torch.manual_seed(seed)`` with
+the reference's own constructors, and the tests rebuild identical weights from the same seed with
+this repository's module containers; per-tensor checksums stored here prove the rebuild is exact.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("SRGAN_REFERENCE", "/root/reference")
+
+
+def _stub_torchvision():
+    for name in ("torchvision", "torchvision.models", "torchvision.transforms",
+                 "torchvision.models.feature_extraction"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.models.feature_extraction"].create_feature_extractor = None
+
+
+def load_ref(subdir):
+    _stub_torchvision()
+    path = os.path.join(REF, subdir)
+    sys.path.insert(0, path)
+    try:
+        sys.modules.pop("model", None)
+        mod = importlib.import_module("model")
+    finally:
+        sys.path.remove(path)
+        sys.modules.pop("model", None)
+    return mod
+
+
+def checksum(t):
+    """(sum, abs-sum, position-weighted sum) in float64 -- catches value AND ordering errors."""
+    a = t.detach().double().flatten()
+    w = torch.cos(torch.arange(a.numel(), dtype=torch.float64) * 0.37)
+    return np.array([a.sum().item(), a.abs().sum().item(), (a * w).sum().item()])
+
+
+def sd_checksums(sd):
+    return {k: checksum(v) for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+
+
+def scaled_init(g, scale, bias):
+    """SURVEY 8c init recipe: default init is degenerate (SR std 5e-5, 35 % clamped)."""
+    with torch.no_grad():
+        for p in g.parameters():
+            if p.dim() == 4:
+                p.mul_(scale)
+        g.conv4.bias.fill_(bias)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):  # checksum tables: one (n,3) array + the key list
+            flat[k] = np.stack([np.asarray(vv) for vv in v.values()]) if v else np.zeros((0, 3))
+            flat[k + "__keys"] = np.array(list(v.keys()))
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} kB, {len(flat)} arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def gold_blocks(M):
+    out = {}
+    for kind, ctor in (("rdb", M._ResidualDenseBlock), ("rrdb", M._ResidualResidualDenseBlock)):
+        torch.manual_seed(0)
+        blk = ctor(64, 32)
+        x = torch.randn(1, 64, 16, 16, requires_grad=True)
+        r = torch.randn(1, 64, 16, 16)
+        y = blk(x)
+        (y * r).sum().backward()
+        out[f"{kind}_x"] = np_(x)
+        out[f"{kind}_r"] = np_(r)
+        out[f"{kind}_y"] = np_(y)
+        out[f"{kind}_dx"] = np_(x.grad)
+        out[f"{kind}_wsum"] = sd_checksums(blk.state_dict())
+        out[f"{kind}_gsum"] = {k: checksum(p.grad) for k, p in blk.named_parameters()}
+        first = "conv1" if kind == "rdb" else "rdb1.conv1"
+        last = "conv5" if kind == "rdb" else "rdb3.conv5"
+        named = dict(blk.named_parameters())
+        out[f"{kind}_g_first_w"] = np_(named[first + ".weight"].grad)
+        out[f"{kind}_g_last_b"] = np_(named[last + ".bias"].grad)
+    save("blocks.npz", **out)
+
+
+def gold_generator(MB, ME):
+    out = {}
+    cases = [
+        ("bsrgan_x4_r2_s3", MB.bsrgan_x4, dict(num_rrdb=2), 4, 3.0, (2, 3, 16, 16)),
+        ("bsrgan_x2_r2_s3", MB.bsrgan_x2, dict(num_rrdb=2), 2, 3.0, (2, 3, 16, 16)),
+        ("bsrgan_x4_r2_s5", MB.bsrgan_x4, dict(num_rrdb=2), 4, 5.0, (2, 3, 16, 16)),
+        ("rrdbnet_x4_r23_s3", ME.rrdbnet_x4, dict(num_blocks=23), 4, 3.0, (1, 3, 16, 16)),
+        ("bsrgan_x4_r23_s3_odd", MB.bsrgan_x4, dict(num_rrdb=23), 4, 3.0, (1, 3, 12, 20)),
+    ]
+    for name, fac, kw, s, scale, shape in cases:
+        torch.manual_seed(0)
+        g = fac(in_channels=3, out_channels=3, channels=64, growth_channels=32, **kw)
+        scaled_init(g, scale, 0.5)
+        x = torch.rand(*shape)
+        gt = torch.rand(shape[0], 3, shape[2] * s, shape[3] * s)
+        sr = g(x)
+        loss = torch.nn.functional.l1_loss(sr, gt)
+        loss.backward()
+        out[f"{name}/x"] = np_(x)
+        out[f"{name}/gt"] = np_(gt)
+        out[f"{name}/sr"] = np_(sr)
+        out[f"{name}/loss"] = np.array(loss.item())
+        out[f"{name}/clamped01"] = np.array([(sr == 0).float().mean().item(), (sr == 1).float().mean().item()])
+        named = dict(g.named_parameters())
+        out[f"{name}/wsum"] = sd_checksums(g.state_dict())
+        out[f"{name}/gsum"] = {k: checksum(p.grad) for k, p in named.items()}
+        for k in ("conv1.weight", "conv4.weight", "conv4.bias", "trunk.0.rdb1.conv1.bias",
+                  "trunk.1.rdb3.conv5.bias", "conv2.bias"):
+            out[f"{name}/grad/{k}"] = np_(named[k].grad)
+    save("generator.npz", **out)
+
+
+def gold_discriminator(MB):
+    out = {}
+    torch.manual_seed(0)
+    d = MB.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    x = torch.rand(2, 3, 64, 64)
+    out["x"] = np_(x)
+    out["wsum0"] = sd_checksums(d.state_dict())
+    d.train()
+    for it in range(3):
+        logits = d(x)
+        out[f"train{it}_logits"] = np_(logits)
+        sd = d.state_dict()
+        for layer in ("down_block1", "up_block1", "conv3"):
+            out[f"train{it}_{layer}_u"] = np_(sd[f"{layer}.0.weight_u"])
+            out[f"train{it}_{layer}_v"] = np_(sd[f"{layer}.0.weight_v"])
+        out[f"train{it}_uvsum"] = {k: checksum(v) for k, v in sd.items() if k.endswith(("_u", "_v"))}
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    loss.backward()
+    out["bce_ones"] = np.array(loss.item())
+    named = dict(d.named_parameters())
+    out["gsum"] = {k: checksum(p.grad) for k, p in named.items()}
+    out["grad/conv1.weight"] = np_(named["conv1.weight"].grad)
+    out["grad/conv4.weight"] = np_(named["conv4.weight"].grad)
+    out["grad/conv4.bias"] = np_(named["conv4.bias"].grad)
+    out["grad/conv3.0.weight_orig"] = np_(named["conv3.0.weight_orig"].grad)
+    d.eval()
+    with torch.no_grad():
+        out["eval_logits"] = np_(d(x))
+    # input gradient (needed by the generator's adversarial term): dgrad-only pass
+    d.train()
+    xin = x.clone().requires_grad_(True)
+    for p in d.parameters():
+        p.requires_grad = False
+    lg = d(xin)
+    torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    out["train3_dx"] = np_(xin.grad)
+    out["train3_logits"] = np_(lg)
+    save("discriminator.npz", **out)
+
+
+def gold_gan_steps(MB):
+    """Two iterations of BSRGAN/train_bsrgan.py:387-483 with the reference modules, torch.optim.Adam,
+    AveragedModel and an (inert on CPU) GradScaler; content loss stubbed to zeros (no VGG weights)."""
+    from torch.optim.swa_utils import AveragedModel
+    out = {}
+    torch.manual_seed(0)
+    d = MB.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    g = MB.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(g, 3.0, 0.5)
+    decay = 0.999
+    ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - decay) * a + decay * p)
+    d_opt = torch.optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)
+    g_opt = torch.optim.Adam(g.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
+    bce = torch.nn.BCEWithLogitsLoss()
+    l1 = torch.nn.L1Loss()
+    pw, cw, aw = torch.Tensor([20.0]), torch.Tensor([1.0]), torch.Tensor([0.5])
+    d.train()
+    g.train()
+    B, h = 2, 16
+    out["wsum_g0"] = sd_checksums(g.state_dict())
+    out["wsum_d0"] = sd_checksums(d.state_dict())
+    for it in range(2):
+        lr = torch.rand(B, 3, h, h)
+        gt = torch.rand(B, 3, 4 * h, 4 * h)
+        out[f"it{it}_lr"] = np_(lr)
+        out[f"it{it}_gt"] = np_(gt)
+        real = torch.full([B, 1, 4 * h, 4 * h], 1.0)
+        fake = torch.full([B, 1, 4 * h, 4 * h], 0.0)
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        d_loss_hr = bce(gt_output, real)
+        d_loss_hr.backward(retain_graph=True)
+        sr = g(lr)
+        sr_output = d(sr.detach().clone())
+        d_loss_sr = bce(sr_output, fake)
+        d_loss_sr.backward()
+        d_loss = d_loss_hr + d_loss_sr
+        d_opt.step()
+        for p in d.parameters():
+            p.requires_grad = False
+        g.zero_grad(set_to_none=True)
+        pixel = l1(sr, gt)
+        content = torch.zeros(1, 5)
+        adv = bce(d(sr), real)
+        pixel = torch.sum(torch.mul(pw, pixel))
+        content = torch.sum(torch.mul(cw, content))
+        adv = torch.sum(torch.mul(aw, adv))
+        g_loss = pixel + content + adv
+        g_loss.backward()
+        g_opt.step()
+        ema.update_parameters(g)
+        out[f"it{it}_scalars"] = np.array([d_loss.item(), pixel.item(), content.item(), adv.item(),
+                                          torch.sigmoid(gt_output.detach()).mean().item(),
+                                          torch.sigmoid(sr_output.detach()).mean().item()])
+        out[f"it{it}_sr"] = np_(sr)
+        out[f"it{it}_wsum_g"] = sd_checksums(g.state_dict())
+        out[f"it{it}_wsum_d"] = sd_checksums(d.state_dict())
+        out[f"it{it}_wsum_ema"] = sd_checksums(ema.state_dict())
+        out[f"it{it}_g_conv4_bias"] = np_(g.conv4.bias)
+        out[f"it{it}_d_conv4_weight"] = np_(d.conv4.weight)
+    save("gan_steps.npz", **out)
+
+
+def gold_g_only_steps(MB, ME):
+    """Two generator-only iterations: ESRGAN/train_rrdbnet.py:244-267 (Adam eps 1e-8, betas .9/.99, lr 2e-4)
+    and BSRGAN/train_bsrnet.py:244-272 (eps 1e-4, lr 1e-4); cfg1 = BASELINE.json configs[0]."""
+    out = {}
+    cases = [
+        ("esrgan_small", ME.rrdbnet_x4, dict(num_blocks=2), (2, 16), 2e-4, (0.9, 0.99), 1e-8, 3.0),
+        ("bsrnet_small", MB.bsrgan_x4, dict(num_rrdb=2), (2, 16), 1e-4, (0.9, 0.99), 1e-4, 3.0),
+        ("cfg1_esrgan_b4_32", ME.rrdbnet_x4, dict(num_blocks=23), (4, 32), 2e-4, (0.9, 0.99), 1e-8, 3.0),
+    ]
+    for name, fac, kw, (B, h), lr_, betas, eps, scale in cases:
+        torch.manual_seed(0)
+        g = fac(in_channels=3, out_channels=3, channels=64, growth_channels=32, **kw)
+        scaled_init(g, scale, 0.5)
+        opt = torch.optim.Adam(g.parameters(), lr_, betas, eps, 0.0)
+        losses = []
+        for it in range(2):
+            lr = torch.rand(B, 3, h, h)
+            gt = torch.rand(B, 3, 4 * h, 4 * h)
+            if B * h * h <= 1024:
+                out[f"{name}/it{it}_lr"] = np_(lr)
+                out[f"{name}/it{it}_gt"] = np_(gt)
+            g.zero_grad(set_to_none=True)
+            sr = g(lr)
+            loss = torch.mul(1.0, torch.nn.functional.l1_loss(sr, gt))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            out[f"{name}/it{it}_wsum"] = sd_checksums(g.state_dict())
+            if B * h * h <= 1024:
+                out[f"{name}/it{it}_sr"] = np_(sr)
+        out[f"{name}/losses"] = np.array(losses)
+        out[f"{name}/conv4_bias"] = np_(g.conv4.bias)
+    save("g_only_steps.npz", **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    MB = load_ref("BSRGAN")
+    ME = load_ref("ESRGAN")
+    gold_blocks(MB)
+    gold_generator(MB, ME)
+    gold_discriminator(MB)
+    gold_gan_steps(MB)
+    gold_g_only_steps(MB, ME)
+
+
+if __name__ == "__main__":
+    main()

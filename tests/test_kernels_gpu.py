@@ -1,0 +1,202 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against CPU torch ops.
+
+f32 mode (v_mfma_f32_32x32x2_f32, exact fp32 fma chain): rel tolerance 2e-5.
+bf16 mode (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the oracle is fed the SAME bf16-rounded
+inputs/weights, so only accumulation order and the final bf16 store differ: tolerance 1e-2 of the
+output scale (bf16 has 8 bits of mantissa -> 3.9e-3 per rounding).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1e-2
+
+
+def _rt(t, dtype):
+    """round-trip through the storage dtype (what the kernel sees)"""
+    return t.to(dtype).to(torch.float64)
+
+
+def _assert_close(got, want, dtype, what):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item() / scale
+    assert err < _tol(dtype), f"{what}: max err / scale = {err:.3e} (scale {scale:.3e})"
+
+
+def _nhwc(t, dtype, cbuf=None, c0=0):
+    """NCHW cpu tensor -> NHWC cuda buffer with cbuf channels, data at [c0, c0+C)"""
+    n, c, h, w = t.shape
+    cbuf = cbuf or c
+    buf = torch.randn(n, h, w, cbuf) * 3.0  # garbage outside the view: must not be read
+    buf[..., c0:c0 + c] = t.permute(0, 2, 3, 1)
+    return buf.to(dtype).cuda()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(n=2, h=16, w=16, cin=64, cout=32, act=1, bias=True),
+    dict(n=1, h=12, w=20, cin=96, cout=32, act=1, bias=True),               # ragged tile edges
+    dict(n=1, h=9, w=37, cin=192, cout=64, res=True, bias=True),            # conv5 + 2 residuals
+    dict(n=1, h=8, w=8, cin=64, cout=64, up=1, act=1, bias=True),           # nearest x2 fused
+    dict(n=1, h=16, w=16, cin=64, cout=3, bias=True, y_f32=True),           # padded cout, fp32 out
+    dict(n=1, h=16, w=16, cin=3, cout=64, bias=True),                       # padded cin
+    dict(n=1, h=16, w=24, cin=64, cout=128, k=4, s=2, act=1),               # discriminator down block
+    dict(n=1, h=8, w=8, cin=512, cout=256, act=1),                          # wide channels
+    dict(n=1, h=8, w=8, cin=64, cout=32, k=1, p=0, bias=True),              # 1x1
+    dict(n=1, h=16, w=16, cin=64, cout=32, mask=True),                      # LeakyReLU' mask epilogue
+])
+def test_conv2d_forward(dtype, case):
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(1)
+    dt = ops.DT[dtype]
+    n, h, w, cin, cout = case["n"], case["h"], case["w"], case["cin"], case["cout"]
+    k, s, p, up = case.get("k", 3), case.get("s", 1), case.get("p", 1), case.get("up", 0)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    b = torch.randn(cout) if case.get("bias") else None
+    cin_p, cout_p = ops.pad32(cin), ops.pad32(cout)
+    xin = torch.zeros(n, cin_p, h, w); xin[:, :cin] = x
+    xbuf = _nhwc(xin, dtype, cbuf=cin_p + 32, c0=32)
+    wp = ops.pack_single(wt.cuda(), dt)
+    hl, wl = h << up, w << up
+    ho, wo = (hl + 2 * p - k) // s + 1, (wl + 2 * p - k) // s + 1
+    ybuf_c, y_c0 = 96 if cout <= 64 else cout + 32, 32
+    y_f32 = case.get("y_f32", False)
+    ybuf = torch.full((n, ho, wo, ybuf_c), 7.0, dtype=torch.float32 if y_f32 else dtype, device="cuda")
+    kw = dict(ksize=k, stride=s, pad=p, up=up, cout_store=cout, act=case.get("act", 0), y_f32=y_f32,
+              bias=b.cuda() if b is not None else None)
+    ref_in = _rt(x, dtype)
+    if up:
+        ref_in = F.interpolate(ref_in, scale_factor=2, mode="nearest")
+    ref = F.conv2d(ref_in, _rt(wt, dtype), b.double() if b is not None else None, stride=s, padding=p)
+    if case.get("act") == 1:
+        ref = F.leaky_relu(ref, 0.2)
+    keep = []
+    if case.get("res"):
+        r1 = torch.randn(n, cout, ho, wo); r2 = torch.randn(n, cout, ho, wo)
+        r1b, r2b = _nhwc(r1, dtype, cbuf=cout + 32, c0=32), _nhwc(r2, dtype)
+        keep += [r1b, r2b]
+        kw.update(post_scale=0.04, r1=A.view(r1b, c0=32), r1_scale=0.2, r2=A.view(r2b), r2_scale=1.0)
+        ref = ref * 0.04 + 0.2 * _rt(r1, dtype) + _rt(r2, dtype)
+    if case.get("mask"):
+        m = torch.randn(n, cout, ho, wo)
+        mb = _nhwc(m, dtype)
+        keep.append(mb)
+        kw.update(mask=A.view(mb), mask_slope=0.2)
+        ref = ref * torch.where(_rt(m, dtype) > 0, 1.0, 0.2)
+    args = ops.conv_args(dt, A.view(xbuf, c0=32), A.view(ybuf, c0=y_c0), wp, n, h, w, cin_p, cout_p, **kw)
+    ops.conv2d(args)
+    torch.cuda.synchronize()
+    got = ybuf[..., y_c0:y_c0 + cout].permute(0, 3, 1, 2)
+    _assert_close(got, ref, dtype, f"conv {case}")
+    # nothing outside the output view may be touched
+    assert torch.all(ybuf[..., :y_c0] == 7.0) and torch.all(ybuf[..., y_c0 + cout:] == 7.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_dgrad_orientation(dtype):
+    """weights packed with transposed=1 turn the same kernel into the data-gradient pass"""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(2)
+    dt = ops.DT[dtype]
+    n, h, w, cin, cout = 1, 12, 20, 96, 32
+    x = torch.randn(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3) / 30
+    dy = torch.randn(n, cout, h, w)
+    F.conv2d(x, _rt(wt, dtype), None, padding=1).backward(_rt(dy, dtype))
+    wp = ops.pack_single(wt.cuda(), dt, transposed=True)
+    dyb = _nhwc(dy, dtype)
+    dxb = torch.zeros(n, h, w, cin, dtype=dtype, device="cuda")
+    ops.conv2d(ops.conv_args(dt, A.view(dyb), A.view(dxb), wp, n, h, w, cout, cin))
+    torch.cuda.synchronize()
+    _assert_close(dxb.permute(0, 3, 1, 2), x.grad, dtype, "dgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(n=2, h=16, w=16, cin=64, cout=32),
+    dict(n=1, h=10, w=37, cin=96, cout=32),
+    dict(n=1, h=12, w=20, cin=160, cout=32),
+    dict(n=2, h=8, w=40, cin=192, cout=64),
+    dict(n=1, h=8, w=8, cin=64, cout=64, up=1),
+    dict(n=1, h=16, w=16, cin=3, cout=64),
+    dict(n=1, h=16, w=16, cin=64, cout=3),
+    dict(n=1, h=16, w=24, cin=64, cout=128, k=4, s=2),
+    dict(n=3, h=8, w=8, cin=256, cout=128, splits=3),
+])
+def test_conv2d_wgrad(dtype, case):
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(3)
+    dt = ops.DT[dtype]
+    n, h, w, cin, cout = case["n"], case["h"], case["w"], case["cin"], case["cout"]
+    k, s, p, up = case.get("k", 3), case.get("s", 1), 1, case.get("up", 0)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    xin = _rt(x, dtype)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    y = F.conv2d(xin, wt, b, stride=s, padding=p)
+    dy = torch.randn_like(y).float()
+    y.backward(_rt(dy, dtype))
+    cin_p, cout_p = ops.pad32(cin), ops.pad32(cout)
+    xpad = torch.zeros(n, cin_p, h, w); xpad[:, :cin] = x
+    dypad = torch.zeros(n, cout_p, *dy.shape[2:]); dypad[:, :cout] = dy
+    xb, dyb = _nhwc(xpad, dtype, cbuf=cin_p + 32, c0=32), _nhwc(dypad, dtype, cbuf=cout_p + 32, c0=0)
+    grads = torch.full((cout * cin * k * k + cout + 8,), 5.0, device="cuda")
+    plan = ops.WgradPlan("cuda", dt, n, h, w, cin_p, cout_p,
+                         [dict(cin=cin_p, cout=cout_p, dw_off=8, db_off=8 + cout * cin * k * k, co_dst=cout, ci_dst=cin,
+                               alpha=0.5)], ksize=k, stride=s, pad=p, up=up, splits=case.get("splits", 0))
+    ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
+    plan.run(A.view(xb, c0=32), A.view(dyb, c0=0), grads, ws)
+    torch.cuda.synchronize()
+    dw = grads[8:8 + cout * cin * k * k].view(cout, cin, k, k)
+    db = grads[8 + cout * cin * k * k:]
+    tol_dtype = dtype
+    _assert_close(dw, 0.5 * wt.grad, tol_dtype, f"wgrad dW {case}")
+    _assert_close(db, 0.5 * b.grad, tol_dtype, f"wgrad db {case}")
+    assert torch.all(grads[:8] == 5.0)
+    # run twice with beta=1 semantics covered in the dense-block test; determinism: bitwise equal
+    g2 = torch.full_like(grads, 5.0)
+    plan.run(A.view(xb, c0=32), A.view(dyb, c0=0), g2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(grads, g2), "wgrad must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_dense_block_fused(dtype):
+    """five convs of a dense block (shared x = concat buffer, shared dy = stacked gradients) in one launch"""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(4)
+    dt = ops.DT[dtype]
+    n, h, w = 1, 12, 36
+    cat = torch.randn(n, 192, h, w)
+    dyall = torch.randn(n, 192, h, w)  # [dY5(64) | dY4 | dY3 | dY2 | dY1]
+    convs, refs, off = [], [], 0
+    lo = {5: 0, 4: 64, 3: 96, 2: 128, 1: 160}
+    for kk in (1, 2, 3, 4, 5):
+        cin, cout = 64 + 32 * (kk - 1), (64 if kk == 5 else 32)
+        wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(_rt(cat[:, :cin], dtype), wt, b, padding=1)
+        y.backward(_rt(dyall[:, lo[kk]:lo[kk] + cout], dtype))
+        convs.append(dict(ci_lo=0, cin=cin, co_lo=lo[kk], cout=cout, dw_off=off, db_off=off + wt.numel(),
+                          co_dst=cout, ci_dst=cin, beta=1.0))
+        refs.append((off, wt.grad, b.grad))
+        off += wt.numel() + cout
+    grads = torch.ones(off, device="cuda")
+    plan = ops.WgradPlan("cuda", dt, n, h, w, 192, 192, convs)
+    ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
+    plan.run(A.view(_nhwc(cat, dtype)), A.view(_nhwc(dyall, dtype)), grads, ws)
+    torch.cuda.synchronize()
+    for o, gw, gb in refs:
+        _assert_close(grads[o:o + gw.numel()].view_as(gw) - 1.0, gw, dtype, "fused dW")
+        _assert_close(grads[o + gw.numel():o + gw.numel() + gb.numel()] - 1.0, gb, dtype, "fused db")
