@@ -1,0 +1,202 @@
+"""Drop-in mirror of the reference's ``model.py`` module surface, running on hand-written HIP kernels.
+
+Same names, constructor kwargs, ``state_dict`` keys/shapes (NCHW fp32 parameters) and ``nn.Module``
+protocol as ``BSRGAN/model.py`` (BSRGAN :311-384, DiscriminatorUNet :91-167, ContentLoss :501-554,
+factories :557-593) and ``ESRGAN/model.py`` (RRDBNet :144-243, factories :301-322), so that
+``model.__dict__[cfg.g_model_arch_name](**kwargs)`` (train_bsrgan.py:274-285), ``AveragedModel``
+deep copies, pickling and ``utils.load_state_dict`` keep working.
+
+The sub-modules (``nn.Conv2d``, ``spectral_norm``) are used ONLY as parameter containers: they give
+the reference's parameter names, shapes, construction order and therefore the same RNG stream at
+init.  Their ``forward`` is never called -- ``forward`` here hands the parameters to the HIP engine
+(``engine.py``), which raises if libsrganfd_hip.so or a GPU is missing (no CPU fallback).
+
+Knobs beyond the reference (all optional, defaults keep reference behaviour):
+  ``compute_dtype``  torch.bfloat16 (default on GPU; the reference trains under autocast) or
+                     torch.float32 (exact-fp32 MFMA "parity mode" used against the CPU oracle).
+"""
+from __future__ import annotations
+
+from typing import Any, List
+
+import torch
+from torch import Tensor, nn
+from torch.nn.utils import spectral_norm
+
+__all__ = [
+    "DiscriminatorUNet", "BSRGAN", "RRDBNet", "ContentLoss",
+    "discriminator_unet", "bsrgan_x2", "bsrgan_x4", "content_loss",
+    "rrdbnet_x1", "rrdbnet_x2", "rrdbnet_x4", "rrdbnet_x8",
+]
+
+
+class _ResidualDenseBlock(nn.Module):
+    """Parameter container of BSRGAN/model.py:31-62; standalone forward = a 1-block trunk on the GPU."""
+
+    def __init__(self, channels: int, growth_channels: int) -> None:
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels + growth_channels * 0, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv2 = nn.Conv2d(channels + growth_channels * 1, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv3 = nn.Conv2d(channels + growth_channels * 2, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv4 = nn.Conv2d(channels + growth_channels * 3, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv5 = nn.Conv2d(channels + growth_channels * 4, channels, (3, 3), (1, 1), (1, 1))
+        self.leaky_relu = nn.LeakyReLU(0.2, True)
+        self.identity = nn.Identity()
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .engine import trunk_apply
+        return trunk_apply(self, x, [self], rrdb=False)
+
+
+class _ResidualResidualDenseBlock(nn.Module):
+    """Parameter container of BSRGAN/model.py:65-88."""
+
+    def __init__(self, channels: int, growth_channels: int) -> None:
+        super().__init__()
+        self.rdb1 = _ResidualDenseBlock(channels, growth_channels)
+        self.rdb2 = _ResidualDenseBlock(channels, growth_channels)
+        self.rdb3 = _ResidualDenseBlock(channels, growth_channels)
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .engine import trunk_apply
+        return trunk_apply(self, x, [self.rdb1, self.rdb2, self.rdb3], rrdb=True)
+
+
+class _RRDBGenerator(nn.Module):
+    """Shared body of BSRGAN (BSRGAN/model.py:311-384) and RRDBNet (ESRGAN/model.py:144-243)."""
+
+    def __init__(self, in_channels: int, out_channels: int, channels: int, growth_channels: int,
+                 num_blocks: int, upscale_factor: int, always_up1: bool) -> None:
+        super().__init__()
+        self.upscale_factor = upscale_factor
+        self.conv1 = nn.Conv2d(in_channels, channels, (3, 3), (1, 1), (1, 1))
+        self.trunk = nn.Sequential(*[_ResidualResidualDenseBlock(channels, growth_channels) for _ in range(num_blocks)])
+        self.conv2 = nn.Conv2d(channels, channels, (3, 3), (1, 1), (1, 1))
+        n_up = {1: 0, 2: 1, 4: 2, 8: 3}[upscale_factor]
+        if always_up1:               # BSRGAN builds upsampling1 unconditionally (model.py:337-340)
+            n_up = max(n_up, 1)
+        for u in range(1, n_up + 1):
+            setattr(self, f"upsampling{u}", nn.Sequential(
+                nn.Conv2d(channels, channels, (3, 3), (1, 1), (1, 1)), nn.LeakyReLU(0.2, True)))
+        self.conv3 = nn.Sequential(nn.Conv2d(channels, channels, (3, 3), (1, 1), (1, 1)), nn.LeakyReLU(0.2, True))
+        self.conv4 = nn.Conv2d(channels, out_channels, (3, 3), (1, 1), (1, 1))
+        # BSRGAN/model.py:358-363, ESRGAN/model.py:236-242
+        for module in self.modules():
+            if isinstance(module, nn.Conv2d):
+                nn.init.kaiming_normal_(module.weight)
+                module.weight.data *= 0.1
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.compute_dtype = torch.bfloat16
+
+    def n_upsample(self) -> int:
+        return {1: 0, 2: 1, 4: 2, 8: 3}[self.upscale_factor]
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._forward_impl(x)
+
+    def _forward_impl(self, x: Tensor) -> Tensor:
+        from .engine import generator_apply
+        return generator_apply(self, x)
+
+
+class BSRGAN(_RRDBGenerator):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, channels: int = 64, growth_channels: int = 32,
+                 num_rrdb: int = 23, upscale_factor: int = 4) -> None:
+        super().__init__(in_channels, out_channels, channels, growth_channels, num_rrdb, upscale_factor, always_up1=True)
+
+
+class RRDBNet(_RRDBGenerator):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, channels: int = 64, growth_channels: int = 32,
+                 num_blocks: int = 23, upscale_factor: int = 4) -> None:
+        super().__init__(in_channels, out_channels, channels, growth_channels, num_blocks, upscale_factor, always_up1=False)
+
+
+class DiscriminatorUNet(nn.Module):
+    """BSRGAN/model.py:91-167 (identical Real_ESRGAN/model.py:29-105)."""
+
+    def __init__(self, in_channels: int, out_channels: int, channels: int, upsample_method: str = "bilinear") -> None:
+        super().__init__()
+        self.upsample_method = upsample_method
+        self.conv1 = nn.Conv2d(in_channels, 64, (3, 3), (1, 1), (1, 1))
+
+        def sn(cin, cout, k, s):
+            return nn.Sequential(spectral_norm(nn.Conv2d(cin, cout, (k, k), (s, s), (1, 1), bias=False)),
+                                 nn.LeakyReLU(0.2, True))
+        self.down_block1 = sn(channels, int(channels * 2), 4, 2)
+        self.down_block2 = sn(int(channels * 2), int(channels * 4), 4, 2)
+        self.down_block3 = sn(int(channels * 4), int(channels * 8), 4, 2)
+        self.up_block1 = sn(int(channels * 8), int(channels * 4), 3, 1)
+        self.up_block2 = sn(int(channels * 4), int(channels * 2), 3, 1)
+        self.up_block3 = sn(int(channels * 2), channels, 3, 1)
+        self.conv2 = sn(channels, channels, 3, 1)
+        self.conv3 = sn(channels, channels, 3, 1)
+        self.conv4 = nn.Conv2d(channels, out_channels, (3, 3), (1, 1), (1, 1))
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._forward_impl(x)
+
+    def _forward_impl(self, x: Tensor) -> Tensor:
+        from .engine import discriminator_apply
+        return discriminator_apply(self, x)
+
+
+class ContentLoss(nn.Module):
+    """BSRGAN/model.py:501-554.  torchvision and the ImageNet VGG-19 weights are not part of the
+    reference tree (third-party, network download), so the VGG-19 ``features[0:35]`` topology is
+    restated here and its weights come from ``weights_path`` (a torchvision ``vgg19`` state_dict) or,
+    when absent, from a seeded random init (benchmarks).  The returned tensor is DETACHED with shape
+    (1, len(nodes)) exactly like the reference's ``torch.Tensor([losses])`` (:552)."""
+
+    def __init__(self, feature_model_extractor_nodes: list, feature_model_normalize_mean: list,
+                 feature_model_normalize_std: list, weights_path: str = "", taps_post_relu: bool = True) -> None:
+        super().__init__()
+        from .vgg import build_vgg19_features
+        self.feature_model_extractor_nodes = list(feature_model_extractor_nodes)
+        self.taps_post_relu = taps_post_relu
+        self.features = build_vgg19_features(weights_path)
+        self.register_buffer("mean", torch.tensor(feature_model_normalize_mean, dtype=torch.float32))
+        self.register_buffer("std", torch.tensor(feature_model_normalize_std, dtype=torch.float32))
+        for p in self.features.parameters():
+            p.requires_grad = False
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, sr_tensor: Tensor, gt_tensor: Tensor) -> Tensor:
+        assert sr_tensor.size() == gt_tensor.size(), "Two tensor must have the same size"
+        from .engine import content_loss_apply
+        return content_loss_apply(self, sr_tensor, gt_tensor)
+
+
+def discriminator_unet(**kwargs: Any) -> DiscriminatorUNet:
+    return DiscriminatorUNet(**kwargs)
+
+
+def bsrgan_x2(**kwargs: Any) -> BSRGAN:
+    return BSRGAN(upscale_factor=2, **kwargs)
+
+
+def bsrgan_x4(**kwargs: Any) -> BSRGAN:
+    return BSRGAN(upscale_factor=4, **kwargs)
+
+
+def content_loss(**kwargs: Any) -> ContentLoss:
+    return ContentLoss(**kwargs)
+
+
+def rrdbnet_x1(**kwargs: Any) -> RRDBNet:
+    return RRDBNet(upscale_factor=1, **kwargs)
+
+
+def rrdbnet_x2(**kwargs: Any) -> RRDBNet:
+    return RRDBNet(upscale_factor=2, **kwargs)
+
+
+def rrdbnet_x4(**kwargs: Any) -> RRDBNet:
+    return RRDBNet(upscale_factor=4, **kwargs)
+
+
+def rrdbnet_x8(**kwargs: Any) -> RRDBNet:
+    return RRDBNet(upscale_factor=8, **kwargs)

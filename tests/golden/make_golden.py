@@ -66,7 +66,7 @@ def scaled_init(g, scale, bias):
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: buffers are later updated in place
 
 
 def save(name, **arrs):

@@ -195,7 +195,8 @@ def test_wgrad_dense_block_fused(dtype):
     grads = torch.ones(off, device="cuda")
     plan = ops.WgradPlan("cuda", dt, n, h, w, 192, 192, convs)
     ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
-    plan.run(A.view(_nhwc(cat, dtype)), A.view(_nhwc(dyall, dtype)), grads, ws)
+    catb, dyb = _nhwc(cat, dtype), _nhwc(dyall, dtype)  # keep alive: views hold raw pointers
+    plan.run(A.view(catb), A.view(dyb), grads, ws)
     torch.cuda.synchronize()
     for o, gw, gb in refs:
         _assert_close(grads[o:o + gw.numel()].view_as(gw) - 1.0, gw, dtype, "fused dW")

@@ -1,0 +1,177 @@
+"""Pin the CPU oracle (oracle/srgan_oracle.py) to golden vectors captured from the reference.
+
+Runs on CPU (`-m "not gpu"`).  Weights are rebuilt from the seed with this repository's parameter
+containers (sr_gan_fd_amd.model); the per-tensor checksums stored in the fixtures prove the rebuild
+is bit-identical to the reference's constructors before any output is compared.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import checksum, load_golden, scaled_init, table, sd_to_params
+
+TOL = 2e-5  # fp32 CPU vs fp32 CPU: only op-ordering noise
+
+
+def _close(a, b, tol=TOL, what=""):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item() / scale
+    assert err < tol, f"{what}: rel err {err:.3e}"
+
+
+def _check_table(tab, named, tol=1e-9, what=""):
+    for k, want in tab.items():
+        got = checksum(named[k])
+        assert np.allclose(got, want, rtol=tol, atol=tol * (abs(want[1]) + 1e-30)), f"{what} checksum {k}: {got} vs {want}"
+
+
+def test_blocks(golden_dir):
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "blocks.npz")
+    for kind, ctor in (("rdb", M._ResidualDenseBlock), ("rrdb", M._ResidualResidualDenseBlock)):
+        torch.manual_seed(0)
+        blk = ctor(64, 32)
+        _check_table(table(g, f"{kind}_wsum"), blk.state_dict(), what=kind)
+        P = sd_to_params(blk.state_dict(), grad=True)
+        x = torch.tensor(g[f"{kind}_x"], requires_grad=True)
+        y = O.rdb_forward(x, P, "") if kind == "rdb" else O.rrdb_forward(x, P, "")
+        _close(y.detach(), g[f"{kind}_y"], what=f"{kind} y")
+        (y * torch.tensor(g[f"{kind}_r"])).sum().backward()
+        _close(x.grad, g[f"{kind}_dx"], what=f"{kind} dx")
+        for k, want in table(g, f"{kind}_gsum").items():
+            got = checksum(P[k].grad)
+            assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * abs(want[1])), f"{kind} grad checksum {k}"
+
+
+@pytest.mark.parametrize("name,fac,kw,s,scale", [
+    ("bsrgan_x4_r2_s3", "bsrgan_x4", dict(num_rrdb=2), 4, 3.0),
+    ("bsrgan_x2_r2_s3", "bsrgan_x2", dict(num_rrdb=2), 2, 3.0),
+    ("bsrgan_x4_r2_s5", "bsrgan_x4", dict(num_rrdb=2), 4, 5.0),
+    ("rrdbnet_x4_r23_s3", "rrdbnet_x4", dict(num_blocks=23), 4, 3.0),
+    ("bsrgan_x4_r23_s3_odd", "bsrgan_x4", dict(num_rrdb=23), 4, 3.0),
+])
+def test_generator(golden_dir, name, fac, kw, s, scale):
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "generator.npz")
+    torch.manual_seed(0)
+    net = getattr(M, fac)(in_channels=3, out_channels=3, channels=64, growth_channels=32, **kw)
+    scaled_init(net, scale, 0.5)
+    _check_table(table(g, f"{name}/wsum"), net.state_dict(), what=name)
+    P = sd_to_params(net.state_dict(), grad=True)
+    sr = O.rrdbnet_forward(torch.tensor(g[f"{name}/x"]), P, s)
+    _close(sr.detach(), g[f"{name}/sr"], what="sr")
+    loss = O.l1_mean(sr, torch.tensor(g[f"{name}/gt"]))
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-6
+    loss.backward()
+    for k in ("conv1.weight", "conv4.weight", "conv4.bias", "trunk.0.rdb1.conv1.bias", "trunk.1.rdb3.conv5.bias", "conv2.bias"):
+        _close(P[k].grad, g[f"{name}/grad/{k}"], tol=2e-4, what=f"grad {k}")
+    for k, want in table(g, f"{name}/gsum").items():
+        got = checksum(P[k].grad)
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * abs(want[1]) + 1e-12), f"{name} grad checksum {k}: {got} {want}"
+
+
+def test_discriminator(golden_dir):
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "discriminator.npz")
+    torch.manual_seed(0)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    _check_table(table(g, "wsum0"), d.state_dict(), what="D")
+    P = sd_to_params(d.state_dict(), grad=True, d=True)
+    x = torch.tensor(g["x"])
+    for it in range(3):
+        logits = O.discriminator_unet_forward(x, P, training=True)
+        _close(logits.detach(), g[f"train{it}_logits"], what=f"logits {it}")
+        for layer in ("down_block1", "up_block1", "conv3"):
+            _close(P[f"{layer}.0.weight_u"], g[f"train{it}_{layer}_u"], what="u")
+            _close(P[f"{layer}.0.weight_v"], g[f"train{it}_{layer}_v"], what="v")
+    loss = O.bce_with_logits_mean(logits, 1.0)
+    assert abs(loss.item() - float(g["bce_ones"])) < 1e-6
+    loss.backward()
+    for k in ("conv1.weight", "conv4.weight", "conv4.bias", "conv3.0.weight_orig"):
+        _close(P[k].grad, g[f"grad/{k}"], tol=2e-4, what=f"grad {k}")
+    for k, want in table(g, "gsum").items():
+        got = checksum(P[k].grad)
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * abs(want[1]) + 1e-12), f"D grad checksum {k}"
+    with torch.no_grad():
+        _close(O.discriminator_unet_forward(x, P, training=False), g["eval_logits"], what="eval logits")
+    xin = x.clone().requires_grad_(True)
+    lg = O.discriminator_unet_forward(xin, P, training=True)
+    _close(lg.detach(), g["train3_logits"], what="logits 3")
+    O.bce_with_logits_mean(lg, 1.0).backward()
+    _close(xin.grad, g["train3_dx"], tol=2e-4, what="dx")
+
+
+def test_gan_steps(golden_dir):
+    """two iterations of train_bsrgan.py:387-483 (content loss = 0: no VGG weights in the reference tree)"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "gan_steps.npz")
+    torch.manual_seed(0)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    gen = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(gen, 3.0, 0.5)
+    _check_table(table(g, "wsum_g0"), gen.state_dict(), what="G0")
+    _check_table(table(g, "wsum_d0"), d.state_dict(), what="D0")
+    G = sd_to_params(gen.state_dict())
+    D = sd_to_params(d.state_dict(), d=True)
+    g_opt = O.AdamState(G, O.g_param_names(G))
+    d_opt = O.AdamState(D, O.d_param_names(D))
+    ema, n_avg = {}, 0
+    for it in range(2):
+        out = O.gan_step(G, D, g_opt, d_opt, torch.tensor(g[f"it{it}_lr"]), torch.tensor(g[f"it{it}_gt"]), upscale=4,
+                         g_lr=8e-5, d_lr=2e-4, betas=(0.9, 0.999), eps=1e-4, pixel_weight=20.0, content_weight=1.0,
+                         adversarial_weight=0.5)
+        n_avg = O.ema_update(ema, {k: G[k] for k in O.g_param_names(G)}, n_avg, 0.999)
+        want = g[f"it{it}_scalars"]
+        got = [out["d_loss"], out["pixel_loss"], out["content_loss"], out["adversarial_loss"],
+               out["d_gt_probability"], out["d_sr_probability"]]
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-6), f"it{it}: {got} vs {want}"
+        _close(G["conv4.bias"], g[f"it{it}_g_conv4_bias"], tol=1e-5, what="G conv4.bias")
+        _close(D["conv4.weight"], g[f"it{it}_d_conv4_weight"], tol=1e-5, what="D conv4.weight")
+        for k, want_c in table(g, f"it{it}_wsum_g").items():
+            assert np.allclose(checksum(G[k]), want_c, rtol=1e-4, atol=1e-5 * abs(want_c[1])), f"G {k}"
+        for k, want_c in table(g, f"it{it}_wsum_d").items():
+            assert np.allclose(checksum(D[k]), want_c, rtol=1e-4, atol=1e-5 * abs(want_c[1])), f"D {k}"
+        for k, want_c in table(g, f"it{it}_wsum_ema").items():
+            if k == "n_averaged":
+                continue
+            assert np.allclose(checksum(ema[k[len("module."):]]), want_c, rtol=1e-4, atol=1e-5 * abs(want_c[1])), f"EMA {k}"
+
+
+@pytest.mark.parametrize("name,fac,kw,lr,eps", [
+    ("esrgan_small", "rrdbnet_x4", dict(num_blocks=2), 2e-4, 1e-8),
+    ("bsrnet_small", "bsrgan_x4", dict(num_rrdb=2), 1e-4, 1e-4),
+])
+def test_g_only_steps(golden_dir, name, fac, kw, lr, eps):
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "g_only_steps.npz")
+    torch.manual_seed(0)
+    net = getattr(M, fac)(in_channels=3, out_channels=3, channels=64, growth_channels=32, **kw)
+    scaled_init(net, 3.0, 0.5)
+    G = sd_to_params(net.state_dict())
+    opt = O.AdamState(G, O.g_param_names(G))
+    for it in range(2):
+        loss, sr = O.g_only_step(G, opt, torch.tensor(g[f"{name}/it{it}_lr"]), torch.tensor(g[f"{name}/it{it}_gt"]),
+                                 upscale=4, lr=lr, betas=(0.9, 0.99), eps=eps)
+        assert abs(loss - g[f"{name}/losses"][it]) < 2e-6
+        _close(sr, g[f"{name}/it{it}_sr"], what="sr")
+        for k, want_c in table(g, f"{name}/it{it}_wsum").items():
+            assert np.allclose(checksum(G[k]), want_c, rtol=1e-4, atol=1e-5 * abs(want_c[1])), f"{name} {k}"
+    _close(G["conv4.bias"], g[f"{name}/conv4_bias"], tol=1e-5, what="conv4.bias")
+
+
+def test_psnr_definition():
+    """_psnr_torch (image_quality_assessment.py:361-395): identical images -> 10*log10(255^2/1e-8)"""
+    from oracle import srgan_oracle as O
+    a = torch.rand(2, 3, 8, 8)
+    assert torch.allclose(O.psnr_y(a, a), torch.full((2,), 10 * np.log10(255.0 ** 2 / 1e-8), dtype=torch.float64))
+    b = (a + 0.1).clamp(0, 1)
+    y = lambda t: ((t * torch.tensor([65.481, 128.553, 24.966]).view(1, 3, 1, 1)).sum(1, keepdim=True) + 16.0) / 255.0
+    mse = ((y(a).double() * 255 - y(b).double() * 255) ** 2 + 1e-8).mean(dim=[1, 2, 3])
+    assert torch.allclose(O.psnr_y(a, b), 10 * torch.log10(255.0 ** 2 / mse), rtol=1e-6)
