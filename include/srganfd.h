@@ -32,6 +32,9 @@ extern "C" {
 
 const char* srganfd_last_error(void);
 int srganfd_abi_version(void);
+/* dry run: entry points validate their arguments and build plans but launch nothing (used by the
+ * CPU-only host-logic tests; never set in production). */
+void srganfd_set_dry_run(int on);
 
 /* A channel-slice view of an NHWC activation buffer: element (n,y,x,c) lives at
  * ptr[((n*H + y)*W + x)*cstride + c0 + c]. */
@@ -70,6 +73,11 @@ typedef struct {
   float alpha, slope, post_scale, r1_scale, r2_scale, mask_slope;
   int32_t act;
   int32_t y_f32;             /* 1: y is fp32 regardless of dtype (final SR / logits) */
+  /* Strided output (all 0 = dense).  Used by the data gradient of the 4x4 stride-2 convs
+   * (model.py:103-114): each of the 4 output parity classes is a 2x2-tap stride-1 conv over dy
+   * whose result pixel (oy,ox) is stored at (oy*out_sy+out_oy, ox*out_sx+out_ox) of an
+   * out_h_full x out_w_full image; pad_y/pad_x replace `pad`; r1/r2/mask use the same addressing. */
+  int32_t out_sy, out_sx, out_oy, out_ox, out_h_full, out_w_full, pad_y, pad_x;
 } srganfd_conv_args;
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream);
@@ -88,7 +96,9 @@ typedef struct {
   int32_t co_src, ci_src;
   int32_t k_lo, k_len;    /* rows [k_lo, k_lo+k_len) of the packed operand */
   int32_t co_off, ci_off;
-  int32_t transposed;     /* 0 forward, 1 data-gradient (flip taps, swap roles) */
+  int32_t transposed;     /* 0 forward, 1 data-gradient (flip taps, swap roles),
+                             2+2*py+px: parity class (py,px) of a 4x4 stride-2 data gradient, packed as a
+                             2x2-tap operand: tap (a,b) <- source tap (ty,tx), ty = py ? 2-2a : 3-2a */
   float scale;
 } srganfd_pack_seg;
 
@@ -137,6 +147,63 @@ int srganfd_wgrad_plan_build(const srganfd_wgrad_shape* s, const srganfd_wgrad_c
 int srganfd_conv2d_wgrad(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy,
                          float* grads, const float* scalars, void* workspace, size_t workspace_bytes,
                          void* stream);
+
+/* ---- boundary layout conversion (the reference's modules take/return NCHW fp32) ---- */
+/* BSRGAN.forward input (model.py:366): NCHW fp32 -> NHWC dtype view, zero padded to cpad channels */
+int srganfd_nchw_to_nhwc(const float* src, int32_t n, int32_t c, int32_t h, int32_t w, srganfd_view dst,
+                         int32_t dtype, int32_t cpad, const float* ch_mean, const float* ch_std, void* stream);
+/* (ch_mean, ch_std: optional per-channel (x - mean) / std of ContentLoss.normalize, model.py:542-543) */
+/* NHWC view (dtype) -> NCHW fp32; clamp01 = torch.clamp_(out, 0, 1) of model.py:379 */
+int srganfd_nhwc_to_nchw(srganfd_view src, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                         float* dst, int32_t clamp01, void* stream);
+/* backward of that clamp + relayout: dst[p][c] = (0 <= pre[p][c] <= 1) ? dsr[n][c][p] : 0 ; pre is fp32 NHWC */
+int srganfd_clamp_grad_to_nhwc(const float* dsr_nchw, srganfd_view pre_f32, int32_t n, int32_t c, int32_t h,
+                               int32_t w, srganfd_view dst, int32_t dtype, int32_t cpad, void* stream);
+
+/* resampling: op 0 = backward of nearest x2 (model.py:372,374), 1 = bilinear x2 forward
+ * (align_corners=False, model.py:150,154,158), 2 = its backward, 3 = 2x2 max-pool (VGG-19).
+ * 4 = ReLU copy.  (h, w) are the LOW-resolution dims for ops 0-2 and the input dims for ops 3-4;
+ * a = source view, b = destination view. */
+int srganfd_resample(int32_t op, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t h,
+                     int32_t w, int32_t c, void* stream);
+/* out = dy * (act - skip > 0 ? 1 : slope): LeakyReLU backward where only act = lrelu(z) + skip was
+ * stored (U-Net skip adds, model.py:153,157,161); skip.ptr may be NULL (plain LeakyReLU backward). */
+int srganfd_lrelu_bwd(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int32_t dtype,
+                      int64_t npix, int32_t c, float slope, void* stream);
+/* y = alpha * x + beta * y over npix pixels x c channels */
+int srganfd_axpby(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, float alpha,
+                  float beta, void* stream);
+
+/* ---- losses (train_bsrgan.py:297,301,417,427,450-452).  workspace: >= 2048 floats.
+ * *out = (accumulate ? *out : 0) + weight * mean(...).  Deterministic two-stage reductions. */
+#define SRGANFD_LOSS_WS_FLOATS 2049
+int srganfd_l1_loss(const float* a, const float* b, int64_t numel, float weight, float* out,
+                    int32_t accumulate, float* grad_a /* or NULL */, float grad_scale, float* workspace,
+                    void* stream);
+int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t npix, int32_t c,
+                          int32_t relu_first, float weight, float* out, int32_t accumulate,
+                          float* workspace, void* stream);
+int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out,
+                       int32_t accumulate, float* sigmoid_mean_out /* or NULL */, float* grad /* or NULL */,
+                       float grad_scale, float* workspace, void* stream);
+
+/* ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132).
+ * One power iteration in place on u, v when training; sigma = u^T W v; workspace >= rows+cols floats. */
+int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols,
+                          int32_t training, float eps, float* sigma_out, float* inv_sigma_out,
+                          float* workspace, void* stream);
+/* dW_orig = beta*dW_orig + (G - <G,W_orig>/sigma * u v^T)/sigma ; workspace >= 1025 floats */
+int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const float* u, const float* v,
+                               const float* inv_sigma, float* dw_orig, int32_t rows, int32_t cols,
+                               float beta, float* workspace, void* stream);
+
+/* ---- fused Adam + EMA over flat buffers (torch.optim.Adam maths, train_bsrgan.py:311-323,436,466;
+ * AveragedModel with the reference's avg_fn, :290-291,470).  ema_mode: 0 none, 1 copy (first
+ * update), 2 ema = (1-decay)*ema + decay*param.  grad_scale multiplies the gradient first
+ * (1/world_size after an all-reduce(sum)). */
+int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                     int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
 
 #ifdef __cplusplus
 }

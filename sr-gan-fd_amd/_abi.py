@@ -28,6 +28,8 @@ class ConvArgs(C.Structure):
         ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("alpha_dev", C.c_void_p),
         ("alpha", C.c_float), ("slope", C.c_float), ("post_scale", C.c_float), ("r1_scale", C.c_float),
         ("r2_scale", C.c_float), ("mask_slope", C.c_float), ("act", C.c_int32), ("y_f32", C.c_int32),
+        ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
+        ("out_h_full", C.c_int32), ("out_w_full", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
     ]
 
 
@@ -66,6 +68,7 @@ class WgradShape(C.Structure):
 SYMBOLS = {
     "srganfd_last_error": (C.c_char_p, []),
     "srganfd_abi_version": (C.c_int, []),
+    "srganfd_set_dry_run": (None, [C.c_int]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -74,8 +77,22 @@ SYMBOLS = {
                                            C.POINTER(C.c_size_t)]),
     "srganfd_conv2d_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
+    "srganfd_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, View, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_lrelu_bwd": (C.c_int, [View, View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "srganfd_nhwc_to_nchw": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "srganfd_clamp_grad_to_nhwc": (C.c_int, [C.c_void_p, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, View, C.c_int32, C.c_int32, C.c_void_p]),
+    "srganfd_resample": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "srganfd_axpby": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+    "srganfd_l1_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_l1_loss_views": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "srganfd_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_spectral_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_spectral_norm_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_adam_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
 }
 
+LOSS_WS_FLOATS = 2049
 _lib = None
 
 
@@ -106,7 +123,19 @@ def check(rc: int, what: str = "") -> None:
         raise SrganfdError(f"{what} failed (rc={rc}): {lib().srganfd_last_error().decode()}")
 
 
+DRY_RUN = False
+
+
+def set_dry_run(on: bool) -> None:
+    """Host-logic tests on CPU: every entry point validates its arguments and launches nothing."""
+    global DRY_RUN
+    DRY_RUN = bool(on)
+    lib().srganfd_set_dry_run(1 if on else 0)
+
+
 def stream_ptr() -> int:
+    if DRY_RUN:
+        return 0
     import torch
     return torch.cuda.current_stream().cuda_stream
 

@@ -4,6 +4,7 @@
 
 namespace srganfd {
 thread_local char g_err[512] = {0};
+int g_dry_run = 0;
 int set_err(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -19,6 +20,21 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
                           size_t* workspace_bytes);
 int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads, const float* scalars,
                void* workspace, size_t workspace_bytes, hipStream_t stream);
+int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s);
+int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int dtype, size_t npix, int c, float slope, hipStream_t s);
+int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, float* dst, int clamp01, hipStream_t s);
+int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s);
+int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int h, int w, int c, hipStream_t s);
+int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s);
+int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s);
+int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s);
+int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
+                    float grad_scale, float* ws, hipStream_t s);
+int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s);
+int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
+                            float beta, float* ws, hipStream_t s);
+int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                  float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -27,6 +43,7 @@ extern "C" {
 
 const char* srganfd_last_error(void) { return g_err; }
 int srganfd_abi_version(void) { return 1; }
+void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }
 
@@ -49,6 +66,53 @@ int srganfd_wgrad_plan_build(const srganfd_wgrad_shape* s, const srganfd_wgrad_c
 int srganfd_conv2d_wgrad(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads,
                          const float* scalars, void* workspace, size_t workspace_bytes, void* stream) {
   return wgrad_impl(plan_host, plan_dev, x, dy, grads, scalars, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int srganfd_nchw_to_nhwc(const float* src, int32_t n, int32_t c, int32_t h, int32_t w, srganfd_view dst, int32_t dtype, int32_t cpad,
+                         const float* ch_mean, const float* ch_std, void* stream) {
+  return nchw_to_nhwc_impl(src, n, c, h, w, dst, dtype, cpad, ch_mean, ch_std, (hipStream_t)stream);
+}
+int srganfd_lrelu_bwd(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, float slope,
+                      void* stream) {
+  return lrelu_bwd_impl(dy, act, skip, out, dtype, (size_t)npix, c, slope, (hipStream_t)stream);
+}
+int srganfd_nhwc_to_nchw(srganfd_view src, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, float* dst, int32_t clamp01, void* stream) {
+  return nhwc_to_nchw_impl(src, dtype, n, c, h, w, dst, clamp01, (hipStream_t)stream);
+}
+int srganfd_clamp_grad_to_nhwc(const float* dsr_nchw, srganfd_view pre_f32, int32_t n, int32_t c, int32_t h, int32_t w, srganfd_view dst,
+                               int32_t dtype, int32_t cpad, void* stream) {
+  return clamp_grad_impl(dsr_nchw, pre_f32, n, c, h, w, dst, dtype, cpad, (hipStream_t)stream);
+}
+int srganfd_resample(int32_t op, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return resample_impl(op, a, b, dtype, n, h, w, c, (hipStream_t)stream);
+}
+int srganfd_axpby(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, float alpha, float beta, void* stream) {
+  return axpby_impl(x, y, dtype, (size_t)npix, c, alpha, beta, (hipStream_t)stream);
+}
+int srganfd_l1_loss(const float* a, const float* b, int64_t numel, float weight, float* out, int32_t accumulate, float* grad_a, float grad_scale,
+                    float* workspace, void* stream) {
+  return l1_loss_impl(a, b, (size_t)numel, weight, out, accumulate, grad_a, grad_scale, workspace, (hipStream_t)stream);
+}
+int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t npix, int32_t c, int32_t relu_first, float weight, float* out,
+                          int32_t accumulate, float* workspace, void* stream) {
+  return l1_views_impl(a, b, dtype, (size_t)npix, c, relu_first, weight, out, accumulate, workspace, (hipStream_t)stream);
+}
+int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out, int32_t accumulate,
+                       float* sigmoid_mean_out, float* grad, float grad_scale, float* workspace, void* stream) {
+  return bce_logits_impl(logits, (size_t)numel, target, weight, loss_out, accumulate, sigmoid_mean_out, grad, grad_scale, workspace, (hipStream_t)stream);
+}
+int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma_out,
+                          float* inv_sigma_out, float* workspace, void* stream) {
+  return spectral_norm_impl(w_orig, u, v, rows, cols, training, eps, sigma_out, inv_sigma_out, workspace, (hipStream_t)stream);
+}
+int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const float* u, const float* v, const float* inv_sigma, float* dw_orig,
+                               int32_t rows, int32_t cols, float beta, float* workspace, void* stream) {
+  return spectral_norm_grad_impl(g_weight, w_orig, u, v, inv_sigma, dw_orig, rows, cols, beta, workspace, (hipStream_t)stream);
+}
+int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream) {
+  return adam_ema_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay,
+                       ema_mode, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -48,15 +48,19 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) {
 }
 
 extern thread_local char g_err[512];
+extern int g_dry_run;  // srganfd_set_dry_run(1): validate arguments, build plans, launch nothing (host-logic tests on CPU)
 int set_err(int code, const char* fmt, ...);
 
 #define SRGANFD_HIP_CHECK(expr)                                                          \
   do {                                                                                   \
+    if (srganfd::g_dry_run) break;                                                       \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess)                                                                \
       return srganfd::set_err(SRGANFD_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
                               hipGetErrorString(_e));                                    \
   } while (0)
+
+#define SRGANFD_LAUNCH(...) do { if (!srganfd::g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -28,7 +28,8 @@ struct ConvK {
   const void* x; void* y; const void* r1; const void* r2; const void* mask; const void* w;
   const float* bias; const float* alpha_dev;
   int xC, x_c0, yC, y_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
-  int N, Hin, Win, up, pad, Hout, Wout;
+  int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
+  int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
   int nChunks;        // cin / 32
   int nNb;            // cout / (32*NR)
   int cout_store;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
     const int item = tid + i * 256;
     const int pix = item / C::CPP, c16 = item % C::CPP;
     const int py = pix / C::PC, px = pix % C::PC;
-    const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
+    const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
     xoff[i] = ok ? ((n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + a.x_c0 + c16 * C::E16 : -1;
   }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
       for (int i = 0; i < 16; ++i) {
         const int ox = ox0 + mfma32_row(i, lane);
         if (cok && oy < a.Hout && ox < a.Wout) {
-          const size_t p = ((size_t)n * a.Hout + oy) * a.Wout + ox;
+          const size_t p = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
           float v = alpha * acc[m][nn][i] + bv;
           if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
           else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -276,7 +277,7 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   kk.tiles_y = ceil_div(k.Hout, C::TH);
   const long long nblk = (long long)k.N * kk.tiles_x * kk.tiles_y * kk.nNb;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d: bad grid %lld", nblk);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, kk);
+  SRGANFD_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, kk);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -289,6 +290,7 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
     return launch_conv<T, 3, 1, 4, 1>(k, a->cout, s);
   }
   if (a->ksize == 4 && a->stride == 2) return launch_conv<T, 4, 2, 1, 1>(k, a->cout, s);
+  if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 4, 1>(k, a->cout, s);
   if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 1>(k, a->cout, s);
   return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
 }
@@ -300,9 +302,14 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   if (a->n <= 0 || a->h_in <= 0 || a->w_in <= 0 || a->h_out <= 0 || a->w_out <= 0)
     return set_err(SRGANFD_EINVAL, "conv2d: bad dims");
   const int hl = a->h_in << (a->up ? 1 : 0), wl = a->w_in << (a->up ? 1 : 0);
-  const int ho = (hl + 2 * a->pad - a->ksize) / a->stride + 1, wo = (wl + 2 * a->pad - a->ksize) / a->stride + 1;
-  if (ho != a->h_out || wo != a->w_out)
-    return set_err(SRGANFD_EINVAL, "conv2d: h_out/w_out %dx%d inconsistent with input (expect %dx%d)", a->h_out, a->w_out, ho, wo);
+  const bool sub = a->out_sy > 1 || a->out_sx > 1;  // parity-class launch of a stride-2 transposed conv
+  if (!sub) {
+    const int ho = (hl + 2 * a->pad - a->ksize) / a->stride + 1, wo = (wl + 2 * a->pad - a->ksize) / a->stride + 1;
+    if (ho != a->h_out || wo != a->w_out)
+      return set_err(SRGANFD_EINVAL, "conv2d: h_out/w_out %dx%d inconsistent with input (expect %dx%d)", a->h_out, a->w_out, ho, wo);
+  } else if (a->out_h_full < (a->h_out - 1) * a->out_sy + a->out_oy + 1 || a->out_w_full < (a->w_out - 1) * a->out_sx + a->out_ox + 1) {
+    return set_err(SRGANFD_EINVAL, "conv2d: strided output does not fit the full image");
+  }
   const int align = a->dtype == SRGANFD_BF16 ? 8 : 4;
   if (a->x.cstride % align || a->x.c0 % align) return set_err(SRGANFD_EINVAL, "conv2d: x view not 16-byte aligned");
   if (a->x.c0 + a->cin > a->x.cstride) return set_err(SRGANFD_EINVAL, "conv2d: x view exceeds buffer channels");
@@ -315,7 +322,9 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.xC = a->x.cstride; k.x_c0 = a->x.c0; k.yC = a->y.cstride; k.y_c0 = a->y.c0;
   k.r1C = a->r1.cstride; k.r1_c0 = a->r1.c0; k.r2C = a->r2.cstride; k.r2_c0 = a->r2.c0;
   k.mC = a->mask.cstride; k.m_c0 = a->mask.c0;
-  k.N = a->n; k.Hin = a->h_in; k.Win = a->w_in; k.up = a->up ? 1 : 0; k.pad = a->pad;
+  k.N = a->n; k.Hin = a->h_in; k.Win = a->w_in; k.up = a->up ? 1 : 0; k.pad_y = sub ? a->pad_y : a->pad; k.pad_x = sub ? a->pad_x : a->pad;
+  k.osy = sub ? a->out_sy : 1; k.osx = sub ? a->out_sx : 1; k.ooy = sub ? a->out_oy : 0; k.oox = sub ? a->out_ox : 0;
+  k.HoutF = sub ? a->out_h_full : a->h_out; k.WoutF = sub ? a->out_w_full : a->w_out;
   k.Hout = a->h_out; k.Wout = a->w_out; k.nChunks = a->cin / 32; k.nNb = 0; k.cout_store = a->cout_store;
   k.tiles_x = k.tiles_y = 0;
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;

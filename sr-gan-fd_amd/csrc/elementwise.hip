@@ -1,0 +1,490 @@
+// elementwise.hip -- the bandwidth-bound pieces of the hot path that are not fused into a conv epilogue:
+// layout/dtype conversion at the module boundary (NCHW fp32 <-> NHWC bf16/f32), clamp (+ its gradient
+// mask), nearest/bilinear x2 resampling gradients, losses (L1, BCE-with-logits), spectral-norm power
+// iteration and its gradient, max-pool, and the fused Adam + EMA update over flat parameter buffers.
+// All kernels are grid-stride, vectorised where the layout allows, and accumulate in fp32.
+// Reductions are two-stage (per-block partials, then one block) -> bitwise reproducible, no atomics.
+#include "common.hpp"
+
+namespace srganfd {
+
+template <typename T> __device__ __forceinline__ float ld(const void* p, size_t i) { return Elem<T>::to_f(((const T*)p)[i]); }
+template <typename T> __device__ __forceinline__ void st(void* p, size_t i, float v) { ((T*)p)[i] = Elem<T>::from_f(v); }
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;  // valid on thread 0
+}
+
+// ---- NCHW fp32 -> NHWC T view, zero padded to cpad channels (BSRGAN.forward input, model.py:366) ----
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* dst, int dC, int d0, int n, int c, int hw, int cpad,
+                                    const float* __restrict__ mean, const float* __restrict__ stdv) {
+  const size_t total = (size_t)n * hw * cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpad);
+    const size_t p = i / cpad;
+    const size_t img = p / hw, pix = p % hw;
+    float v = 0.f;
+    if (ch < c) {
+      v = src[(img * c + ch) * hw + pix];
+      if (mean) v = (v - mean[ch]) / stdv[ch];
+    }
+    st<T>(dst, p * dC + d0 + ch, v);
+  }
+}
+
+// ---- NHWC view (T or fp32) -> NCHW fp32, optional clamp to [0,1] (model.py:379) ----
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int sC, int s0, float* __restrict__ dst, int n, int c, int hw, int clamp01) {
+  const size_t total = (size_t)n * c * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i % hw;
+    const size_t t = i / hw;
+    const int ch = (int)(t % c);
+    const size_t img = t / c;
+    float v = ld<T>(src, (img * hw + pix) * sC + s0 + ch);
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.0f);
+    dst[i] = v;
+  }
+}
+
+// ---- gradient of clamp_(0,1) + NCHW fp32 -> NHWC T (zero padded): d pre = (0 <= pre <= 1) ? d sr : 0 ----
+template <typename T>
+__global__ void clamp_grad_kernel(const float* __restrict__ dsr, const float* __restrict__ pre, int pC, int p0, void* dst, int dC, int d0,
+                                  int n, int c, int hw, int cpad) {
+  const size_t total = (size_t)n * hw * cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpad);
+    const size_t p = i / cpad;
+    const size_t img = p / hw, pix = p % hw;
+    float v = 0.f;
+    if (ch < c) {
+      const float q = pre[p * pC + p0 + ch];
+      if (q >= 0.f && q <= 1.f) v = dsr[(img * c + ch) * hw + pix];
+    }
+    st<T>(dst, p * dC + d0 + ch, v);
+  }
+}
+
+// ---- backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:372,374): 2x2 sum ----
+template <typename T>
+__global__ void up2_nearest_bwd_kernel(const void* __restrict__ dy, int yC, int y0, void* dx, int xC, int x0, int n, int h, int w, int c) {
+  const size_t total = (size_t)n * h * w * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    size_t p = i / c;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const size_t img = p / h;
+    const size_t b = ((img * 2 * h + 2 * y) * 2 * w + 2 * x);
+    const float s = ld<T>(dy, b * yC + y0 + ch) + ld<T>(dy, (b + 1) * yC + y0 + ch) + ld<T>(dy, (b + 2 * w) * yC + y0 + ch) +
+                    ld<T>(dy, (b + 2 * w + 1) * yC + y0 + ch);
+    st<T>(dx, (i / c) * xC + x0 + ch, s);
+  }
+}
+
+// ---- bilinear x2, align_corners=False (model.py:150,154,158) forward and backward ----
+// dst(2k)   = 0.25*src(k-1) + 0.75*src(k)   (src index clamped to [0, n-1])
+// dst(2k+1) = 0.75*src(k)   + 0.25*src(k+1)
+__device__ __forceinline__ void bil_taps(int d, int n, int& i0, int& i1, float& w0, float& w1) {
+  const int k = d >> 1;
+  if (d & 1) { i0 = k; i1 = min(k + 1, n - 1); w0 = 0.75f; w1 = 0.25f; }
+  else { i0 = max(k - 1, 0); i1 = k; w0 = 0.25f; w1 = 0.75f; }
+}
+template <typename T>
+__global__ void up2_bilinear_fwd_kernel(const void* __restrict__ x, int xC, int x0, void* y, int yC, int y0, int n, int h, int w, int c) {
+  const size_t total = (size_t)n * 4 * h * w * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    size_t p = i / c;
+    const int ox = (int)(p % (2 * w)); p /= (2 * w);
+    const int oy = (int)(p % (2 * h));
+    const size_t img = p / (2 * h);
+    int ya, yb, xa, xb; float wya, wyb, wxa, wxb;
+    bil_taps(oy, h, ya, yb, wya, wyb);
+    bil_taps(ox, w, xa, xb, wxa, wxb);
+    const size_t r0 = (img * h + ya) * w, r1 = (img * h + yb) * w;
+    const float v = wya * (wxa * ld<T>(x, (r0 + xa) * xC + x0 + ch) + wxb * ld<T>(x, (r0 + xb) * xC + x0 + ch)) +
+                    wyb * (wxa * ld<T>(x, (r1 + xa) * xC + x0 + ch) + wxb * ld<T>(x, (r1 + xb) * xC + x0 + ch));
+    st<T>(y, (i / c) * yC + y0 + ch, v);
+  }
+}
+// gather form of the transpose: src pixel k receives from dst 2k-1 (0.25), 2k (0.75), 2k+1 (0.75), 2k+2 (0.25),
+// plus the clamped border contributions (dst 0 -> src 0 with the 0.25 that would go to src -1; same at the top).
+__device__ __forceinline__ int bil_bwd_taps(int k, int n, int* d, float* wt) {
+  int cnt = 0;
+  for (int dd = 2 * k - 2; dd <= 2 * k + 3; ++dd) {
+    if (dd < 0 || dd >= 2 * n) continue;
+    int i0, i1; float w0, w1;
+    bil_taps(dd, n, i0, i1, w0, w1);
+    float ww = 0.f;
+    if (i0 == k) ww += w0;
+    if (i1 == k) ww += w1;
+    if (ww != 0.f) { d[cnt] = dd; wt[cnt] = ww; ++cnt; }
+  }
+  return cnt;
+}
+template <typename T>
+__global__ void up2_bilinear_bwd_kernel(const void* __restrict__ dy, int yC, int y0, void* dx, int xC, int x0, int n, int h, int w, int c) {
+  const size_t total = (size_t)n * h * w * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    size_t p = i / c;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const size_t img = p / h;
+    int dys[6], dxs[6]; float wys[6], wxs[6];
+    const int ny = bil_bwd_taps(y, h, dys, wys), nx = bil_bwd_taps(x, w, dxs, wxs);
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b)
+        s += wys[a] * wxs[b] * ld<T>(dy, ((img * 2 * h + dys[a]) * 2 * w + dxs[b]) * yC + y0 + ch);
+    st<T>(dx, (i / c) * xC + x0 + ch, s);
+  }
+}
+
+// ---- y = a*x + b*y on channel-slice views ----
+template <typename T>
+__global__ void axpby_kernel(const void* __restrict__ x, int xC, int x0, void* y, int yC, int y0, size_t npix, int c, float a, float b) {
+  const size_t total = npix * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const float v = a * ld<T>(x, p * xC + x0 + ch) + (b != 0.f ? b * ld<T>(y, p * yC + y0 + ch) : 0.f);
+    st<T>(y, p * yC + y0 + ch, v);
+  }
+}
+
+// ---- 2x2 max pool (+ the preceding ReLU is already in the conv epilogue) for VGG-19 features ----
+template <typename T>
+__global__ void maxpool2_kernel(const void* __restrict__ x, int xC, int x0, void* y, int yC, int y0, int n, int h, int w, int c) {
+  const int ho = h / 2, wo = w / 2;
+  const size_t total = (size_t)n * ho * wo * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    size_t p = i / c;
+    const int ox = (int)(p % wo); p /= wo;
+    const int oy = (int)(p % ho);
+    const size_t img = p / ho;
+    const size_t b = (img * h + 2 * oy) * w + 2 * ox;
+    const float v = fmaxf(fmaxf(ld<T>(x, b * xC + x0 + ch), ld<T>(x, (b + 1) * xC + x0 + ch)),
+                          fmaxf(ld<T>(x, (b + w) * xC + x0 + ch), ld<T>(x, (b + w + 1) * xC + x0 + ch)));
+    st<T>(y, (i / c) * yC + y0 + ch, v);
+  }
+}
+
+// ---- ReLU copy (VGG taps observed pre-ReLU) and LeakyReLU backward with the sign recovered from act - skip ----
+template <typename T>
+__global__ void relu_copy_kernel(const void* __restrict__ x, int xC, int x0, void* y, int yC, int y0, int n, int h, int w, int c) {
+  const size_t total = (size_t)n * h * w * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    st<T>(y, p * yC + y0 + ch, fmaxf(ld<T>(x, p * xC + x0 + ch), 0.f));
+  }
+}
+template <typename T>
+__global__ void lrelu_bwd_kernel(const void* __restrict__ dy, int dC, int d0, const void* __restrict__ act, int aC, int a0,
+                                 const void* __restrict__ skip, int sC, int s0, void* out, int oC, int o0, size_t npix, int c, float slope) {
+  const size_t total = npix * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    float z = ld<T>(act, p * aC + a0 + ch);
+    if (skip) z -= ld<T>(skip, p * sC + s0 + ch);
+    st<T>(out, p * oC + o0 + ch, ld<T>(dy, p * dC + d0 + ch) * (z > 0.f ? 1.f : slope));
+  }
+}
+
+// ---- losses.  out[slot] (+)= weight * mean(...) ; two-stage deterministic reduction ----
+// L1 (nn.L1Loss, train_bsrgan.py:297,450) on flat fp32 arrays, optional gradient wrt a.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float gscale,
+                                                         float* __restrict__ grad, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    s += fabsf(d);
+    if (grad) grad[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+  }
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+// L1 between two NHWC T views (VGG feature taps, model.py:548-550), no gradient (detached in the reference)
+template <typename T>
+__global__ __launch_bounds__(256) void l1_views_partial_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
+                                                               size_t npix, int c, int relu, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const size_t total = npix * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    float va = ld<T>(a, p * aC + a0 + ch), vb = ld<T>(b, p * bC + b0 + ch);
+    if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+    s += fabsf(va - vb);
+  }
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+// BCE-with-logits against a constant label map (train_bsrgan.py:301,403-404): loss and sigmoid mean
+__global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ x, size_t n, float target, float gscale,
+                                                          float* __restrict__ grad, float* __restrict__ partial, float* __restrict__ partial_sig) {
+  __shared__ float sh[4];
+  float s = 0.f, sg = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = x[i];
+    s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    const float sig = 1.f / (1.f + expf(-v));
+    sg += sig;
+    if (grad) grad[i] = (sig - target) * gscale;
+  }
+  float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  r = block_reduce_sum(sg, sh);
+  if (threadIdx.x == 0) partial_sig[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partial, int nblk, float scale, float* out, int accumulate) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + r * scale;
+}
+
+// ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132) ----
+// W is (rows=Cout, cols=Cin*k*k) row-major fp32.
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw, int rows, int cols) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += W[(size_t)r * cols + k] * u[r];
+  vraw[k] = s;
+}
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float eps) {
+  __shared__ float sh[4];
+  __shared__ float inv;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i] * in[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) inv = 1.f / fmaxf(sqrtf(r), eps);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = in[i] * inv;
+}
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ t, int rows, int cols) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < cols; k += 256) s += W[(size_t)r * cols + k] * v[k];
+  const float tot = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) t[r] = tot;
+}
+// u = normalize(t) (only if update_u), sigma = u . t, inv_sigma = 1/sigma
+__global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ t, float* __restrict__ u, int rows, float eps, int update_u,
+                                                        float* __restrict__ sigma_out, float* __restrict__ inv_sigma_out) {
+  __shared__ float sh[4];
+  __shared__ float inv;
+  float s = 0.f;
+  if (update_u) {
+    for (int i = threadIdx.x; i < rows; i += 256) s += t[i] * t[i];
+    const float r = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) inv = 1.f / fmaxf(sqrtf(r), eps);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += 256) u[i] = t[i] * inv;
+    __syncthreads();
+  }
+  s = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) s += u[i] * t[i];
+  const float sig = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) { *sigma_out = sig; *inv_sigma_out = 1.f / sig; }
+}
+// gradient through weight = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
+//   dW_orig = (G - <G, W_orig>/sigma * u v^T) / sigma        with G = dL/d(weight)
+__global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ G, const float* __restrict__ W, size_t n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += G[i] * W[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
+                                                      const float* __restrict__ dot, const float* __restrict__ inv_sigma, float* __restrict__ dW,
+                                                      int rows, int cols, float beta) {
+  const size_t n = (size_t)rows * cols;
+  const float is = *inv_sigma, coef = *dot * is;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / cols), k = (int)(i % cols);
+    const float g = (G[i] - coef * u[r] * v[k]) * is;
+    dW[i] = g + (beta != 0.f ? beta * dW[i] : 0.f);
+  }
+}
+
+// ---- fused Adam (torch.optim.Adam maths, train_bsrgan.py:311-323) + EMA (train_bsrgan.py:290-291,470) ----
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                       float bc1, float bc2_sqrt, float gscale, float ema_decay, int ema_mode) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (ema_mode == 1) ema[i] = pi;                                               // first update: copy
+    else if (ema_mode == 2) ema[i] = (1.f - ema_decay) * ema[i] + ema_decay * pi; // reference avg_fn
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 8192) {
+  size_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32)                                  \
+  if ((dtype) == SRGANFD_BF16) { CALL_BF; } else if ((dtype) == SRGANFD_F32) { CALL_F32; } \
+  else return set_err(SRGANFD_EINVAL, "bad dtype %d", (int)(dtype));
+
+int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s) {
+  if (!src || !dst.ptr || n <= 0 || c <= 0 || cpad < c || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "nchw_to_nhwc: bad args");
+  const size_t total = (size_t)n * h * w * cpad;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv),
+             SRGANFD_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, float* dst, int clamp01, hipStream_t s) {
+  if (!src.ptr || !dst || src.c0 + c > src.cstride) return set_err(SRGANFD_EINVAL, "nhwc_to_nchw: bad args");
+  const size_t total = (size_t)n * h * w * c;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src.ptr, src.cstride, src.c0, dst, n, c, h * w, clamp01),
+             SRGANFD_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src.ptr, src.cstride, src.c0, dst, n, c, h * w, clamp01));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s) {
+  if (!dsr || !pre.ptr || !dst.ptr || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "clamp_grad: bad args");
+  const size_t total = (size_t)n * h * w * cpad;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(clamp_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad),
+             SRGANFD_LAUNCH(clamp_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+// op: 0 nearest-x2 backward, 1 bilinear-x2 forward, 2 bilinear-x2 backward, 3 maxpool2 ; (h, w) = low-res dims (op 3: input dims)
+int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int h, int w, int c, hipStream_t s) {
+  if (!a.ptr || !b.ptr || a.c0 + c > a.cstride || b.c0 + c > b.cstride) return set_err(SRGANFD_EINVAL, "resample: bad args");
+  const size_t lo = (size_t)n * h * w * c;
+#define RS(K, TOTAL) DISPATCH_T(dtype, \
+    SRGANFD_LAUNCH(K<bf16_t>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c), \
+    SRGANFD_LAUNCH(K<float>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
+  if (op == 0) { RS(up2_nearest_bwd_kernel, lo); }
+  else if (op == 1) { RS(up2_bilinear_fwd_kernel, lo * 4); }
+  else if (op == 2) { RS(up2_bilinear_bwd_kernel, lo); }
+  else if (op == 3) { RS(maxpool2_kernel, lo / 4); }
+  else if (op == 4) { RS(relu_copy_kernel, lo); }
+  else return set_err(SRGANFD_EINVAL, "resample: bad op %d", op);
+#undef RS
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int dtype, size_t npix, int c, float slope, hipStream_t s) {
+  if (!dy.ptr || !act.ptr || !out.ptr) return set_err(SRGANFD_EINVAL, "lrelu_bwd: null");
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope),
+             SRGANFD_LAUNCH(lrelu_bwd_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s) {
+  if (!x.ptr || !y.ptr) return set_err(SRGANFD_EINVAL, "axpby: null");
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(axpby_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b),
+             SRGANFD_LAUNCH(axpby_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+static constexpr int kRedBlocks = 1024;  // workspace floats needed by the loss entry points: 2 * kRedBlocks
+
+int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s) {
+  if (!a || !b || !out || !ws || n == 0) return set_err(SRGANFD_EINVAL, "l1_loss: bad args");
+  const unsigned g = grid_for(n, 256, kRedBlocks);
+  SRGANFD_LAUNCH(l1_partial_kernel, dim3(g), dim3(256), 0, s, a, b, n, grad_scale / (float)n, grad, ws);
+  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, out, accumulate);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s) {
+  if (!a.ptr || !b.ptr || !out || !ws) return set_err(SRGANFD_EINVAL, "l1_views: bad args");
+  const size_t n = npix * c;
+  const unsigned g = grid_for(n, 256, kRedBlocks);
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(l1_views_partial_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws),
+             SRGANFD_LAUNCH(l1_views_partial_kernel<float>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
+  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, out, accumulate);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
+                    float grad_scale, float* ws, hipStream_t s) {
+  if (!x || !loss_out || !ws || n == 0) return set_err(SRGANFD_EINVAL, "bce: bad args");
+  const unsigned g = grid_for(n, 256, kRedBlocks);
+  SRGANFD_LAUNCH(bce_partial_kernel, dim3(g), dim3(256), 0, s, x, n, target, grad_scale / (float)n, grad, ws, ws + kRedBlocks);
+  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, loss_out, accumulate);
+  if (sig_mean_out) SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + kRedBlocks), (int)g, 1.f / (float)n, sig_mean_out, 0);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+// ws: cols + rows floats
+int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s) {
+  if (!W || !u || !v || !sigma || !inv_sigma || !ws || rows <= 0 || cols <= 0) return set_err(SRGANFD_EINVAL, "spectral_norm: bad args");
+  float* vraw = ws; float* t = ws + cols;
+  if (training) {
+    SRGANFD_LAUNCH(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, W, (const float*)u, vraw, rows, cols);
+    SRGANFD_LAUNCH(sn_normalize_kernel, dim3(1), dim3(256), 0, s, (const float*)vraw, v, cols, eps);
+  }
+  SRGANFD_LAUNCH(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, W, (const float*)v, t, rows, cols);
+  SRGANFD_LAUNCH(sn_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)t, u, rows, eps, training, sigma, inv_sigma);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+// ws: kRedBlocks + 1 floats
+int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
+                            float beta, float* ws, hipStream_t s) {
+  if (!G || !W || !u || !v || !inv_sigma || !dW || !ws) return set_err(SRGANFD_EINVAL, "spectral_norm_grad: bad args");
+  const size_t n = (size_t)rows * cols;
+  const unsigned g = grid_for(n, 256, kRedBlocks);
+  SRGANFD_LAUNCH(sn_dot_partial_kernel, dim3(g), dim3(256), 0, s, G, W, n, ws);
+  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, 1.f, ws + kRedBlocks, 0);
+  SRGANFD_LAUNCH(sn_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, G, u, v, (const float*)(ws + kRedBlocks), inv_sigma, dW, rows, cols, beta);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                  float grad_scale, float ema_decay, int ema_mode, hipStream_t s) {
+  if (!p || !g || !m || !v || n == 0 || step < 1 || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam: bad args");
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  SRGANFD_LAUNCH(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2),
+                     grad_scale, ema_decay, ema_mode);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+}  // namespace srganfd

@@ -35,10 +35,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const srganfd_pack_job* __res
       if (k >= S.k_lo && k < S.k_lo + S.k_len) {
         const int kk = k - S.k_lo;
         int co, ci, t;
+        int KTs = KT;
         if (!S.transposed) { co = n + S.co_off; ci = kk + S.ci_off; t = tap; }
-        else { co = kk + S.co_off; ci = n + S.ci_off; t = KT - 1 - tap; }
+        else if (S.transposed == 1) { co = kk + S.co_off; ci = n + S.ci_off; t = KT - 1 - tap; }
+        else {  // parity class of the 4x4 stride-2 data gradient: this operand has 2x2 taps, the source 4x4
+          const int py = (S.transposed - 2) >> 1, px = (S.transposed - 2) & 1, ta = tap >> 1, tb = tap & 1;
+          const int ty = py ? 2 - 2 * ta : 3 - 2 * ta, tx = px ? 2 - 2 * tb : 3 - 2 * tb;
+          co = kk + S.co_off; ci = n + S.ci_off; t = ty * 4 + tx; KTs = 16;
+        }
         if (co < S.co_src && ci < S.ci_src) {
-          v = params[S.src_off + ((long long)co * S.ci_src + ci) * KT + t] * S.scale;
+          v = params[S.src_off + ((long long)co * S.ci_src + ci) * KTs + t] * S.scale;
           if (S.scale_off >= 0) v *= scalars[S.scale_off];
         }
         break;
@@ -54,7 +60,7 @@ int pack_weights_impl(const srganfd_pack_job* jobs_dev, int njobs, long long max
   if (!jobs_dev || njobs <= 0 || max_elems <= 0 || !params || !packed) return set_err(SRGANFD_EINVAL, "pack_weights: bad args");
   long long gx = (max_elems + 255) / 256;
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, stream, jobs_dev, params, scalars, (char*)packed);
+  SRGANFD_LAUNCH(pack_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, stream, jobs_dev, params, scalars, (char*)packed);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -381,7 +381,7 @@ static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
     SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
     attr_lds = H.lds_bytes;
   }
-  hipLaunchKernelGGL(kern, dim3(H.S, H.ngroups), dim3(256), H.lds_bytes, stream, k);
+  SRGANFD_LAUNCH(kern, dim3(H.S, H.ngroups), dim3(256), H.lds_bytes, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -406,7 +406,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
   if (rc != SRGANFD_OK) return rc;
   const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((H.ntap_wave * 1024 + 255) / 256, H.ntasks), dim3(256), 0, stream, tasks_dev,
+  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3((H.ntap_wave * 1024 + 255) / 256, H.ntasks), dim3(256), 0, stream, tasks_dev,
                      (const float*)k.slabs, (const float*)k.bslabs, grads, scalars, H.ntap_wave);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
