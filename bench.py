@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- SR training images/sec of the MI355X-native hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload g_only|gan] [--batch B] [--lr-size S]
+
+One "step" = one training iteration of the reference (``train()`` body) on one synthetic batch that is
+already resident in HBM.  Default workload = BASELINE.json configs[1]: BSRGAN RRDBNet x4 (23 RRDB)
+generator-only, L1 pixel loss, batch 32 per GPU, 128x128 -> 512x512, bf16 MFMA with fp32 master
+weights, Adam + EMA inside the timed region.  N > 1: one process per GPU (torchrun), weak scaling
+(batch 32 per GPU), one RCCL all-reduce of the flat gradient per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- dominant kernel, achieved TFLOP/s from HIP-event brackets around its launches in the
+                  timed region vs the dense bf16 MFMA peak,
+  cpu_baseline -- the CPU oracle (oracle/srgan_oracle.py, torch-CPU fp32) timed on this host on a
+                  bounded sample (batch 1) of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# algorithmic FLOP per image, SURVEY.md 8(d): 1 MAC = 2 FLOP, backward = 2x forward
+FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9}
+
+
+def conv_flops(a) -> float:
+    """algorithmic FLOP of one fused-conv launch: 2 * pixels_out * k*k * cin * cout_store"""
+    return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan"])
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--lr-size", type=int, default=128)
+    ap.add_argument("--num-rrdb", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd import profiling
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+
+    B, h = args.batch, args.lr_size
+    torch.manual_seed(0)                      # identical weights on every rank (bsrgan_config.py:35-37 seeds at import)
+    g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)
+    g.compute_dtype = torch.bfloat16
+    g.to(dev)
+    if args.workload == "g_only":
+        # BSRGAN/bsrnet_config.py:86-96 hyper-parameters
+        trainer = GeneratorTrainer(g, lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999, process_group=pg)
+        step_fn = trainer.step
+    else:
+        from sr_gan_fd_amd.gan import GanTrainer
+        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        d.compute_dtype = torch.bfloat16
+        d.to(dev)
+        trainer = GanTrainer(g, d, process_group=pg)
+        step_fn = trainer.step
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    lr_img = torch.rand(B, 3, h, h, device=dev, generator=gen)
+    gt = torch.rand(B, 3, 4 * h, 4 * h, device=dev, generator=gen)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step_fn(lr_img, gt)
+    barrier()
+    rec = None if args.no_kernel_events else profiling.enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_fn(lr_img, gt)
+    barrier()
+    dt = time.perf_counter() - t0
+    profiling.disable()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    out = {
+        "metric": "SR training images/sec (128->512 x4, bf16)", "value": round(value, 3), "unit": "img/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("BSRGAN RRDBNet x4 generator-only (L1), 23 RRDB, batch %d/GPU, %d->%d" % (B, h, 4 * h))
+                   if args.workload == "g_only" else
+                   ("BSRGAN full GAN step (RRDBNet + U-Net D + VGG19 content), batch %d/GPU, %d->%d" % (B, h, 4 * h)),
+                   "global_batch": B * world, "num_rrdb": args.num_rrdb, "parallelism": "dp%d" % world,
+                   "flop_per_image": FLOP_PER_IMG[args.workload]},
+        "step_tflops_per_gpu": round(value / world * FLOP_PER_IMG[args.workload] * (args.num_rrdb / 23.0) / 1e12, 2),
+    }
+    if rank == 0:
+        if rec is not None:
+            out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS)
+            out["kernel_classes"] = profiling.summary(rec)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, h, args.num_rrdb)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(workload: str, h: int, num_rrdb: int):
+    """The CPU oracle's training iteration (oracle/srgan_oracle.py, torch-CPU fp32) on a bounded sample:
+    batch 1 of the same 128->512 workload, 1 warm-up + 2 timed iterations."""
+    import torch
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(num_rrdb=num_rrdb)
+    G = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    opt = O.AdamState(G, O.g_param_names(G))
+    lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        if workload == "g_only":
+            O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
+        else:
+            raise NotImplementedError
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "batch 1, %d->%d, fp32, 1 warm-up + 2 timed iterations (min)" % (h, 4 * h)}
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,7 @@ from torch import Tensor, nn
 
 from . import _abi as A
 from . import ops
+from . import profiling
 
 _ENGINES: "weakref.WeakKeyDictionary[nn.Module, object]" = weakref.WeakKeyDictionary()
 
@@ -397,10 +398,15 @@ class TrunkEngine:
             A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.xin), dtc, 32, None, None, st), "nchw_to_nhwc")
         else:
             A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.Cc, H, W, A.view(sp.catb(0)), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
-        for a in sp.fw:
-            rc = L.srganfd_conv2d(C.byref(a), st)
-            if rc:
-                A.check(rc, "conv2d")
+        rec = profiling.REC
+        if rec is None:
+            for a in sp.fw:
+                rc = L.srganfd_conv2d(C.byref(a), st)
+                if rc:
+                    A.check(rc, "conv2d")
+        else:
+            for a in sp.fw:
+                rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d"))
         if self.full:
             out = torch.empty(N, self.out_ch, sp.hs, sp.ws, dtype=torch.float32, device=dev)
             A.check(L.srganfd_nhwc_to_nchw(A.view(sp.srp), A.F32, N, self.out_ch, sp.hs, sp.ws, out.data_ptr(), 1, st), "nhwc_to_nchw")
@@ -426,17 +432,25 @@ class TrunkEngine:
         else:
             A.check(L.srganfd_nchw_to_nhwc(dout.data_ptr(), N, self.Cc, H, W, A.view(sp.dy[(self.R - 1) % 4]), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
         gptr = flat_grad.data_ptr()
+        rec = profiling.REC
         for item in sp.bw:
             kind = item[0]
             if kind == "conv":
-                rc = L.srganfd_conv2d(C.byref(item[1]), st)
-                if rc:
-                    A.check(rc, "conv2d(dgrad)")
+                if rec is None:
+                    rc = L.srganfd_conv2d(C.byref(item[1]), st)
+                    if rc:
+                        A.check(rc, "conv2d(dgrad)")
+                else:
+                    a = item[1]
+                    rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
             elif kind == "wgrad":
                 _, plan, xv, dyv, goff = item
-                rc = L.srganfd_conv2d_wgrad(plan.host, plan.dev.data_ptr(), xv, dyv, gptr + 4 * goff, None, sp.wg_ws.data_ptr(), sp.wg_ws.numel(), st)
-                if rc:
-                    A.check(rc, "conv2d_wgrad")
+                run = lambda: A.check(L.srganfd_conv2d_wgrad(plan.host, plan.dev.data_ptr(), xv, dyv, gptr + 4 * goff, None,
+                                                             sp.wg_ws.data_ptr(), sp.wg_ws.numel(), st), "conv2d_wgrad")
+                if rec is None:
+                    run()
+                else:
+                    rec.bracket(plan.label, plan.flops, run)
             else:
                 item[1]()
         dx = None

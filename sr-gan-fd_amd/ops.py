@@ -112,6 +112,9 @@ class WgradPlan:
             w.dw_off, w.db_off = c["dw_off"], c.get("db_off", -1)
             w.co_dst, w.ci_dst = c["co_dst"], c["ci_dst"]
             w.alpha, w.beta, w.alpha_off = c.get("alpha", 1.0), c.get("beta", 0.0), c.get("alpha_off", -1)
+        ho, wo = s.h_out, s.w_out
+        self.flops = sum(2.0 * n * ho * wo * ksize * ksize * c["co_dst"] * c["ci_dst"] for c in convs)
+        self.label = f"wgrad_kernel<{'bf16' if dtype == A.BF16 else 'f32'},KS={ksize},S={stride}>+reduce"
         L = A.lib()
         nbytes = L.srganfd_wgrad_plan_bytes(C.byref(s), carr)
         if nbytes == 0:
