@@ -34,6 +34,30 @@ def conv_flops(a) -> float:
     return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
 
 
+def log(msg):
+    """progress on stderr (rank 0 prints the single JSON result line on stdout)"""
+    print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores() -> int:
+    """CPU share of this process: min(affinity, cgroup quota); capped at 16 (the GPU box's share per GPU)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,8 +118,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("model + inputs ready (B=%d/GPU, %dx%d -> %dx%d), warm-up" % (B, h, h, 4 * h, 4 * h))
+    for i in range(args.warmup):
         step_fn(lr_img, gt)
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
     barrier()
     rec = None if args.no_kernel_events else profiling.enable()
     t0 = time.perf_counter()
@@ -104,6 +131,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     profiling.disable()
+    log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -139,12 +167,9 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     import torch
     from oracle import srgan_oracle as O
     from sr_gan_fd_amd import model as M
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log("cpu baseline: oracle on %d threads" % cores)
     torch.manual_seed(0)
     g = M.bsrgan_x4(num_rrdb=num_rrdb)
     G = {k: v.detach().clone() for k, v in g.state_dict().items()}
@@ -158,6 +183,7 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
         else:
             raise NotImplementedError
         times.append(time.perf_counter() - t0)
+        log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
     t = min(times[1:])
     return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port",
             "sample": "batch 1, %d->%d, fp32, 1 warm-up + 2 timed iterations (min)" % (h, 4 * h)}
