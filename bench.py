@@ -163,7 +163,7 @@ def main():
 
 def cpu_baseline(workload: str, h: int, num_rrdb: int):
     """The CPU oracle's training iteration (oracle/srgan_oracle.py, torch-CPU fp32) on a bounded sample:
-    batch 1 of the same 128->512 workload, 1 warm-up + 2 timed iterations."""
+    batch 1 of the same 128->512 workload, 1 warm-up + 8 timed iterations (about 10 s of CPU work)."""
     import torch
     from oracle import srgan_oracle as O
     from sr_gan_fd_amd import model as M
@@ -176,7 +176,7 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     opt = O.AdamState(G, O.g_param_names(G))
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
     times = []
-    for it in range(3):
+    for it in range(9):
         t0 = time.perf_counter()
         if workload == "g_only":
             O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
@@ -186,7 +186,7 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
         log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
     t = min(times[1:])
     return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "batch 1, %d->%d, fp32, 1 warm-up + 2 timed iterations (min)" % (h, 4 * h)}
+            "sample": "batch 1, %d->%d, fp32, 1 warm-up + 8 timed iterations (min)" % (h, 4 * h)}
 
 
 if __name__ == "__main__":
