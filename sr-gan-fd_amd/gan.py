@@ -1,0 +1,97 @@
+"""Fused GAN training iteration -- the reference's BSRGAN/train_bsrgan.py:387-483 on the HIP engines.
+
+Order kept exactly: D(gt) forward+backward, G forward, D(sr.detach())
+forward+backward (gradients accumulate), D Adam step, freeze D, pixel (L1) + content (VGG-19, detached:
+logged only) + adversarial (BCE vs ones through the UPDATED D; spectral-norm u/v advance a third time),
+G backward (through D's data gradient only), G Adam step, EMA update.
+Data parallel: one flat-gradient all-reduce per network per iteration (D after its second backward,
+G after its backward) over RCCL; losses are means over the local shard, identical maths to the
+single-process step on the concatenated batch.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _abi as A
+from .engine import generator_engine
+from .engine_d import discriminator_engine
+from .trainer import FlatAdamEMA
+
+
+class GanTrainer:
+    def __init__(self, g_model, d_model, content_criterion=None, *, g_lr: float = 8e-5, d_lr: float = 2e-4, betas=(0.9, 0.999),
+                 eps: float = 1e-4, weight_decay: float = 0.0, ema_decay: float = 0.999, pixel_weight: float = 20.0,
+                 content_weight: float = 1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None):
+        # defaults = BSRGAN/bsrgan_config.py:137-159
+        self.g, self.d, self.content = g_model, d_model, content_criterion
+        self.ge, self.de = generator_engine(g_model), discriminator_engine(d_model)
+        dev = next(g_model.parameters()).device
+        self.dev = dev
+        self.g_opt = FlatAdamEMA(self.ge.fp.sync(dev), g_lr, betas, eps, weight_decay, ema_decay)
+        self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None)
+        self.pw, self.cw, self.aw = pixel_weight, content_weight, adversarial_weight
+        self.train_generator = train_generator
+        self.pg = process_group
+        # [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt) prob, D(sr) prob]
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
+        self.content_vals: Optional[Tensor] = None
+        self._bufs: Dict[tuple, Tensor] = {}
+
+    def _buf(self, name, like: Tensor) -> Tensor:
+        b = self._bufs.get((name, tuple(like.shape)))
+        if b is None:
+            b = torch.empty_like(like)
+            self._bufs[(name, tuple(like.shape))] = b
+        return b
+
+    def _allreduce(self, grad: Tensor) -> float:
+        if self.pg is None:
+            return 1.0
+        import torch.distributed as dist
+        dist.all_reduce(grad, group=self.pg)
+        return 1.0 / dist.get_world_size(self.pg)
+
+    def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
+        s = self.scalars.data_ptr()
+        A.check(A.lib().srganfd_bce_logits(logits.data_ptr(), logits.numel(), target, weight, s + 4 * slot, 0,
+                                           (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight,
+                                           self.ws.data_ptr(), A.stream_ptr()), "bce_logits")
+
+    def step(self, lr_img: Tensor, gt: Tensor) -> Tensor:
+        """One iteration; returns the device tensor [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt), D(sr), 0, 0]
+        (no host synchronisation inside; content-loss values are in ``self.content_vals``)."""
+        L, st = A.lib(), A.stream_ptr()
+        ge, de = self.ge, self.de
+        gt = gt.contiguous().float()
+        # ---- discriminator ----
+        gt_out = de.forward(gt, True)
+        dl = self._buf("dl", gt_out)
+        self._bce(gt_out, 1.0, 1.0, 0, 4, dl)
+        gd1, _ = de.backward(de._last, de.token, dl, True, False)
+        sr = ge.forward(lr_img, True)
+        g_sp, g_tok = ge._last, ge.token
+        sr_out = de.forward(sr, True)
+        self._bce(sr_out, 0.0, 1.0, 1, 5, dl)
+        gd2, _ = de.backward(de._last, de.token, dl, True, False)
+        A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
+        self.d_opt.step(gd2, self._allreduce(gd2))
+        # ---- generator ----
+        dsr = self._buf("dsr", sr)
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+                                  self.ws.data_ptr(), st), "l1_loss")
+        if self.content is not None:
+            self.content_vals = self.content(sr, gt) * self.cw
+        adv_out = de.forward(sr, True)                      # updated D, SN state advances again (train_bsrgan.py:452)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
+        if self.train_generator:
+            _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
+            A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
+            gg, _ = ge.backward(g_sp, g_tok, dsr, False)
+            self.g_opt.step(gg, self._allreduce(gg))
+            ge.fp._seen = None
+        self.sr = sr
+        return self.scalars

@@ -1,0 +1,256 @@
+"""GPU parity of the discriminator, spectral norm, losses, optimizer, content loss and the full GAN
+iteration (through the C ABI) against golden vectors captured from the reference and the CPU oracle.
+
+f32 mode tolerance 1e-3 (north_star); bf16 mode (benchmark dtype) bounded at 5e-2 and reported.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import checksum, load_golden, scaled_init, table, sd_to_params
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 1e-3, torch.bfloat16: 5e-2}
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("op", ["bilinear_fwd", "bilinear_bwd", "nearest_bwd", "maxpool"])
+def test_resample_kernels(op):
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(0)
+    n, h, w, c = 2, 6, 10, 32
+    L, st = A.lib(), A.stream_ptr()
+    if op == "bilinear_fwd":
+        x = torch.randn(n, c, h, w)
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        a, b = x.permute(0, 2, 3, 1).contiguous().cuda(), torch.empty(n, 2 * h, 2 * w, c, device="cuda")
+        A.check(L.srganfd_resample(1, A.view(a), A.view(b), A.F32, n, h, w, c, st))
+    elif op in ("bilinear_bwd", "nearest_bwd"):
+        x = torch.randn(n, c, h, w, requires_grad=True)
+        dy = torch.randn(n, c, 2 * h, 2 * w)
+        mode = dict(mode="bilinear", align_corners=False) if op == "bilinear_bwd" else dict(mode="nearest")
+        F.interpolate(x, scale_factor=2, **mode).backward(dy)
+        ref = x.grad
+        a, b = dy.permute(0, 2, 3, 1).contiguous().cuda(), torch.empty(n, h, w, c, device="cuda")
+        A.check(L.srganfd_resample(2 if op == "bilinear_bwd" else 0, A.view(a), A.view(b), A.F32, n, h, w, c, st))
+    else:
+        x = torch.randn(n, c, h, w)
+        ref = F.max_pool2d(x, 2, 2)
+        a, b = x.permute(0, 2, 3, 1).contiguous().cuda(), torch.empty(n, h // 2, w // 2, c, device="cuda")
+        A.check(L.srganfd_resample(3, A.view(a), A.view(b), A.F32, n, h, w, c, st))
+    torch.cuda.synchronize()
+    assert _rel(b.permute(0, 3, 1, 2), ref) < 1e-6
+
+
+def test_adam_ema_matches_torch():
+    from sr_gan_fd_amd.trainer import FlatAdamEMA
+    torch.manual_seed(0)
+    p0 = torch.randn(1000)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], 2e-4, (0.9, 0.999), 1e-4, 0.0)
+    flat = p0.clone().cuda()
+    mine = FlatAdamEMA(flat, 2e-4, (0.9, 0.999), 1e-4, 0.0, ema_decay=0.999)
+    ema = None
+    for it in range(3):
+        g = torch.randn(1000)
+        ref.grad = g.clone()
+        opt.step()
+        mine.step(g.cuda())
+        ema = ref.detach().clone() if ema is None else (1 - 0.999) * ema + 0.999 * ref.detach()
+    torch.cuda.synchronize()
+    assert _rel(flat, ref) < 1e-6
+    assert _rel(mine.ema, ema) < 1e-6
+
+
+def test_losses_match_torch():
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(0)
+    L, st = A.lib(), A.stream_ptr()
+    a, b = torch.rand(2, 3, 40, 40), torch.rand(2, 3, 40, 40)
+    ar = a.clone().requires_grad_(True)
+    ref = 20.0 * F.l1_loss(ar, b)
+    ref.backward()
+    out, ws = torch.zeros(2, device="cuda"), torch.empty(A.LOSS_WS_FLOATS, device="cuda")
+    ag, grad = a.cuda(), torch.empty(2, 3, 40, 40, device="cuda")
+    A.check(L.srganfd_l1_loss(ag.data_ptr(), b.cuda().data_ptr(), a.numel(), 20.0, out.data_ptr(), 0, grad.data_ptr(), 20.0, ws.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - ref.item()) < 1e-5 * abs(ref.item()) and _rel(grad, ar.grad) < 1e-6
+    x = torch.randn(2, 1, 40, 40) * 3
+    for target in (0.0, 1.0):
+        xr = x.clone().requires_grad_(True)
+        ref = 0.5 * F.binary_cross_entropy_with_logits(xr, torch.full_like(x, target))
+        ref.backward()
+        xg, g2 = x.cuda(), torch.empty_like(x, device="cuda")
+        A.check(L.srganfd_bce_logits(xg.data_ptr(), x.numel(), target, 0.5, out.data_ptr(), 0, out.data_ptr() + 4, g2.data_ptr(), 0.5, ws.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert abs(out[0].item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert abs(out[1].item() - torch.sigmoid(x).mean().item()) < 1e-6
+        assert _rel(g2, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminator(golden_dir, dtype):
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "discriminator.npz")
+    torch.manual_seed(0)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    d.compute_dtype = dtype
+    d.cuda().train()
+    x = torch.tensor(g["x"]).cuda()
+    for it in range(3):
+        logits = d(x)
+        e = _rel(logits, g[f"train{it}_logits"])
+        print(f"D {dtype} train fwd {it}: logits err {e:.2e}")
+        assert e < TOL[dtype]
+        sd = d.state_dict()
+        for layer in ("down_block1", "up_block1", "conv3"):   # power iteration runs in fp32 in both modes
+            assert _rel(sd[f"{layer}.0.weight_u"], g[f"train{it}_{layer}_u"]) < 1e-4
+            assert _rel(sd[f"{layer}.0.weight_v"], g[f"train{it}_{layer}_v"]) < 1e-4
+    loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    assert abs(loss.item() - float(g["bce_ones"])) < TOL[dtype]
+    loss.backward()
+    named = dict(d.named_parameters())
+    worst = 0.0
+    for k in ("conv1.weight", "conv4.weight", "conv4.bias", "conv3.0.weight_orig"):
+        worst = max(worst, _rel(named[k].grad, g[f"grad/{k}"]))
+    print(f"D {dtype}: worst grad err {worst:.2e}")
+    assert worst < (2e-3 if dtype == torch.float32 else 1e-1)
+    if dtype == torch.float32:
+        for k, want in table(g, "gsum").items():
+            got = checksum(named[k].grad)
+            assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * abs(want[1]) + 1e-12), f"D grad checksum {k}: {got} vs {want}"
+    d.eval()
+    with torch.no_grad():
+        assert _rel(d(x), g["eval_logits"]) < TOL[dtype]
+    d.train()
+    for p in d.parameters():
+        p.requires_grad = False
+    xin = x.clone().requires_grad_(True)
+    lg = d(xin)
+    assert _rel(lg, g["train3_logits"]) < TOL[dtype]
+    F.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    e = _rel(xin.grad, g["train3_dx"])
+    print(f"D {dtype}: input-gradient err {e:.2e}")
+    assert e < (2e-3 if dtype == torch.float32 else 1e-1)
+
+
+def _build_gan(dtype):
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    gen = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(gen, 3.0, 0.5)
+    d.compute_dtype = gen.compute_dtype = dtype
+    return gen.cuda().train(), d.cuda().train()
+
+
+def test_gan_steps_fused_trainer(golden_dir):
+    """GanTrainer.step == two iterations of train_bsrgan.py:387-483 (golden, content loss stubbed to 0)"""
+    from sr_gan_fd_amd.gan import GanTrainer
+    g = load_golden(golden_dir, "gan_steps.npz")
+    gen, d = _build_gan(torch.float32)
+    tr = GanTrainer(gen, d, None)
+    for it in range(2):
+        s = tr.step(torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()).cpu().numpy()
+        want = g[f"it{it}_scalars"]  # d_loss, pixel, content, adv, D(gt), D(sr)
+        got = [s[0] + s[1], s[2], 0.0, s[3], s[4], s[5]]
+        print(f"GAN it{it}: got {got} want {list(want)}")
+        assert np.allclose(got, want, rtol=1e-3, atol=1e-5)
+        assert _rel(tr.sr, g[f"it{it}_sr"]) < 1e-3
+        assert _rel(gen.conv4.bias, g[f"it{it}_g_conv4_bias"]) < 1e-3
+        assert _rel(d.conv4.weight, g[f"it{it}_d_conv4_weight"]) < 1e-3
+        for sd, key in ((gen.state_dict(), f"it{it}_wsum_g"), (d.state_dict(), f"it{it}_wsum_d")):
+            for k, want_c in table(g, key).items():
+                assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=2e-4 * abs(want_c[1])), f"{key} {k}"
+        ema = dict(zip(tr.ge.fp.names, tr.ge.fp.grad_views(tr.g_opt.ema)))
+        for k, want_c in table(g, f"it{it}_wsum_ema").items():
+            if k != "n_averaged":
+                assert np.allclose(checksum(ema[k[len("module."):]]), want_c, rtol=2e-3, atol=2e-4 * abs(want_c[1])), f"EMA {k}"
+
+
+def test_gan_steps_dropin_modules(golden_dir):
+    """the reference's own loop (torch.optim.Adam, AveragedModel, autograd, retain_graph) over the drop-in modules"""
+    from torch.optim.swa_utils import AveragedModel
+    g = load_golden(golden_dir, "gan_steps.npz")
+    gen, d = _build_gan(torch.float32)
+    ema = AveragedModel(gen, avg_fn=lambda a, p, n: (1 - 0.999) * a + 0.999 * p)
+    d_opt = torch.optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)
+    g_opt = torch.optim.Adam(gen.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    for it in range(2):
+        lr, gt = torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()
+        real, fake = torch.ones(2, 1, 64, 64, device="cuda"), torch.zeros(2, 1, 64, 64, device="cuda")
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        d_loss_hr = bce(gt_output, real)
+        d_loss_hr.backward(retain_graph=True)
+        sr = gen(lr)
+        sr_output = d(sr.detach().clone())
+        d_loss_sr = bce(sr_output, fake)
+        d_loss_sr.backward()
+        d_opt.step()
+        for p in d.parameters():
+            p.requires_grad = False
+        gen.zero_grad(set_to_none=True)
+        pixel = 20.0 * l1(sr, gt)
+        adv = 0.5 * bce(d(sr), real)
+        (pixel + adv).backward()
+        g_opt.step()
+        ema.update_parameters(gen)
+        got = [(d_loss_hr + d_loss_sr).item(), pixel.item(), 0.0, adv.item(), torch.sigmoid(gt_output).mean().item(),
+               torch.sigmoid(sr_output).mean().item()]
+        assert np.allclose(got, g[f"it{it}_scalars"], rtol=1e-3, atol=1e-5), f"{got} vs {g[f'it{it}_scalars']}"
+        for sd, key in ((gen.state_dict(), f"it{it}_wsum_g"), (d.state_dict(), f"it{it}_wsum_d"), (ema.state_dict(), f"it{it}_wsum_ema")):
+            for k, want_c in table(g, key).items():
+                if k != "n_averaged":
+                    assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=2e-4 * abs(want_c[1])), f"{key} {k}"
+
+
+def test_gan_step_bf16_runs_close():
+    """bf16 (benchmark dtype) GAN iteration stays within 5e-2 of the f32 iteration on the same inputs"""
+    from sr_gan_fd_amd.gan import GanTrainer
+    torch.manual_seed(5)
+    lr, gt = torch.rand(2, 3, 16, 16).cuda(), torch.rand(2, 3, 64, 64).cuda()
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        gen, d = _build_gan(dt)
+        outs[dt] = GanTrainer(gen, d, None).step(lr, gt).cpu().numpy()[:6].copy()
+    print("GAN scalars f32 ", outs[torch.float32], "\nGAN scalars bf16", outs[torch.bfloat16])
+    assert np.allclose(outs[torch.bfloat16], outs[torch.float32], rtol=5e-2, atol=5e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_content_loss_vs_oracle(dtype):
+    """VGG-19 taps (parity pinned only against the CPU oracle: no torchvision / ImageNet weights offline)"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    nodes = ["features.2", "features.7", "features.16", "features.25", "features.34"]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    cl = M.ContentLoss(nodes, mean, std)
+    cl.compute_dtype = dtype
+    torch.manual_seed(3)
+    sr, gt = torch.rand(2, 3, 32, 48), torch.rand(2, 3, 32, 48)
+    P = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
+    want = O.content_loss(sr, gt, P, nodes, mean, std, taps_post_relu=True)
+    cl.cuda()
+    got = cl(sr.cuda(), gt.cuda())
+    assert got.shape == (1, 5) and not got.requires_grad
+    e = _rel(got, want)
+    print(f"content loss {dtype}: {got.cpu().numpy()} vs {want.numpy()} err {e:.2e}")
+    assert e < (1e-3 if dtype == torch.float32 else 5e-2)
+    if dtype == torch.float32:
+        cl2 = M.ContentLoss(nodes, mean, std, taps_post_relu=False)
+        cl2.compute_dtype = dtype
+        cl2.cuda()
+        want2 = O.content_loss(sr, gt, P, nodes, mean, std, taps_post_relu=False)
+        assert _rel(cl2(sr.cuda(), gt.cuda()), want2) < 1e-3
