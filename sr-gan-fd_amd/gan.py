@@ -18,6 +18,7 @@ from torch import Tensor
 from . import _abi as A
 from .engine import generator_engine
 from .engine_d import discriminator_engine
+from .parallel import allreduce_sum_
 from .trainer import FlatAdamEMA
 
 
@@ -49,11 +50,7 @@ class GanTrainer:
         return b
 
     def _allreduce(self, grad: Tensor) -> float:
-        if self.pg is None:
-            return 1.0
-        import torch.distributed as dist
-        dist.all_reduce(grad, group=self.pg)
-        return 1.0 / dist.get_world_size(self.pg)
+        return allreduce_sum_(grad, self.pg)
 
     def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
         s = self.scalars.data_ptr()

@@ -20,6 +20,7 @@ from torch import Tensor
 
 from . import _abi as A
 from .engine import generator_engine
+from .parallel import allreduce_sum_
 
 
 class FlatAdamEMA:
@@ -74,11 +75,7 @@ class GeneratorTrainer:
         A.check(A.lib().srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.loss_weight, self.loss_buf.data_ptr(), 0,
                                         self.dsr.data_ptr(), self.loss_weight, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
         grad, _ = eng.backward(sp, token, self.dsr, False)
-        scale = 1.0
-        if self.pg is not None:
-            import torch.distributed as dist
-            dist.all_reduce(grad, group=self.pg)      # RCCL ring over xGMI: one flat 67 MB buffer per step
-            scale = 1.0 / dist.get_world_size(self.pg)
+        scale = allreduce_sum_(grad, self.pg)          # RCCL over xGMI: ONE flat 67 MB buffer per step
         self.opt.step(grad, scale)
         eng.fp._seen = None                             # parameters changed behind autograd's back -> re-pack
         self.sr = sr

@@ -1,0 +1,79 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel glue used by bench.py / the trainers for N > 1."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from sr_gan_fd_amd import parallel as P
+    r, lr, w, pg = P.init_from_env("gloo")
+    assert (r, w) == (rank, world) and pg is not None
+    # 1. flat-gradient exchange: sum over ranks, 1/world returned for the optimizer
+    torch.manual_seed(100 + rank)
+    g = torch.randn(1003)
+    mine = g.clone()
+    scale = P.allreduce_sum_(g, pg)
+    torch.manual_seed(100)
+    a = torch.randn(1003)
+    torch.manual_seed(101)
+    b = torch.randn(1003)
+    ok1 = scale == 0.5 and torch.allclose(g * scale, (a + b) / 2, atol=1e-6)
+    # 2. parameters identical on every rank after the broadcast
+    p = torch.full((17,), float(rank + 1))
+    P.broadcast_(p, pg)
+    ok2 = bool(torch.all(p == 1.0))
+    # 3. shards tile the global batch exactly
+    batch = torch.arange(8 * 3).view(8, 3)
+    sh = P.shard(batch, rank, world)
+    gathered = [torch.empty_like(sh) for _ in range(world)]
+    dist.all_gather(gathered, sh, group=pg)
+    ok3 = torch.equal(torch.cat(gathered), batch)
+    # 4. data-parallel mean-loss gradient == single-process gradient on the concatenated batch
+    torch.manual_seed(7)
+    wgt = torch.randn(5, requires_grad=True)
+    x = torch.randn(8, 5)
+    full = (x @ wgt).abs().mean()
+    gfull, = torch.autograd.grad(full, wgt)
+    local = (P.shard(x, rank, world) @ wgt).abs().mean()
+    gl, = torch.autograd.grad(local, wgt)
+    gl = gl.clone()
+    sc = P.allreduce_sum_(gl, pg)
+    ok4 = torch.allclose(gl * sc, gfull, atol=1e-6)
+    t = P.max_over_ranks(float(rank + 1), pg, "cpu")
+    ok5 = t == float(world)
+    q.put((rank, ok1, ok2, ok3, ok4, ok5))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), f"rank {r[0]} failed: {r}"
+
+
+def test_shard_rejects_uneven_batch():
+    from sr_gan_fd_amd import parallel as P
+    with pytest.raises(ValueError):
+        P.shard(torch.zeros(5, 3), 0, 2)
