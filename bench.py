@@ -29,6 +29,10 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9}
 
 
+NODES = ["features.2", "features.7", "features.16", "features.25", "features.34"]   # bsrgan_config.py:130-132
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
 def conv_flops(a) -> float:
     """algorithmic FLOP of one fused-conv launch: 2 * pixels_out * k*k * cin * cout_store"""
     return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
@@ -103,9 +107,11 @@ def main():
     else:
         from sr_gan_fd_amd.gan import GanTrainer
         d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
-        d.compute_dtype = torch.bfloat16
+        cl = M.ContentLoss(NODES, MEAN, STD)      # seeded random VGG-19 weights (no ImageNet download offline)
+        d.compute_dtype = cl.compute_dtype = torch.bfloat16
         d.to(dev)
-        trainer = GanTrainer(g, d, process_group=pg)
+        cl.to(dev)
+        trainer = GanTrainer(g, d, cl, process_group=pg)
         step_fn = trainer.step
 
     gen = torch.Generator(device=dev)
@@ -175,18 +181,28 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     G = {k: v.detach().clone() for k, v in g.state_dict().items()}
     opt = O.AdamState(G, O.g_param_names(G))
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
+    n_it = 9
+    if workload == "gan":
+        n_it = 4
+        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+        d_opt = O.AdamState(D, O.d_param_names(D))
+        cl = M.ContentLoss(NODES, MEAN, STD)
+        VP = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
+        content_fn = lambda sr, gt_: O.content_loss(sr, gt_, VP, NODES, MEAN, STD)
     times = []
-    for it in range(9):
+    for it in range(n_it):
         t0 = time.perf_counter()
         if workload == "g_only":
             O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
         else:
-            raise NotImplementedError
+            O.gan_step(G, D, opt, d_opt, lr_img, gt, upscale=4, g_lr=8e-5, d_lr=2e-4, betas=(0.9, 0.999), eps=1e-4,
+                       pixel_weight=20.0, content_weight=1.0, adversarial_weight=0.5, content_fn=content_fn)
         times.append(time.perf_counter() - t0)
         log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
     t = min(times[1:])
     return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "batch 1, %d->%d, fp32, 1 warm-up + 8 timed iterations (min)" % (h, 4 * h)}
+            "sample": "batch 1, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (h, 4 * h, n_it - 1)}
 
 
 if __name__ == "__main__":
