@@ -35,7 +35,7 @@ struct ConvK {
   int cout_store;
   int tiles_x, tiles_y;
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
-  int act, y_f32;
+  int act, y_f32, fast_epi;
 };
 
 template <typename T> struct FragAB;
@@ -68,7 +68,11 @@ struct ConvCfg {
   static constexpr int XI = (NX + 255) / 256;
   static constexpr int NW = NR * WN_BYTES / 16;
   static constexpr int WI = (NW + 255) / 256;
-  static constexpr int LDS_BYTES = XBYTES + NR * WN_BYTES;
+  static constexpr int STAGE_BYTES = XBYTES + NR * WN_BYTES;
+  static constexpr int NB = 32 * NR;                           // output channels per workgroup
+  static constexpr int EPI_BYTES = TH * TW * NB * 4;           // fp32 tile for the vectorised epilogue
+  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int NROWS = (MR - 1) * STRIDE + KS;         // patch rows one wave touches
 };
 
 template <typename T> __device__ __forceinline__ int lds_x_chunk_off(int pix, int c16);
@@ -195,41 +199,120 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
     __syncthreads();
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
 
-    auto tap_body = [&](int tap) {
-      const int dy = tap / KS, dx = tap % KS;
+    // For a fixed kernel column kx and k-step s, the MR output rows of this wave and the KS kernel rows
+    // touch only NROWS = (MR-1)*S + KS patch rows: read each A fragment ONCE and reuse it for every
+    // (output row, kernel row) pair that needs it (6 LDS reads instead of 12 per 12 MFMAs at MR=4, KS=3).
+    auto col_body = [&](int kx, int s) {
+      Frag av[C::NROWS];
 #pragma unroll
-      for (int s = 0; s < C::KSTEPS; ++s) {
-        Frag b[NR];
+      for (int rr = 0; rr < C::NROWS; ++rr) {
+        const int pix = (wave * MR * STRIDE + rr) * C::PC + r * STRIDE + kx;
+        if constexpr (sizeof(T) == 2) av[rr] = *(const Frag*)(ldsX + lds_x_chunk_off<bf16_t>(pix, 2 * s + h));
+        else av[rr] = *(const Frag*)(ldsX + lds_x_f32_off(pix, 2 * s + h));
+      }
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        Frag bq[NR];
 #pragma unroll
         for (int nn = 0; nn < NR; ++nn)
-          b[nn] = *(const Frag*)(ldsW + ((nn * C::KT + tap) * C::KSTEPS + s) * 64 * C::FRAGB + lane * C::FRAGB);
+          bq[nn] = *(const Frag*)(ldsW + ((nn * C::KT + ky * KS + kx) * C::KSTEPS + s) * 64 * C::FRAGB + lane * C::FRAGB);
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          const int pix = ((wave * MR + m) * STRIDE + dy) * C::PC + r * STRIDE + dx;
-          Frag av;
-          if constexpr (sizeof(T) == 2) av = *(const Frag*)(ldsX + lds_x_chunk_off<bf16_t>(pix, 2 * s + h));
-          else av = *(const Frag*)(ldsX + lds_x_f32_off(pix, 2 * s + h));
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int nn = 0; nn < NR; ++nn) acc[m][nn] = mfma32<T>(av, b[nn], acc[m][nn]);
-        }
+          for (int nn = 0; nn < NR; ++nn) acc[m][nn] = mfma32<T>(av[m * STRIDE + ky], bq[nn], acc[m][nn]);
       }
     };
     if constexpr (sizeof(T) == 2) {
-      // taps of one kernel row unrolled, kernel rows rolled: keeps the live LDS-read set small
 #pragma unroll 1
-      for (int ky = 0; ky < KS; ++ky) {
+      for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) tap_body(ky * KS + kx);
+        for (int s2 = 0; s2 < C::KSTEPS; ++s2) col_body(kx, s2);
       }
     } else {
 #pragma unroll 1
-      for (int tap = 0; tap < C::KT; ++tap) tap_body(tap);
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll 2
+        for (int s2 = 0; s2 < C::KSTEPS; ++s2) col_body(kx, s2);
+      }
     }
   }
 
   // ---- epilogue (see srganfd.h for the formula) ----
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
+  if (a.fast_epi) {
+    // Vectorised epilogue: (1) every lane applies the per-channel part (alpha, bias, activation, scale) to
+    // its accumulators and drops them as fp32 into an LDS tile [pixel][channel]; (2) the workgroup
+    // re-reads the tile 16 output bytes per lane, adds residuals / applies the LeakyReLU' mask with
+    // 16-byte global loads, and issues 16-byte stores (one pixel's channels are contiguous in NHWC).
+    float* tile = (float*)smem;
+    __syncthreads();   // all waves are done with the staging buffers
+#pragma unroll
+    for (int nn = 0; nn < NR; ++nn) {
+      const int co = (nb * NR + nn) * 32 + r;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = alpha * acc[m][nn][i] + bv;
+          if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+          else if (a.act == SRGANFD_ACT_RELU) v = fmaxf(v, 0.f);
+          tile[((wave * MR + m) * 32 + mfma32_row(i, lane)) * C::NB + nn * 32 + r] = v * a.post_scale;
+        }
+    }
+    __syncthreads();
+    constexpr int CP = C::NB / C::E16;                 // 16-byte output chunks per pixel
+    constexpr int ITEMS = C::TH * 32 * CP;
+    const int cbase = nb * C::NB;
+#pragma unroll 2
+    for (int item = tid; item < ITEMS; item += 256) {
+      const int pix = item / CP, ck = item % CP;
+      const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+      if (oy < a.Hout && ox < a.Wout) {
+        const size_t p = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+        float v[C::E16];
+        const f32x4* tp = (const f32x4*)(tile + pix * C::NB + ck * C::E16);
+#pragma unroll
+        for (int q = 0; q < C::E16 / 4; ++q) {
+          const f32x4 t4 = tp[q];
+          v[4 * q] = t4[0]; v[4 * q + 1] = t4[1]; v[4 * q + 2] = t4[2]; v[4 * q + 3] = t4[3];
+        }
+        const int cch = cbase + ck * C::E16;
+        auto load16 = [&](const void* base, int Cs, int c0, float* out) {
+          const u32x4 raw = *(const u32x4*)((const T*)base + p * Cs + c0 + cch);
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { out[2 * q] = __builtin_bit_cast(float, raw[q] << 16); out[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u); }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = __builtin_bit_cast(float, raw[q]);
+          }
+        };
+        float t[C::E16];
+        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, t);
+#pragma unroll
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * t[q]; }
+        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, t);
+#pragma unroll
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * t[q]; }
+        if (a.mask) { load16(a.mask, a.mC, a.m_c0, t);
+#pragma unroll
+          for (int q = 0; q < C::E16; ++q) v[q] *= t[q] > 0.f ? 1.f : a.mask_slope; }
+        u32x4 o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (unsigned)f2bf(v[2 * q]) | ((unsigned)f2bf(v[2 * q + 1]) << 16);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = __builtin_bit_cast(unsigned, v[q]);
+        }
+        *(u32x4*)((T*)a.y + p * a.yC + a.y_c0 + cch) = o;
+      }
+    }
+    return;
+  }
+  // generic epilogue (padded channel counts, fp32 output): scalar stores
   T* __restrict__ yg = (T*)a.y;
   const T* __restrict__ r1g = (const T*)a.r1;
   const T* __restrict__ r2g = (const T*)a.r2;
@@ -242,11 +325,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       const int oy = oy0 + wave * MR + m;
+      if (!cok || oy >= a.Hout) continue;
+      const size_t prow = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + a.oox;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ox = ox0 + mfma32_row(i, lane);
-        if (cok && oy < a.Hout && ox < a.Wout) {
-          const size_t p = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+        if (ox < a.Wout) {
+          const size_t p = prow + ox * a.osx;
           float v = alpha * acc[m][nn][i] + bv;
           if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
           else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -329,6 +414,8 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.tiles_x = k.tiles_y = 0;
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;
+  auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
+  k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F32) return dispatch_conv<float>(a, k, stream);
   return set_err(SRGANFD_EINVAL, "conv2d: bad dtype %d", a->dtype);
