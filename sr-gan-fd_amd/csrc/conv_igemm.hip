@@ -280,13 +280,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
         }
         const int cch = cbase + ck * C::E16;
         auto load16 = [&](const void* base, int Cs, int c0, float* out) {
-          const u32x4 raw = *(const u32x4*)((const T*)base + p * Cs + c0 + cch);
+          const T* src = (const T*)base + p * Cs + c0 + cch;
           if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { out[2 * q] = __builtin_bit_cast(float, raw[q] << 16); out[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u); }
+            const u32x4 raw = *(const u32x4*)src;
+            const unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+            out[0] = __uint_as_float(w0 << 16); out[1] = __uint_as_float(w0 & 0xffff0000u);
+            out[2] = __uint_as_float(w1 << 16); out[3] = __uint_as_float(w1 & 0xffff0000u);
+            out[4] = __uint_as_float(w2 << 16); out[5] = __uint_as_float(w2 & 0xffff0000u);
+            out[6] = __uint_as_float(w3 << 16); out[7] = __uint_as_float(w3 & 0xffff0000u);
           } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) out[q] = __builtin_bit_cast(float, raw[q]);
+            const f32x4 rf = *(const f32x4*)src;
+            out[0] = rf[0]; out[1] = rf[1]; out[2] = rf[2]; out[3] = rf[3];
           }
         };
         float t[C::E16];
@@ -299,15 +303,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
         if (a.mask) { load16(a.mask, a.mC, a.m_c0, t);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] *= t[q] > 0.f ? 1.f : a.mask_slope; }
-        u32x4 o;
+        T* dstp = (T*)a.y + p * a.yC + a.y_c0 + cch;
         if constexpr (sizeof(T) == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (unsigned)f2bf(v[2 * q]) | ((unsigned)f2bf(v[2 * q + 1]) << 16);
+          u32x4 o;
+          o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          o[2] = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+          o[3] = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+          *(u32x4*)dstp = o;
         } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = __builtin_bit_cast(unsigned, v[q]);
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)dstp = o;
         }
-        *(u32x4*)((T*)a.y + p * a.yC + a.y_c0 + cch) = o;
       }
     }
     return;
