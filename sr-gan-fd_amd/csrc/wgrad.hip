@@ -22,10 +22,10 @@
 namespace srganfd {
 
 static constexpr int kWgMagic = 0x57475244;  // 'WGRD'
-static constexpr int kTH = 4;                // output rows per pixel tile
 
+static constexpr int kMaxWaves = 12;
 struct WgWave { int active, ci_rel, co_rel, ks_idx, ks_n, tap0, slab_base, bias_slab; };
-struct WgGroup { int x_c0, x_units, dy_c0, dy_units; WgWave w[4]; };
+struct WgGroup { int x_c0, x_units, dy_c0, dy_units; WgWave w[kMaxWaves]; };
 struct WgTask {
   long long dw_off, db_off, alpha_off;
   int co_dst, ci_dst, co_base, ci_base, tap0, ntap, ksize, slab_base, nslabs, bias_slab;
@@ -45,29 +45,42 @@ struct WgK {
   int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y;
 };
 
-__device__ __forceinline__ int swz_f(int upad, int pix) { return upad >= 4 ? (pix & 3) : (upad == 2 ? ((pix >> 1) & 1) : 0); }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+template <int KS, int STRIDE> struct WgTile { static constexpr int TH = (STRIDE == 1) ? 8 : 4; };
+
+template <int KS> struct WgWaves { static constexpr int NW = (KS == 3) ? 12 : (KS == 4 ? 8 : 4); };
+
+// One wave = one (32 ci x 32 co) block x ONE kernel row (KS taps, KS*16 accumulator registers), so a
+// 3x3 workgroup runs 12 waves (3 per SIMD, <=168 VGPRs each) over the same staged tiles.
 template <typename T, int KS, int STRIDE>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(const WgK a) {
-  constexpr int NT = (KS == 4) ? 8 : KS * KS;
-  constexpr int PR = (kTH - 1) * STRIDE + KS, PC = 31 * STRIDE + KS;
+__global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a) {
+  constexpr int TH = WgTile<KS, STRIDE>::TH;
+  constexpr int NTHR = 64 * WgWaves<KS>::NW;
+  constexpr int NT = KS;
+  constexpr int PR = (TH - 1) * STRIDE + KS, PC = 31 * STRIDE + KS;
   constexpr int UB = 32 * (int)sizeof(T);   // bytes of one 32-channel unit
-  constexpr int CPU = UB / 16;              // 16-byte chunks per unit
+  constexpr int CPU = UB / 16;              // 16-byte chunks per unit (4 bf16 / 8 f32)
+  constexpr int CPU_SH = (CPU == 4) ? 2 : 3;
   constexpr int E16 = 16 / (int)sizeof(T);
+  // staging items per thread for the largest group (2 units each side)
+  constexpr int XI = (PR * PC * 2 * CPU + NTHR - 1) / NTHR;
+  constexpr int YI = (TH * 32 * 2 * CPU + NTHR - 1) / NTHR;
+  constexpr bool kPrefetch = sizeof(T) == 2;   // bf16: next tile's loads are issued before the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WgGroup& G = a.groups[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WgWave W = G.w[wave];
   const int r = lane & 31, h = lane >> 5;
-  const int xRowB = a.x_upad * UB, dyRowB = a.dy_upad * UB;
+  const int xu_sh = G.x_units == 2 ? 1 : 0, yu_sh = G.dy_units == 2 ? 1 : 0;   // units are 1 or 2
+  const int xRowB = UB << xu_sh, dyRowB = UB << yu_sh;
   char* ldsX = smem;
-  char* ldsY = smem + PR * PC * xRowB;
+  char* ldsY = smem + PR * PC * (UB * 2);
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
-  const T* __restrict__ xg = (const T*)a.x;
-  const T* __restrict__ dyg = (const T*)a.dy;
+  const T* __restrict__ xg = (const T*)a.x + a.x_c0v + G.x_c0;
+  const T* __restrict__ dyg = (const T*)a.dy + a.dy_c0v + G.dy_c0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -76,42 +89,91 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
 
-  const int xItems = PR * PC * G.x_units * CPU;
-  const int yItems = kTH * 32 * G.dy_units * CPU;
-  const int rows_per = kTH / W.ks_n;
+  const int xItems = (PR * PC * CPU) << xu_sh;
+  const int yItems = (TH * 32 * CPU) << yu_sh;
+  const int rows_per = TH / W.ks_n;
+  auto swz = [](int ush, int pix) { return ush ? ((pix >> 1) & 1) : 0; };
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
-    int t = tile;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int n = t / a.tiles_y;
-    const int oy0 = ty * kTH, ox0 = tx * 32;
-    __syncthreads();  // previous tile's LDS reads done
-    for (int item = tid; item < xItems; item += 256) {
-      const int cpp = G.x_units * CPU;
-      const int pix = item / cpp, c16 = item - pix * cpp;
-      const int unit = c16 / CPU, w16 = c16 - unit * CPU;
+  auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
+    const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    n = tile / a.tiles_y; oy0 = ty * TH; ox0 = tx * 32;
+  };
+  auto load_x = [&](int i, int n, int oy0, int ox0) -> u32x4 {
+    const int item = tid + i * NTHR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (item < xItems) {
+      const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
-      u32x4 v = {0u, 0u, 0u, 0u};
       if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-        v = *(const u32x4*)(xg + ((size_t)(n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + a.x_c0v + G.x_c0 + unit * 32 + w16 * E16);
-      const int f = sizeof(T) == 2 ? swz_f(a.x_upad, pix) : 0;
+        v = *(const u32x4*)(xg + ((size_t)(n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + c16 * E16);
+    }
+    return v;
+  };
+  auto store_x = [&](int i, u32x4 v) {
+    const int item = tid + i * NTHR;
+    if (item < xItems) {
+      const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
+      const int unit = c16 >> CPU_SH, w16 = c16 & (CPU - 1);
+      const int f = sizeof(T) == 2 ? swz(xu_sh, pix) : 0;
       *(u32x4*)(ldsX + pix * xRowB + ((unit ^ f) * UB) + w16 * 16) = v;
     }
-    for (int item = tid; item < yItems; item += 256) {
-      const int cpp = G.dy_units * CPU;
-      const int pix = item / cpp, c16 = item - pix * cpp;
-      const int unit = c16 / CPU, w16 = c16 - unit * CPU;
-      const int py = pix >> 5, px = pix & 31;
-      const int oy = oy0 + py, ox = ox0 + px;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < a.Hout && ox < a.Wout)
-        v = *(const u32x4*)(dyg + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.dyC + a.dy_c0v + G.dy_c0 + unit * 32 + w16 * E16);
-      const int f = sizeof(T) == 2 ? swz_f(a.dy_upad, pix) : 0;
+  };
+  auto load_y = [&](int i, int n, int oy0, int ox0) -> u32x4 {
+    const int item = tid + i * NTHR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (item < yItems) {
+      const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
+      const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.dyC + c16 * E16);
+    }
+    return v;
+  };
+  auto store_y = [&](int i, u32x4 v) {
+    const int item = tid + i * NTHR;
+    if (item < yItems) {
+      const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
+      const int unit = c16 >> CPU_SH, w16 = c16 & (CPU - 1);
+      const int f = sizeof(T) == 2 ? swz(yu_sh, pix) : 0;
       *(u32x4*)(ldsY + pix * dyRowB + ((unit ^ f) * UB) + w16 * 16) = v;
     }
+  };
+  constexpr int XR = kPrefetch ? XI : 1, YR = kPrefetch ? YI : 1;
+  u32x4 xr[XR], yr[YR];
+  auto prefetch = [&](int tile) {
+    if constexpr (kPrefetch) {
+      int n, oy0, ox0;
+      tile_origin(tile, n, oy0, ox0);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xr[i] = load_x(i, n, oy0, ox0);
+#pragma unroll
+      for (int i = 0; i < YI; ++i) yr[i] = load_y(i, n, oy0, ox0);
+    }
+  };
+  auto commit = [&](int tile) {
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) store_x(i, xr[i]);
+#pragma unroll
+      for (int i = 0; i < YI; ++i) store_y(i, yr[i]);
+    } else {
+      int n, oy0, ox0;
+      tile_origin(tile, n, oy0, ox0);
+#pragma unroll 4
+      for (int i = 0; i < XI; ++i) store_x(i, load_x(i, n, oy0, ox0));
+#pragma unroll 4
+      for (int i = 0; i < YI; ++i) store_y(i, load_y(i, n, oy0, ox0));
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += a.S) {
+    __syncthreads();  // previous tile's LDS reads done
+    commit(tile);
     __syncthreads();
+    if (tile + a.S < a.ntiles) prefetch(tile + a.S);
     if (W.active) {
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
@@ -126,14 +188,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
             bf16x8 bfrag;
             {
               const int p0 = ro * 32 + kc0, p1 = p0 + 4;
-              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p0 * dyRowB + ((W.co_rel ^ swz_f(a.dy_upad, p0)) * UB) + chb));
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p1 * dyRowB + ((W.co_rel ^ swz_f(a.dy_upad, p1)) * UB) + chb));
+              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p0 * dyRowB + ((W.co_rel ^ swz(yu_sh, p0)) * UB) + chb));
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p1 * dyRowB + ((W.co_rel ^ swz(yu_sh, p1)) * UB) + chb));
               u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
                           (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
               bfrag = __builtin_bit_cast(bf16x8, pk);
               if (W.bias_slab >= 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += bf2f(pk[j]);
+                bsum += bf2f((unsigned short)lo[0]) + bf2f((unsigned short)lo[1]) + bf2f((unsigned short)lo[2]) + bf2f((unsigned short)lo[3]) +
+                        bf2f((unsigned short)hi[0]) + bf2f((unsigned short)hi[1]) + bf2f((unsigned short)hi[2]) + bf2f((unsigned short)hi[3]);
               }
             }
 #pragma unroll
@@ -141,8 +203,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
               const int tap = W.tap0 + tl;
               const int dy = tap / KS, dx = tap - dy * KS;
               const int p0 = (ro * STRIDE + dy) * PC + kc0 * STRIDE + dx, p1 = p0 + 4 * STRIDE;
-              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p0 * xRowB + ((W.ci_rel ^ swz_f(a.x_upad, p0)) * UB) + chb));
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p1 * xRowB + ((W.ci_rel ^ swz_f(a.x_upad, p1)) * UB) + chb));
+              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p0 * xRowB + ((W.ci_rel ^ swz(xu_sh, p0)) * UB) + chb));
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p1 * xRowB + ((W.ci_rel ^ swz(xu_sh, p1)) * UB) + chb));
               u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
                           (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
               acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), bfrag, acc[tl], 0, 0, 0);
@@ -168,7 +230,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(co
     }
   }
   if (W.active) {
-    float* slab = a.slabs + (size_t)(W.slab_base + blockIdx.x * W.ks_n + W.ks_idx) * (NT * 1024);
+    float* slab = a.slabs + (size_t)(W.slab_base + blockIdx.x * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
@@ -228,90 +290,67 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   if ((hl + 2 * s->pad - s->ksize) / s->stride + 1 != s->h_out || (wl + 2 * s->pad - s->ksize) / s->stride + 1 != s->w_out)
     return set_err(SRGANFD_EINVAL, "wgrad: output dims inconsistent");
   const int KT = s->ksize * s->ksize;
-  const int NT = s->ksize == 4 ? 8 : KT;
-  const int nth = KT / NT;
+  const int NT = KT;                                   // taps per slab (all of them; one wave covers one kernel row)
+  const int NW = s->ksize == 3 ? 12 : (s->ksize == 4 ? 8 : 4);
+  const int cap = NW / s->ksize;                       // (ci,co) blocks per workgroup
   WgHeader& H = pb.hdr;
   memset(&H, 0, sizeof(H));
   H.magic = kWgMagic; H.dtype = s->dtype; H.N = s->n; H.Hin = s->h_in; H.Win = s->w_in; H.up = s->up ? 1 : 0;
   H.ks = s->ksize; H.stride = s->stride; H.pad = s->pad; H.Hout = s->h_out; H.Wout = s->w_out; H.ntap_wave = NT;
-  H.tiles_x = ceil_div(s->w_out, 32); H.tiles_y = ceil_div(s->h_out, kTH);
-  H.ntiles = s->n * H.tiles_x * H.tiles_y;
+  H.tiles_x = ceil_div(s->w_out, 32);
 
-  // wave tasks grouped into workgroups of 4 waves that share the staged x / dy channel ranges
-  struct WT { int conv, cb, ob, th, task; };
-  int max_xu = 1, max_yu = 1;
+  // Wave tasks = (32-channel x block, 32-channel dy block, tap half).  Tasks of ALL convs of the launch
+  // are bucketed by the 64-channel x range and 64-channel dy range they read (32-channel x range for the
+  // 4x4 stride-2 case, whose patch is 4x larger): one workgroup stages those ranges once and its four
+  // waves run the bucket's tasks (split over tile rows when a bucket holds fewer than four).
+  const int kTH = (s->stride == 1) ? 8 : 4;
+  H.tiles_y = ceil_div(s->h_out, kTH);
+  H.ntiles = s->n * H.tiles_x * H.tiles_y;
+  struct Bucket { int xb, yb; std::vector<int> tasks; std::vector<int> ci_abs, co_abs; };
+  std::vector<Bucket> buckets;
+  const int xdiv = (s->ksize == 4) ? 1 : 2;
   for (int c = 0; c < s->nconv; ++c) {
     const srganfd_wgrad_conv& cv = convs[c];
-    if (cv.cin <= 0 || cv.cin % 32 || cv.cout <= 0 || cv.cout % 32 || cv.ci_lo % 32 || cv.co_lo % 32 ||
+    if (cv.cin <= 0 || cv.cin % 32 || cv.cout <= 0 || cv.cout % 32 || cv.ci_lo % 32 || cv.co_lo % 32 || cv.ci_lo < 0 || cv.co_lo < 0 ||
         cv.ci_lo + cv.cin > s->x_channels || cv.co_lo + cv.cout > s->dy_channels)
       return set_err(SRGANFD_EINVAL, "wgrad: conv %d channel ranges invalid", c);
     const int cib = cv.cin / 32, cob = cv.cout / 32;
-    // task table (one per 32x32 block and tap half), slab bases filled later
-    const int task0 = (int)pb.tasks.size();
     for (int ob = 0; ob < cob; ++ob)
       for (int cb = 0; cb < cib; ++cb)
-        for (int th = 0; th < nth; ++th) {
+        {
           WgTask t; memset(&t, 0, sizeof(t));
           t.dw_off = cv.dw_off; t.db_off = cv.db_off; t.alpha_off = cv.alpha_off;
           t.co_dst = cv.co_dst; t.ci_dst = cv.ci_dst; t.co_base = ob * 32; t.ci_base = cb * 32;
-          t.tap0 = th * NT; t.ntap = NT; t.ksize = s->ksize; t.alpha = cv.alpha; t.beta = cv.beta;
-          t.bias_slab = (cb == 0 && th == 0 && cv.db_off >= 0) ? 0 : -1;  // resolved below
+          t.tap0 = 0; t.ntap = NT; t.ksize = s->ksize; t.alpha = cv.alpha; t.beta = cv.beta;
+          t.bias_slab = (cb == 0 && cv.db_off >= 0) ? 0 : -1;  // resolved below
+          const int id = (int)pb.tasks.size();
           pb.tasks.push_back(t);
+          const int ca = cv.ci_lo / 32 + cb, oa = cv.co_lo / 32 + ob;
+          Bucket* bk = nullptr;
+          for (auto& q : buckets)
+            if (q.xb == ca / xdiv && q.yb == oa / 2 && (int)q.tasks.size() < cap) { bk = &q; break; }
+          if (!bk) { buckets.push_back(Bucket{ca / xdiv, oa / 2, {}, {}, {}}); bk = &buckets.back(); }
+          bk->tasks.push_back(id); bk->ci_abs.push_back(ca); bk->co_abs.push_back(oa);
         }
-    auto task_id = [&](int ob, int cb, int th) { return task0 + (ob * cib + cb) * nth + th; };
-    auto emit = [&](int cb0, int ncb, int ob0, int nob, int ks_n) {
-      // ncb * nob * nth * ks_n wave slots, packed 4 per group
-      std::vector<WgWave> ws;
-      for (int ob = 0; ob < nob; ++ob)
-        for (int cb = 0; cb < ncb; ++cb)
-          for (int th = 0; th < nth; ++th)
-            for (int k = 0; k < ks_n; ++k) {
-              WgWave w; memset(&w, 0, sizeof(w));
-              w.active = 1; w.ci_rel = cb; w.co_rel = ob; w.ks_idx = k; w.ks_n = ks_n; w.tap0 = th * NT;
-              w.slab_base = task_id(ob0 + ob, cb0 + cb, th);  // task id for now
-              ws.push_back(w);
-            }
-      for (size_t i = 0; i < ws.size(); i += 4) {
-        WgGroup g; memset(&g, 0, sizeof(g));
-        g.x_c0 = cv.ci_lo + cb0 * 32; g.x_units = ncb; g.dy_c0 = cv.co_lo + ob0 * 32; g.dy_units = nob;
-        for (int k = 0; k < 4; ++k) {
-          if (i + k < ws.size()) g.w[k] = ws[i + k];
-          else { g.w[k].active = 0; g.w[k].ks_n = 1; g.w[k].bias_slab = -1; }
+  }
+  for (auto& bk : buckets) {
+    WgGroup g; memset(&g, 0, sizeof(g));
+    g.x_c0 = bk.xb * xdiv * 32; g.dy_c0 = bk.yb * 64;
+    g.x_units = (xdiv == 2 && s->x_channels - g.x_c0 >= 64) ? 2 : 1;
+    g.dy_units = (s->dy_channels - g.dy_c0 >= 64) ? 2 : 1;
+    const int nt = (int)bk.tasks.size();
+    const int ks_n = (cap % nt == 0) ? cap / nt : 1;
+    int k = 0;
+    for (int t = 0; t < nt; ++t)
+      for (int ky = 0; ky < s->ksize; ++ky)
+        for (int q = 0; q < ks_n; ++q) {
+          WgWave& w = g.w[k++];
+          w.active = 1; w.ci_rel = bk.ci_abs[t] - g.x_c0 / 32; w.co_rel = bk.co_abs[t] - g.dy_c0 / 32;
+          w.ks_idx = q; w.ks_n = ks_n; w.tap0 = ky * s->ksize; w.slab_base = bk.tasks[t];  // task id for now
+          w.bias_slab = ky == 0 ? 0 : -1;                                                    // resolved below
         }
-        pb.groups.push_back(g);
-      }
-      if (ncb > max_xu) max_xu = ncb;
-      if (nob > max_yu) max_yu = nob;
-    };
-    if (nth == 2) {  // 4x4 stride 2: two tap halves per block -> (1 ci x 2 co x 2 halves) per group
-      for (int cb = 0; cb < cib; ++cb) {
-        int ob = 0;
-        for (; ob + 2 <= cob; ob += 2) emit(cb, 1, ob, 2, 1);
-        if (ob < cob) emit(cb, 1, ob, 1, 2);
-      }
-    } else if (cob >= 2) {
-      int ob = 0;
-      for (; ob + 2 <= cob; ob += 2) {
-        int cb = 0;
-        for (; cb + 2 <= cib; cb += 2) emit(cb, 2, ob, 2, 1);
-        if (cb < cib) emit(cb, 1, ob, 2, 2);
-      }
-      if (ob < cob) {
-        int cb = 0;
-        for (; cb + 4 <= cib; cb += 4) emit(cb, 4, ob, 1, 1);
-        const int rem = cib - cb;
-        if (rem == 3) emit(cb, 3, ob, 1, 1);
-        else if (rem == 2) emit(cb, 2, ob, 1, 2);
-        else if (rem == 1) emit(cb, 1, ob, 1, 4);
-      }
-    } else {
-      int cb = 0;
-      for (; cb + 4 <= cib; cb += 4) emit(cb, 4, 0, 1, 1);
-      const int rem = cib - cb;
-      if (rem == 3) emit(cb, 3, 0, 1, 1);
-      else if (rem == 2) emit(cb, 2, 0, 1, 2);
-      else if (rem == 1) emit(cb, 1, 0, 1, 4);
-    }
+    for (; k < kMaxWaves; ++k) { g.w[k].active = 0; g.w[k].ks_n = 1; g.w[k].bias_slab = -1; }
+    pb.groups.push_back(g);
   }
   H.ngroups = (int)pb.groups.size();
   H.ntasks = (int)pb.tasks.size();
@@ -324,7 +363,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   // slab allocation: per task S * ks_n slabs
   std::vector<int> ksn(pb.tasks.size(), 1);
   for (auto& g : pb.groups)
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kMaxWaves; ++k)
       if (g.w[k].active) ksn[g.w[k].slab_base] = g.w[k].ks_n;
   long long slab = 0, bslab = 0;
   for (size_t t = 0; t < pb.tasks.size(); ++t) {
@@ -334,18 +373,18 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   }
   if (slab > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "wgrad: too many slabs");
   for (auto& g : pb.groups)
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kMaxWaves; ++k)
       if (g.w[k].active) {
         const WgTask& t = pb.tasks[g.w[k].slab_base];
-        g.w[k].bias_slab = t.bias_slab;
+        g.w[k].bias_slab = (g.w[k].bias_slab == 0) ? t.bias_slab : -1;   // only the ky == 0 wave sums the bias
         g.w[k].slab_base = t.slab_base;
       }
   H.nslabs_total = slab; H.nbias_slabs = bslab;
   H.bias_slab_off = slab * NT * 1024;
-  H.x_upad = pow2ceil(max_xu); H.dy_upad = pow2ceil(max_yu);
+  H.x_upad = 2; H.dy_upad = 2;
   const int UB = 32 * (s->dtype == SRGANFD_BF16 ? 2 : 4);
   const int PR = (kTH - 1) * s->stride + s->ksize, PC = 31 * s->stride + s->ksize;
-  H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
+  H.lds_bytes = PR * PC * 2 * UB + kTH * 32 * 2 * UB;
   if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
   H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
   H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;
@@ -381,7 +420,7 @@ static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
     SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
     attr_lds = H.lds_bytes;
   }
-  SRGANFD_LAUNCH(kern, dim3(H.S, H.ngroups), dim3(256), H.lds_bytes, stream, k);
+  SRGANFD_LAUNCH(kern, dim3(H.S, H.ngroups), dim3(64 * WgWaves<KS>::NW), H.lds_bytes, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
