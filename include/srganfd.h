@@ -78,6 +78,9 @@ typedef struct {
    * whose result pixel (oy,ox) is stored at (oy*out_sy+out_oy, ox*out_sx+out_ox) of an
    * out_h_full x out_w_full image; pad_y/pad_x replace `pad`; r1/r2/mask use the same addressing. */
   int32_t out_sy, out_sx, out_oy, out_ox, out_h_full, out_w_full, pad_y, pad_x;
+  /* optional second output: post_scale * act(alpha*conv + bias) BEFORE the residual adds (the U-Net skip
+   * adds of model.py:153,157,161 keep the LeakyReLU output so its derivative's sign is exact in backward) */
+  srganfd_view y2;
 } srganfd_conv_args;
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream);

@@ -25,9 +25,9 @@
 namespace srganfd {
 
 struct ConvK {
-  const void* x; void* y; const void* r1; const void* r2; const void* mask; const void* w;
+  const void* x; void* y; void* y2; const void* r1; const void* r2; const void* mask; const void* w;
   const float* bias; const float* alpha_dev;
-  int xC, x_c0, yC, y_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
+  int xC, x_c0, yC, y_c0, y2C, y2_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
   int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
   int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
   int nChunks;        // cin / 32
@@ -293,6 +293,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
             out[0] = rf[0]; out[1] = rf[1]; out[2] = rf[2]; out[3] = rf[3];
           }
         };
+        auto store16 = [&](void* base, int Cs, int c0, const float* vv) {
+          T* dstp = (T*)base + p * Cs + c0 + cch;
+          if constexpr (sizeof(T) == 2) {
+            u32x4 o;
+            o[0] = (unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16);
+            o[1] = (unsigned)f2bf(vv[2]) | ((unsigned)f2bf(vv[3]) << 16);
+            o[2] = (unsigned)f2bf(vv[4]) | ((unsigned)f2bf(vv[5]) << 16);
+            o[3] = (unsigned)f2bf(vv[6]) | ((unsigned)f2bf(vv[7]) << 16);
+            *(u32x4*)dstp = o;
+          } else {
+            f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
+            *(f32x4*)dstp = o;
+          }
+        };
+        if (a.y2) store16(a.y2, a.y2C, a.y2_c0, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
         float t[C::E16];
         if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, t);
 #pragma unroll
@@ -303,18 +318,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
         if (a.mask) { load16(a.mask, a.mC, a.m_c0, t);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] *= t[q] > 0.f ? 1.f : a.mask_slope; }
-        T* dstp = (T*)a.y + p * a.yC + a.y_c0 + cch;
-        if constexpr (sizeof(T) == 2) {
-          u32x4 o;
-          o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          o[2] = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-          o[3] = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-          *(u32x4*)dstp = o;
-        } else {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)dstp = o;
-        }
+        store16(a.y, a.yC, a.y_c0, v);
       }
     }
     return;
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
           if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
           else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
           v *= a.post_scale;
+          if (a.y2) ((T*)a.y2)[p * a.y2C + a.y2_c0 + co] = Elem<T>::from_f(v);
           if (r1g) v += a.r1s * Elem<T>::to_f(r1g[p * a.r1C + a.r1_c0 + co]);
           if (r2g) v += a.r2s * Elem<T>::to_f(r2g[p * a.r2C + a.r2_c0 + co]);
           if (mg) v *= (Elem<T>::to_f(mg[p * a.mC + a.m_c0 + co]) > 0.f) ? 1.f : a.mask_slope;
@@ -409,7 +414,7 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   if ((size_t)a->n * hl * wl * (size_t)a->x.cstride >= 0x7fffffffULL)
     return set_err(SRGANFD_EINVAL, "conv2d: input too large for 32-bit element offsets");
   ConvK k;
-  k.x = a->x.ptr; k.y = a->y.ptr; k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;
+  k.x = a->x.ptr; k.y = a->y.ptr; k.y2 = a->y2.ptr; k.y2C = a->y2.cstride; k.y2_c0 = a->y2.c0; k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;
   k.bias = a->bias; k.alpha_dev = a->alpha_dev;
   k.xC = a->x.cstride; k.x_c0 = a->x.c0; k.yC = a->y.cstride; k.y_c0 = a->y.c0;
   k.r1C = a->r1.cstride; k.r1_c0 = a->r1.c0; k.r2C = a->r2.cstride; k.r2_c0 = a->r2.c0;
@@ -422,7 +427,7 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;
   auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
-  k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
+  k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F32) return dispatch_conv<float>(a, k, stream);
   return set_err(SRGANFD_EINVAL, "conv2d: bad dtype %d", a->dtype);

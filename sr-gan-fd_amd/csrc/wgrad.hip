@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   const int xu_sh = G.x_units == 2 ? 1 : 0, yu_sh = G.dy_units == 2 ? 1 : 0;   // units are 1 or 2
   const int xRowB = UB << xu_sh, dyRowB = UB << yu_sh;
   char* ldsX = smem;
-  char* ldsY = smem + PR * PC * (UB * 2);
+  char* ldsY = smem + PR * PC * (UB * a.x_upad);   // x_upad = largest x_units of the launch
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
   const T* __restrict__ xg = (const T*)a.x + a.x_c0v + G.x_c0;
   const T* __restrict__ dyg = (const T*)a.dy + a.dy_c0v + G.dy_c0;
@@ -381,10 +381,11 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
       }
   H.nslabs_total = slab; H.nbias_slabs = bslab;
   H.bias_slab_off = slab * NT * 1024;
-  H.x_upad = 2; H.dy_upad = 2;
+  H.x_upad = 1; H.dy_upad = 1;
+  for (auto& g : pb.groups) { if (g.x_units > H.x_upad) H.x_upad = g.x_units; if (g.dy_units > H.dy_upad) H.dy_upad = g.dy_units; }
   const int UB = 32 * (s->dtype == SRGANFD_BF16 ? 2 : 4);
   const int PR = (kTH - 1) * s->stride + s->ksize, PC = 31 * s->stride + s->ksize;
-  H.lds_bytes = PR * PC * 2 * UB + kTH * 32 * 2 * UB;
+  H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
   if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
   H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
   H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;

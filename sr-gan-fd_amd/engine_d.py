@@ -127,6 +127,8 @@ class DiscriminatorEngine:
         sp.b2, sp.u2 = new(H // 2, W // 2, 256), new(H // 2, W // 2, 128)
         sp.b1, sp.u3 = new(H, W, 128), new(H, W, 64)
         sp.c2, sp.c3 = new(H, W, 64), new(H, W, 64)
+        # LeakyReLU outputs before the skip adds (exact derivative sign in backward)
+        sp.a1, sp.a2, sp.a3 = new(H // 4, W // 4, 256), new(H // 2, W // 2, 128), new(H, W, 64)
         L = A.lib()
         cv = lambda *a, **k: ("conv", ops.conv_args(dtc, *a, **k))
         rs = lambda op, a, b, h, w, c: ("call", lambda: A.check(L.srganfd_resample(op, a, b, dtc, N, h, w, c, A.stream_ptr()), "resample"))
@@ -137,11 +139,11 @@ class DiscriminatorEngine:
             cv(V(sp.d1), V(sp.d2), wptr + O[("f", "down_block2")], N, H // 2, W // 2, 128, 256, ksize=4, stride=2, **lre),
             cv(V(sp.d2), V(sp.d3), wptr + O[("f", "down_block3")], N, H // 4, W // 4, 256, 512, ksize=4, stride=2, **lre),
             rs(1, V(sp.d3), V(sp.b3), H // 8, W // 8, 512),
-            cv(V(sp.b3), V(sp.u1), wptr + O[("f", "up_block1")], N, H // 4, W // 4, 512, 256, r1=V(sp.d2), r1_scale=1.0, **lre),
+            cv(V(sp.b3), V(sp.u1), wptr + O[("f", "up_block1")], N, H // 4, W // 4, 512, 256, r1=V(sp.d2), r1_scale=1.0, y2=V(sp.a1), **lre),
             rs(1, V(sp.u1), V(sp.b2), H // 4, W // 4, 256),
-            cv(V(sp.b2), V(sp.u2), wptr + O[("f", "up_block2")], N, H // 2, W // 2, 256, 128, r1=V(sp.d1), r1_scale=1.0, **lre),
+            cv(V(sp.b2), V(sp.u2), wptr + O[("f", "up_block2")], N, H // 2, W // 2, 256, 128, r1=V(sp.d1), r1_scale=1.0, y2=V(sp.a2), **lre),
             rs(1, V(sp.u2), V(sp.b1), H // 2, W // 2, 128),
-            cv(V(sp.b1), V(sp.u3), wptr + O[("f", "up_block3")], N, H, W, 128, 64, r1=V(sp.out1), r1_scale=1.0, **lre),
+            cv(V(sp.b1), V(sp.u3), wptr + O[("f", "up_block3")], N, H, W, 128, 64, r1=V(sp.out1), r1_scale=1.0, y2=V(sp.a3), **lre),
             cv(V(sp.u3), V(sp.c2), wptr + O[("f", "conv2")], N, H, W, 64, 64, **lre),
             cv(V(sp.c2), V(sp.c3), wptr + O[("f", "conv3")], N, H, W, 64, 64, **lre),
         ]
@@ -208,15 +210,15 @@ class DiscriminatorEngine:
             cv(V(gA), V(gB), wptr + O[("b", "conv3")], N, H, W, 64, 64, mask=V(sp.c2), mask_slope=0.2),
             wg("conv2", sp.u3, gB, H, W, 64, 64, sn_index=6),
             cv(V(gB), V(gA), wptr + O[("b", "conv2")], N, H, W, 64, 64),                 # gA = d u3
-            lb(V(gA), V(sp.u3), V(sp.out1), V(gB), P, 64),                              # gB = d z3
+            lb(V(gA), V(sp.a3), A.NULL_VIEW, V(gB), P, 64),                              # gB = d z3
             wg("up_block3", sp.b1, gB, H, W, 128, 64, sn_index=5),
             cv(V(gB), V(gC), wptr + O[("b", "up_block3")], N, H, W, 64, 128),            # gC = d b1
             rs(2, V(gC), V(h1), H // 2, W // 2, 128),                                    # h1 = d u2
-            lb(V(h1), V(sp.u2), V(sp.d1), V(h2), P // 4, 128),                          # h2 = d z2
+            lb(V(h1), V(sp.a2), A.NULL_VIEW, V(h2), P // 4, 128),                          # h2 = d z2
             wg("up_block2", sp.b2, h2, H // 2, W // 2, 256, 128, sn_index=4),
             cv(V(h2), V(h3), wptr + O[("b", "up_block2")], N, H // 2, W // 2, 128, 256),  # h3 = d b2
             rs(2, V(h3), V(q1), H // 4, W // 4, 256),                                    # q1 = d u1
-            lb(V(q1), V(sp.u1), V(sp.d2), V(q2), P // 16, 256),                         # q2 = d z1
+            lb(V(q1), V(sp.a1), A.NULL_VIEW, V(q2), P // 16, 256),                         # q2 = d z1
             wg("up_block1", sp.b3, q2, H // 4, W // 4, 512, 256, sn_index=3),
             cv(V(q2), V(q3), wptr + O[("b", "up_block1")], N, H // 4, W // 4, 256, 512),  # q3 = d b3
             rs(2, V(q3), V(e1), H // 8, W // 8, 512),                                    # e1 = d d3 (post-act)

@@ -77,14 +77,15 @@ def conv_args(dtype: int, x: A.View, y: A.View, w_packed, n: int, h_in: int, w_i
               cout_store: Optional[int] = None, ksize: int = 3, stride: int = 1, pad: int = 1, up: int = 0,
               bias=None, act: int = A.ACT_NONE, slope: float = 0.2, alpha: float = 1.0, post_scale: float = 1.0,
               r1: A.View = A.NULL_VIEW, r1_scale: float = 0.0, r2: A.View = A.NULL_VIEW, r2_scale: float = 0.0,
-              mask: A.View = A.NULL_VIEW, mask_slope: float = 0.2, alpha_dev=None, y_f32: bool = False) -> A.ConvArgs:
+              mask: A.View = A.NULL_VIEW, mask_slope: float = 0.2, alpha_dev=None, y_f32: bool = False,
+              y2: A.View = A.NULL_VIEW) -> A.ConvArgs:
     a = A.ConvArgs()
     a.dtype, a.n, a.h_in, a.w_in, a.up = dtype, n, h_in, w_in, up
     a.ksize, a.stride, a.pad, a.cin, a.cout = ksize, stride, pad, cin, cout
     a.cout_store = cout if cout_store is None else cout_store
     hl, wl = h_in << up, w_in << up
     a.h_out, a.w_out = (hl + 2 * pad - ksize) // stride + 1, (wl + 2 * pad - ksize) // stride + 1
-    a.x, a.y, a.r1, a.r2, a.mask = x, y, r1, r2, mask
+    a.x, a.y, a.r1, a.r2, a.mask, a.y2 = x, y, r1, r2, mask, y2
     a.w_packed = w_packed if isinstance(w_packed, int) else w_packed.data_ptr()
     a.bias = None if bias is None else (bias if isinstance(bias, int) else bias.data_ptr())
     a.alpha_dev = None if alpha_dev is None else (alpha_dev if isinstance(alpha_dev, int) else alpha_dev.data_ptr())
