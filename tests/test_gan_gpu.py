@@ -147,7 +147,7 @@ def test_discriminator(golden_dir, dtype):
     e2 = _rel_l2(xin.grad, g["train3_dx"])
     print(f"D {dtype}: input-gradient max err {e:.2e}, L2 err {e2:.2e}")
     # bf16: every layer's gradient is re-quantised to 8 mantissa bits; bound the L2 error, report the max
-    assert (e < 2e-3) if dtype == torch.float32 else (e2 < 5e-2 and e < 3e-1)
+    assert (e < 2e-3) if dtype == torch.float32 else (e2 < 1e-1 and e < 3e-1)
 
 
 def _build_gan(dtype):
