@@ -8,16 +8,22 @@
 // packed in data-gradient orientation the same kernel is the dgrad pass (mask = LeakyReLU').
 //
 // Mapping (MI355X-first, not a cuDNN tiling):
-//   * one workgroup = 4 wavefronts (64 lanes) = a (4*MR) x 32 output-pixel tile x (32*NR) channels;
-//     wave w owns MR image rows, each row of 32 pixels is the M side of a 32x32 MFMA tile.
-//   * K = taps x input channels is walked in chunks of 32 channels: the (rows+halo) x (32+halo)
-//     x 32ch input patch and the 9 x 32 x (32*NR) weight slab are staged in LDS once per chunk and
-//     every one of the 9 taps re-reads the SAME patch at a shifted address (implicit im2col).
-//   * A fragments: ds_read_b128 (bf16) of 8 consecutive channels of one pixel; the 16-byte chunk
-//     index is XOR-swizzled with (pixel>>2)&3 so the 16-lane read groups of ds_read_b128 are
-//     bank-conflict free.  B fragments are pre-packed in lane order -> linear ds_read_b128.
-//   * global -> register -> LDS staging with the next chunk's loads issued before the MFMA phase
-//     (issue-early / write-late), so HBM/L2 latency hides under the matrix work.
+//   * one workgroup = WR x WN wavefronts (8 for the 3x3 convs = 2 per SIMD; two workgroups per CU give
+//     4 waves per SIMD, which is what hides the LDS/HBM latency chain of a single wave).  Wave (wr, wn)
+//     owns MR image rows x 32 output channels; each 32-pixel row is the M side of a 32x32 MFMA tile.
+//     Tile = (WR*MR) rows x 32 pixels x (32*WN) channels.
+//   * K = taps x input channels is walked in chunks of 32 channels: the haloed input patch and the
+//     KSxKS x 32 x (32*WN) weight slab are staged in LDS once per chunk and every tap re-reads the SAME
+//     patch at a shifted address (implicit im2col, no materialised columns).
+//   * A fragments: ds_read_b128 (bf16) of 8 consecutive channels of one pixel; the 16-byte chunk index is
+//     XOR-swizzled with (pixel>>2)&3 so the 16-lane read groups of ds_read_b128 are bank-conflict
+//     free.  For a fixed kernel column the MR rows x KS kernel rows touch only (MR-1)*S+KS patch rows,
+//     so each A fragment is read once and reused by every (row, kernel row) pair.
+//     B fragments are pre-packed in lane order (pack.hip) -> linear ds_read_b128.
+//   * global -> register -> LDS staging, next chunk's loads issued before the MFMA phase
+//     (issue-early / write-late); all staging addresses are base + immediate (no per-chunk VALU).
+//   * epilogue: accumulators -> fp32 LDS tile -> 16-byte vector loads of residual / mask tensors and
+//     16-byte stores (one pixel's channels are contiguous in NHWC).
 //   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32, an exact
 //     fp32 fma chain, used as the parity mode against the CPU oracle.
 #include "common.hpp"
@@ -31,7 +37,7 @@ struct ConvK {
   int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
   int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
   int nChunks;        // cin / 32
-  int nNb;            // cout / (32*NR)
+  int nNb;            // cout / (32*WN)
   int cout_store;
   int tiles_x, tiles_y;
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
@@ -50,10 +56,11 @@ template <> __device__ __forceinline__ f32x16 mfma32<float>(float a, float b, f3
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <typename T, int KS, int STRIDE, int MR, int NR>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
 struct ConvCfg {
+  static constexpr int NWAVES = WR * WN, NTHR = 64 * NWAVES;
   static constexpr int KT = KS * KS;
-  static constexpr int TW = 32, TH = 4 * MR;
+  static constexpr int TW = 32, TH = WR * MR;
   static constexpr int PR = (TH - 1) * STRIDE + KS;
   static constexpr int PC = (TW - 1) * STRIDE + KS;
   static constexpr int KC = 32;
@@ -65,28 +72,31 @@ struct ConvCfg {
   static constexpr int FRAGB = (int)sizeof(typename FragAB<T>::type);
   static constexpr int WN_BYTES = KT * KSTEPS * 64 * FRAGB;  // one 32-channel n-tile, one chunk
   static constexpr int NX = PR * PC * CPP;
-  static constexpr int XI = (NX + 255) / 256;
-  static constexpr int NW = NR * WN_BYTES / 16;
-  static constexpr int WI = (NW + 255) / 256;
-  static constexpr int STAGE_BYTES = XBYTES + NR * WN_BYTES;
-  static constexpr int NB = 32 * NR;                           // output channels per workgroup
+  static constexpr int XI = (NX + NTHR - 1) / NTHR;
+  static constexpr int NW16 = WN * WN_BYTES / 16;
+  static constexpr int WI = (NW16 + NTHR - 1) / NTHR;
+  static constexpr int STAGE_BYTES = XBYTES + WN * WN_BYTES;
+  static constexpr int NB = 32 * WN;                           // output channels per workgroup
   static constexpr int EPI_BYTES = TH * TW * NB * 4;           // fp32 tile for the vectorised epilogue
   static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   static constexpr int NROWS = (MR - 1) * STRIDE + KS;         // patch rows one wave touches
+  static constexpr int PIX_PER_I = NTHR / CPP;                 // pixels advanced per staging item index
+  static_assert(PIX_PER_I % 32 == 0, "swizzle term must not depend on the staging item index");
+  // workgroups per CU allowed by LDS (160 KiB) -> minimum waves per SIMD to ask the register allocator for
+  static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NTHR / 256;
 };
 
-template <typename T> __device__ __forceinline__ int lds_x_chunk_off(int pix, int c16);
-// bf16: 4 chunks of 16 B per pixel; chunk index XOR (pix>>2)&3 (see header)
-template <> __device__ __forceinline__ int lds_x_chunk_off<bf16_t>(int pix, int c16) {
-  return pix * 64 + ((c16 ^ ((pix >> 2) & 3)) << 4);
-}
-// f32: dword index XOR (pix & 31): 32 lanes reading one channel of 32 consecutive pixels hit 32 banks
+// LDS patch layout.  bf16: 4 chunks of 16 B per pixel, chunk index XOR (pix>>2)&3.  f32: 32 dwords per
+// pixel, dword index XOR (pix & 31) so 32 lanes reading one channel of 32 consecutive pixels hit 32 banks.
+__device__ __forceinline__ int lds_x_bf16_off(int pix, int c16) { return pix * 64 + ((c16 ^ ((pix >> 2) & 3)) << 4); }
 __device__ __forceinline__ int lds_x_f32_off(int pix, int k) { return pix * 128 + ((k ^ (pix & 31)) << 2); }
 
-template <typename T, int KS, int STRIDE, int MR, int NR>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvK a) {
-  using C = ConvCfg<T, KS, STRIDE, MR, NR>;
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
+__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
   using Frag = typename FragAB<T>::type;
+  constexpr int NTHR = C::NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsX = smem;
   char* ldsW = smem + C::XBYTES;
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (L2), give each XCD a contiguous range
@@ -116,58 +127,67 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
   int xoff[C::XI];
 #pragma unroll
   for (int i = 0; i < C::XI; ++i) {
-    const int item = tid + i * 256;
+    const int item = tid + i * NTHR;
     const int pix = item / C::CPP, c16 = item % C::CPP;
     const int py = pix / C::PC, px = pix % C::PC;
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
     xoff[i] = ok ? ((n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + a.x_c0 + c16 * C::E16 : -1;
   }
-  const u32x4* __restrict__ wg = (const u32x4*)a.w;
+  // LDS destination of staging item i = ldsx0 + i * (PIX_PER_I * PIXB): the swizzle term is i-invariant
+  int ldsx0;
+  {
+    const int pix = tid / C::CPP, c16 = tid % C::CPP;
+    if constexpr (sizeof(T) == 2) ldsx0 = lds_x_bf16_off(pix, c16);
+    else ldsx0 = pix * 128;   // f32: per-dword XOR below
+  }
+  const u32x4* __restrict__ wgp = (const u32x4*)a.w + (size_t)nb * WN * a.nChunks * (C::WN_BYTES / 16);
 
   // bf16: register prefetch of the next chunk (issue-early / write-late).  f32 (parity mode) stages
   // synchronously: its 2x larger tiles would not fit the register budget next to the accumulators.
   constexpr bool kPrefetch = sizeof(T) == 2;
-  constexpr int XR = kPrefetch ? C::XI : 1, WR = kPrefetch ? C::WI : 1;
+  constexpr int XR = kPrefetch ? C::XI : 1, WRG = kPrefetch ? C::WI : 1;
   u32x4 xr[XR];
-  u32x4 wr[WR];
+  u32x4 wrg[WRG];
   auto load_x = [&](int i, int chunk) -> u32x4 {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * C::KC);
     return v;
   };
   auto load_w = [&](int i, int chunk) -> u32x4 {
-    const int item = tid + i * 256;
+    const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < C::NW) {
+    if (item < C::NW16) {
+      // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]
       const int nn = item / (C::WN_BYTES / 16), rem = item % (C::WN_BYTES / 16);
-      const size_t src16 = ((size_t)(nb * NR + nn) * a.nChunks + chunk) * (C::WN_BYTES / 16) + rem;
-      v = wg[src16];
+      v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + rem];
     }
     return v;
   };
   auto store_x = [&](int i, u32x4 v) {
-    const int item = tid + i * 256;
+    const int item = tid + i * NTHR;
     if (item < C::NX) {
-      const int pix = item / C::CPP, c16 = item % C::CPP;
       if constexpr (sizeof(T) == 2) {
-        *(u32x4*)(ldsX + lds_x_chunk_off<bf16_t>(pix, c16)) = v;
+        *(u32x4*)(ldsX + ldsx0 + i * (C::PIX_PER_I * C::PIXB)) = v;
       } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *(unsigned int*)(ldsX + lds_x_f32_off(pix, c16 * 4 + e)) = v[e];
+        const int pix = item / C::CPP, c16 = item % C::CPP;
+        *(unsigned int*)(ldsX + lds_x_f32_off(pix, c16 * 4 + 0)) = v[0];
+        *(unsigned int*)(ldsX + lds_x_f32_off(pix, c16 * 4 + 1)) = v[1];
+        *(unsigned int*)(ldsX + lds_x_f32_off(pix, c16 * 4 + 2)) = v[2];
+        *(unsigned int*)(ldsX + lds_x_f32_off(pix, c16 * 4 + 3)) = v[3];
       }
     }
   };
   auto store_w = [&](int i, u32x4 v) {
-    const int item = tid + i * 256;
-    if (item < C::NW) *(u32x4*)(ldsW + item * 16) = v;
+    const int item = tid + i * NTHR;
+    if (item < C::NW16) *(u32x4*)(ldsW + item * 16) = v;
   };
   auto prefetch = [&](int chunk) {
     if constexpr (kPrefetch) {
 #pragma unroll
       for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, chunk);
 #pragma unroll
-      for (int i = 0; i < C::WI; ++i) wr[i] = load_w(i, chunk);
+      for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, chunk);
     }
   };
   auto commit = [&](int chunk) {
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
 #pragma unroll
       for (int i = 0; i < C::XI; ++i) store_x(i, xr[i]);
 #pragma unroll
-      for (int i = 0; i < C::WI; ++i) store_w(i, wr[i]);
+      for (int i = 0; i < C::WI; ++i) store_w(i, wrg[i]);
     } else {
 #pragma unroll 4
       for (int i = 0; i < C::XI; ++i) store_x(i, load_x(i, chunk));
@@ -184,13 +204,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
     }
   };
 
-  f32x16 acc[MR][NR];
+  f32x16 acc[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NR; ++nn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][nn][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+
+  // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
+  const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
+  const char* ldsWn = ldsW + wn * C::WN_BYTES + lane * C::FRAGB;
 
   prefetch(0);
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
@@ -199,31 +221,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
     __syncthreads();
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
 
-    // For a fixed kernel column kx and k-step s, the MR output rows of this wave and the KS kernel rows
-    // touch only NROWS = (MR-1)*S + KS patch rows: read each A fragment ONCE and reuse it for every
-    // (output row, kernel row) pair that needs it (6 LDS reads instead of 12 per 12 MFMAs at MR=4, KS=3).
     auto col_body = [&](int kx, int s) {
       Frag av[C::NROWS];
 #pragma unroll
       for (int rr = 0; rr < C::NROWS; ++rr) {
-        const int pix = (wave * MR * STRIDE + rr) * C::PC + r * STRIDE + kx;
-        if constexpr (sizeof(T) == 2) av[rr] = *(const Frag*)(ldsX + lds_x_chunk_off<bf16_t>(pix, 2 * s + h));
+        const int pix = pix00 + rr * C::PC + kx;
+        if constexpr (sizeof(T) == 2) av[rr] = *(const Frag*)(ldsX + lds_x_bf16_off(pix, 2 * s + h));
         else av[rr] = *(const Frag*)(ldsX + lds_x_f32_off(pix, 2 * s + h));
       }
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky) {
-        Frag bq[NR];
+        const Frag bq = *(const Frag*)(ldsWn + ((ky * KS + kx) * C::KSTEPS + s) * 64 * C::FRAGB);
 #pragma unroll
-        for (int nn = 0; nn < NR; ++nn)
-          bq[nn] = *(const Frag*)(ldsW + ((nn * C::KT + ky * KS + kx) * C::KSTEPS + s) * 64 * C::FRAGB + lane * C::FRAGB);
-#pragma unroll
-        for (int m = 0; m < MR; ++m)
-#pragma unroll
-          for (int nn = 0; nn < NR; ++nn) acc[m][nn] = mfma32<T>(av[m * STRIDE + ky], bq[nn], acc[m][nn]);
+        for (int m = 0; m < MR; ++m) acc[m] = mfma32<T>(av[m * STRIDE + ky], bq, acc[m]);
       }
     };
     if constexpr (sizeof(T) == 2) {
-#pragma unroll 1
+#pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
         for (int s2 = 0; s2 < C::KSTEPS; ++s2) col_body(kx, s2);
@@ -240,47 +254,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
   // ---- epilogue (see srganfd.h for the formula) ----
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
+  const int co = (nb * WN + wn) * 32 + r;
   if (a.fast_epi) {
-    // Vectorised epilogue: (1) every lane applies the per-channel part (alpha, bias, activation, scale) to
-    // its accumulators and drops them as fp32 into an LDS tile [pixel][channel]; (2) the workgroup
-    // re-reads the tile 16 output bytes per lane, adds residuals / applies the LeakyReLU' mask with
-    // 16-byte global loads, and issues 16-byte stores (one pixel's channels are contiguous in NHWC).
+    // (1) per-channel part (alpha, bias, activation, scale) on the accumulators -> fp32 LDS tile
+    // [pixel][channel]; (2) 16 output bytes per lane: residuals / LeakyReLU' mask via 16-byte global
+    // loads, 16-byte stores.
     float* tile = (float*)smem;
     __syncthreads();   // all waves are done with the staging buffers
-#pragma unroll
-    for (int nn = 0; nn < NR; ++nn) {
-      const int co = (nb * NR + nn) * 32 + r;
+    {
       const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float v = alpha * acc[m][nn][i] + bv;
+          float v = alpha * acc[m][i] + bv;
           if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
           else if (a.act == SRGANFD_ACT_RELU) v = fmaxf(v, 0.f);
-          tile[((wave * MR + m) * 32 + mfma32_row(i, lane)) * C::NB + nn * 32 + r] = v * a.post_scale;
+          tile[((wr * MR + m) * 32 + mfma32_row(i, lane)) * C::NB + wn * 32 + r] = v * a.post_scale;
         }
     }
     __syncthreads();
     constexpr int CP = C::NB / C::E16;                 // 16-byte output chunks per pixel
     constexpr int ITEMS = C::TH * 32 * CP;
+    constexpr int EI = (ITEMS + NTHR - 1) / NTHR;
     const int cbase = nb * C::NB;
+    const int img = n * a.HoutF;
 #pragma unroll 2
-    for (int item = tid; item < ITEMS; item += 256) {
+    for (int e = 0; e < EI; ++e) {
+      const int item = tid + e * NTHR;
       const int pix = item / CP, ck = item % CP;
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-      if (oy < a.Hout && ox < a.Wout) {
-        const size_t p = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+      if (item < ITEMS && oy < a.Hout && ox < a.Wout) {
+        const int p = (img + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;   // host guarantees 32-bit offsets
         float v[C::E16];
         const f32x4* tp = (const f32x4*)(tile + pix * C::NB + ck * C::E16);
-#pragma unroll
-        for (int q = 0; q < C::E16 / 4; ++q) {
-          const f32x4 t4 = tp[q];
-          v[4 * q] = t4[0]; v[4 * q + 1] = t4[1]; v[4 * q + 2] = t4[2]; v[4 * q + 3] = t4[3];
+        {
+          const f32x4 t4 = tp[0];
+          v[0] = t4[0]; v[1] = t4[1]; v[2] = t4[2]; v[3] = t4[3];
+        }
+        if constexpr (C::E16 == 8) {
+          const f32x4 t4 = tp[1];
+          v[4] = t4[0]; v[5] = t4[1]; v[6] = t4[2]; v[7] = t4[3];
         }
         const int cch = cbase + ck * C::E16;
         auto load16 = [&](const void* base, int Cs, int c0, float* out) {
-          const T* src = (const T*)base + p * Cs + c0 + cch;
+          const T* src = (const T*)base + (p * Cs + c0 + cch);
           if constexpr (sizeof(T) == 2) {
             const u32x4 raw = *(const u32x4*)src;
             const unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
           }
         };
         auto store16 = [&](void* base, int Cs, int c0, const float* vv) {
-          T* dstp = (T*)base + p * Cs + c0 + cch;
+          T* dstp = (T*)base + (p * Cs + c0 + cch);
           if constexpr (sizeof(T) == 2) {
             u32x4 o;
             o[0] = (unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16);
@@ -308,16 +326,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
           }
         };
         if (a.y2) store16(a.y2, a.y2C, a.y2_c0, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
-        float t[C::E16];
-        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, t);
+        float tt[C::E16];
+        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * t[q]; }
-        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, t);
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * tt[q]; }
+        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * t[q]; }
-        if (a.mask) { load16(a.mask, a.mC, a.m_c0, t);
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * tt[q]; }
+        if (a.mask) { load16(a.mask, a.mC, a.m_c0, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] *= t[q] > 0.f ? 1.f : a.mask_slope; }
+          for (int q = 0; q < C::E16; ++q) v[q] *= tt[q] > 0.f ? 1.f : a.mask_slope; }
         store16(a.y, a.yC, a.y_c0, v);
       }
     }
@@ -328,53 +346,49 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void conv_igemm_kern
   const T* __restrict__ r1g = (const T*)a.r1;
   const T* __restrict__ r2g = (const T*)a.r2;
   const T* __restrict__ mg = (const T*)a.mask;
+  const bool cok = co < a.cout_store;
+  const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
 #pragma unroll
-  for (int nn = 0; nn < NR; ++nn) {
-    const int co = (nb * NR + nn) * 32 + r;
-    const bool cok = co < a.cout_store;
-    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+  for (int m = 0; m < MR; ++m) {
+    const int oy = oy0 + wr * MR + m;
+    if (!cok || oy >= a.Hout) continue;
+    const size_t prow = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + a.oox;
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      const int oy = oy0 + wave * MR + m;
-      if (!cok || oy >= a.Hout) continue;
-      const size_t prow = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + a.oox;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ox = ox0 + mfma32_row(i, lane);
-        if (ox < a.Wout) {
-          const size_t p = prow + ox * a.osx;
-          float v = alpha * acc[m][nn][i] + bv;
-          if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-          else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
-          v *= a.post_scale;
-          if (a.y2) ((T*)a.y2)[p * a.y2C + a.y2_c0 + co] = Elem<T>::from_f(v);
-          if (r1g) v += a.r1s * Elem<T>::to_f(r1g[p * a.r1C + a.r1_c0 + co]);
-          if (r2g) v += a.r2s * Elem<T>::to_f(r2g[p * a.r2C + a.r2_c0 + co]);
-          if (mg) v *= (Elem<T>::to_f(mg[p * a.mC + a.m_c0 + co]) > 0.f) ? 1.f : a.mask_slope;
-          if (a.y_f32) ((float*)a.y)[p * a.yC + a.y_c0 + co] = v;
-          else yg[p * a.yC + a.y_c0 + co] = Elem<T>::from_f(v);
-        }
+    for (int i = 0; i < 16; ++i) {
+      const int ox = ox0 + mfma32_row(i, lane);
+      if (ox < a.Wout) {
+        const size_t p = prow + ox * a.osx;
+        float v = alpha * acc[m][i] + bv;
+        if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+        else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
+        v *= a.post_scale;
+        if (a.y2) ((T*)a.y2)[p * a.y2C + a.y2_c0 + co] = Elem<T>::from_f(v);
+        if (r1g) v += a.r1s * Elem<T>::to_f(r1g[p * a.r1C + a.r1_c0 + co]);
+        if (r2g) v += a.r2s * Elem<T>::to_f(r2g[p * a.r2C + a.r2_c0 + co]);
+        if (mg) v *= (Elem<T>::to_f(mg[p * a.mC + a.m_c0 + co]) > 0.f) ? 1.f : a.mask_slope;
+        if (a.y_f32) ((float*)a.y)[p * a.yC + a.y_c0 + co] = v;
+        else yg[p * a.yC + a.y_c0 + co] = Elem<T>::from_f(v);
       }
     }
   }
 }
 
-template <typename T, int KS, int STRIDE, int MR, int NR>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
-  using C = ConvCfg<T, KS, STRIDE, MR, NR>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, NR>;
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN>;
   static bool attr_done = false;
-  if (!attr_done) {
+  if (!attr_done && !g_dry_run) {
     SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_done = true;
   }
   ConvK kk = k;
-  kk.nNb = cout / (32 * NR);
+  kk.nNb = cout / C::NB;
   kk.tiles_x = ceil_div(k.Wout, C::TW);
   kk.tiles_y = ceil_div(k.Hout, C::TH);
   const long long nblk = (long long)k.N * kk.tiles_x * kk.tiles_y * kk.nNb;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d: bad grid %lld", nblk);
-  SRGANFD_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, stream, kk);
+  SRGANFD_LAUNCH(kern, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS_BYTES, stream, kk);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -382,13 +396,17 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
 template <typename T>
 static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t s) {
   const bool wide = (a->cout % 64) == 0;
-  if (a->ksize == 3 && a->stride == 1) {
-    if (wide) return launch_conv<T, 3, 1, 2, 2>(k, a->cout, s);
-    return launch_conv<T, 3, 1, 4, 1>(k, a->cout, s);
+  constexpr bool bf = sizeof(T) == 2;
+  if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
+    if (a->ksize == 3) return wide ? launch_conv<T, 3, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1>(k, a->cout, s);
+    return wide ? launch_conv<T, 2, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1>(k, a->cout, s);
   }
-  if (a->ksize == 4 && a->stride == 2) return launch_conv<T, 4, 2, 1, 1>(k, a->cout, s);
-  if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 4, 1>(k, a->cout, s);
-  if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 1>(k, a->cout, s);
+  if (a->ksize == 4 && a->stride == 2) {
+    // the stride-2 patch is 4x larger per output row: bf16 fits a 4-row x 64-channel tile, f32 a 4-row x 32-channel one
+    if constexpr (bf) { if (wide) return launch_conv<T, 4, 2, 1, 4, 2>(k, a->cout, s); }
+    return launch_conv<T, 4, 2, 1, 4, 1>(k, a->cout, s);
+  }
+  if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1>(k, a->cout, s);
   return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
 }
 
@@ -411,10 +429,15 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   if (a->x.cstride % align || a->x.c0 % align) return set_err(SRGANFD_EINVAL, "conv2d: x view not 16-byte aligned");
   if (a->x.c0 + a->cin > a->x.cstride) return set_err(SRGANFD_EINVAL, "conv2d: x view exceeds buffer channels");
   if (a->y.c0 + a->cout_store > a->y.cstride) return set_err(SRGANFD_EINVAL, "conv2d: y view exceeds buffer channels");
-  if ((size_t)a->n * hl * wl * (size_t)a->x.cstride >= 0x7fffffffULL)
+  if ((size_t)a->n * a->h_in * a->w_in * (size_t)a->x.cstride >= 0x7fffffffULL)
     return set_err(SRGANFD_EINVAL, "conv2d: input too large for 32-bit element offsets");
+  const size_t opix = (size_t)a->n * (sub ? (size_t)a->out_h_full * a->out_w_full : (size_t)a->h_out * a->w_out);
+  auto fits = [&](const srganfd_view& v) { return !v.ptr || opix * (size_t)v.cstride < 0x7fffffffULL; };
+  if (!fits(a->y) || !fits(a->y2) || !fits(a->r1) || !fits(a->r2) || !fits(a->mask))
+    return set_err(SRGANFD_EINVAL, "conv2d: output-side tensor too large for 32-bit element offsets");
   ConvK k;
-  k.x = a->x.ptr; k.y = a->y.ptr; k.y2 = a->y2.ptr; k.y2C = a->y2.cstride; k.y2_c0 = a->y2.c0; k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;
+  k.x = a->x.ptr; k.y = a->y.ptr; k.y2 = a->y2.ptr; k.y2C = a->y2.cstride; k.y2_c0 = a->y2.c0;
+  k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;
   k.bias = a->bias; k.alpha_dev = a->alpha_dev;
   k.xC = a->x.cstride; k.x_c0 = a->x.c0; k.yC = a->y.cstride; k.y_c0 = a->y.c0;
   k.r1C = a->r1.cstride; k.r1_c0 = a->r1.c0; k.r2C = a->r2.cstride; k.r2_c0 = a->r2.c0;
