@@ -167,6 +167,30 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     }
   };
 
+  // ---- lane-constant LDS address tables (keeps the MFMA loop almost free of address VALU work) ----
+  // ds_read_b64_tr_b16 lane roles inside a 16-lane group: lane 4q+p supplies row q (pixel), columns
+  // 4p..4p+3 (channels); lane i receives channel i of the 4 pixels.  This lane's first block row is pixel
+  // L = 8*(lane>>5) + q of the 16-pixel k-step, its channels start at byte chb inside the 32-channel unit.
+  // The 64-byte-unit swizzle ((pixel>>1)&1) only depends on (row start mod 4, dx, L): row starts are
+  // multiples of PC (= 2 mod 4 for the 3x3/4x4 patches), so two tables (row parity P) cover every case and
+  // the per-step address is table + wave-uniform row offset (+ compile-time offsets for the second half).
+  const int g16 = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
+  const int Lpix = 8 * (g16 >> 1) + lq;
+  const int chb = (16 * (g16 & 1) + 4 * lp) * 2;
+  int tabX[2][KS];
+  int tabY = 0;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const int x = 2 * P + dx + Lpix * STRIDE;   // pixel index mod 4 is what the swizzle needs
+        tabX[P][dx] = (Lpix * STRIDE + dx) * xRowB + ((W.ci_rel ^ swz(xu_sh, x)) * UB) + chb;
+      }
+    tabY = Lpix * dyRowB + ((W.co_rel ^ swz(yu_sh, Lpix)) * UB) + chb;
+  }
+  const int ky = W.tap0 / KS;   // this wave's kernel row
+
   int tile = blockIdx.x;
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += a.S) {
@@ -178,36 +202,34 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
         if constexpr (sizeof(T) == 2) {
-          // lane roles of ds_read_b64_tr_b16 inside its 16-lane group: lane 4q+p supplies row q
-          // (pixel), columns 4p..4p+3 (channels); lane i receives channel i of the 4 pixels.
-          const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-          const int chb = (16 * (g & 1) + 4 * pp) * 2;  // byte offset of the 4 channels inside the unit
-#pragma unroll 1
+          const int prow = ro * STRIDE + ky;                       // patch row
+          const int P = ((PC & 3) == 2) ? (prow & 1) : 0;          // (prow*PC) mod 4 == 2*P
+          const int xrow_off = prow * PC * xRowB;                  // wave-uniform
+          const int yrow_off = ro * 32 * dyRowB;
+          int ax[KS];
+#pragma unroll
+          for (int dx = 0; dx < KS; ++dx) ax[dx] = (P ? tabX[1][dx] : tabX[0][dx]) + xrow_off;
+          const int ay = tabY + yrow_off;
+#pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const int kc0 = 16 * hh + 8 * (g >> 1) + q;  // output column of this lane's first block row
-            bf16x8 bfrag;
-            {
-              const int p0 = ro * 32 + kc0, p1 = p0 + 4;
-              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p0 * dyRowB + ((W.co_rel ^ swz(yu_sh, p0)) * UB) + chb));
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsY + p1 * dyRowB + ((W.co_rel ^ swz(yu_sh, p1)) * UB) + chb));
-              u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
-                          (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
-              bfrag = __builtin_bit_cast(bf16x8, pk);
-              if (W.bias_slab >= 0) {
-                bsum += bf2f((unsigned short)lo[0]) + bf2f((unsigned short)lo[1]) + bf2f((unsigned short)lo[2]) + bf2f((unsigned short)lo[3]) +
-                        bf2f((unsigned short)hi[0]) + bf2f((unsigned short)hi[1]) + bf2f((unsigned short)hi[2]) + bf2f((unsigned short)hi[3]);
-              }
+            const char* yb = ldsY + ay + hh * 16 * dyRowB;
+            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb));
+            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 4 * dyRowB));
+            const u16x8 bpk = {(unsigned short)blo[0], (unsigned short)blo[1], (unsigned short)blo[2], (unsigned short)blo[3],
+                               (unsigned short)bhi[0], (unsigned short)bhi[1], (unsigned short)bhi[2], (unsigned short)bhi[3]};
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bpk);
+            if (W.bias_slab >= 0) {
+              bsum += bf2f((unsigned short)blo[0]) + bf2f((unsigned short)blo[1]) + bf2f((unsigned short)blo[2]) + bf2f((unsigned short)blo[3]) +
+                      bf2f((unsigned short)bhi[0]) + bf2f((unsigned short)bhi[1]) + bf2f((unsigned short)bhi[2]) + bf2f((unsigned short)bhi[3]);
             }
 #pragma unroll
-            for (int tl = 0; tl < NT; ++tl) {
-              const int tap = W.tap0 + tl;
-              const int dy = tap / KS, dx = tap - dy * KS;
-              const int p0 = (ro * STRIDE + dy) * PC + kc0 * STRIDE + dx, p1 = p0 + 4 * STRIDE;
-              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p0 * xRowB + ((W.ci_rel ^ swz(xu_sh, p0)) * UB) + chb));
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsX + p1 * xRowB + ((W.ci_rel ^ swz(xu_sh, p1)) * UB) + chb));
-              u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
-                          (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
-              acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), bfrag, acc[tl], 0, 0, 0);
+            for (int dx = 0; dx < KS; ++dx) {
+              const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
+              const u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+                                (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+              acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), bfrag, acc[dx], 0, 0, 0);
             }
           }
         } else {
@@ -217,12 +239,10 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
             const float bv = *(const float*)(ldsY + (ro * 32 + oc) * dyRowB + (W.co_rel * 32 + r) * 4);
             if (W.bias_slab >= 0) bsum += bv;
 #pragma unroll
-            for (int tl = 0; tl < NT; ++tl) {
-              const int tap = W.tap0 + tl;
-              const int dy = tap / KS, dx = tap - dy * KS;
-              const int p = (ro * STRIDE + dy) * PC + oc * STRIDE + dx;
+            for (int dx = 0; dx < KS; ++dx) {
+              const int p = (ro * STRIDE + ky) * PC + oc * STRIDE + dx;
               const float av = *(const float*)(ldsX + p * xRowB + (W.ci_rel * 32 + r) * 4);
-              acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tl], 0, 0, 0);
+              acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[dx], 0, 0, 0);
             }
           }
         }

@@ -36,17 +36,16 @@ def disable() -> None:
 
 
 def conv_label(a) -> str:
+    """kernel template the launch dispatches to (conv_igemm.hip: dispatch_conv)"""
     dt = "bf16" if a.dtype == 0 else "f32"
     wide = a.cout % 64 == 0
-    if a.ksize == 3:
-        mr, nr = (2, 2) if wide else (4, 1)
+    if a.ksize in (3, 2):
+        mr, wr, wn = (2, 4, 2) if wide else (2, 8, 1)
     elif a.ksize == 4:
-        mr, nr = 1, 1
-    elif a.ksize == 2:
-        mr, nr = (2, 2) if wide else (4, 1)
+        mr, wr, wn = (1, 4, 2) if (wide and a.dtype == 0) else (1, 4, 1)
     else:
-        mr, nr = 2, 1
-    return f"conv_igemm_kernel<{dt},KS={a.ksize},S={a.stride},MR={mr},NR={nr}>"
+        mr, wr, wn = 2, 4, 1
+    return f"conv_igemm_kernel<{dt},KS={a.ksize},S={a.stride},MR={mr},WR={wr},WN={wn}>"
 
 
 def conv_flops(a) -> float:
