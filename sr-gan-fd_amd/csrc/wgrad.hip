@@ -42,7 +42,7 @@ struct WgK {
   const void* x; const void* dy; float* slabs; float* bslabs;
   const WgGroup* groups;
   int xC, x_c0v, dyC, dy_c0v;
-  int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y;
+  int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y, ngroups;
 };
 
 
@@ -69,7 +69,16 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   constexpr int YI = (TH * 32 * 2 * CPU + NTHR - 1) / NTHR;
   constexpr bool kPrefetch = sizeof(T) == 2;   // bf16: next tile's loads are issued before the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const WgGroup& G = a.groups[blockIdx.y];
+  // 1-D grid.  Blocks b and b+8 share an XCD (private L2): remap so that each XCD owns a contiguous range of
+  // work ids, with the channel group as the FAST index -- the workgroups that stream the same pixel tiles
+  // (different channel groups of one split) then run together on one XCD and re-read x / dy from its L2.
+  int wgid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = wgid & 7, q = nwg >> 3, rr = nwg & 7;
+    wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (wgid >> 3);
+  }
+  const int grp = wgid % a.ngroups, split = wgid / a.ngroups;
+  const WgGroup& G = a.groups[grp];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WgWave W = G.w[wave];
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   }
   const int ky = W.tap0 / KS;   // this wave's kernel row
 
-  int tile = blockIdx.x;
+  int tile = split;
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += a.S) {
     __syncthreads();  // previous tile's LDS reads done
@@ -250,12 +259,12 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     }
   }
   if (W.active) {
-    float* slab = a.slabs + (size_t)(W.slab_base + blockIdx.x * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
+    float* slab = a.slabs + (size_t)(W.slab_base + split * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
       for (int i = 0; i < 16; ++i) slab[(tl * 32 + mfma32_row(i, lane)) * 32 + r] = acc[tl][i];
-    if (W.bias_slab >= 0) a.bslabs[(size_t)(W.bias_slab + blockIdx.x * W.ks_n + W.ks_idx) * 64 + lane] = bsum;
+    if (W.bias_slab >= 0) a.bslabs[(size_t)(W.bias_slab + split * W.ks_n + W.ks_idx) * 64 + lane] = bsum;
   }
 }
 
@@ -441,7 +450,7 @@ static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
     SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
     attr_lds = H.lds_bytes;
   }
-  SRGANFD_LAUNCH(kern, dim3(H.S, H.ngroups), dim3(64 * WgWaves<KS>::NW), H.lds_bytes, stream, k);
+  SRGANFD_LAUNCH(kern, dim3(H.S * H.ngroups), dim3(64 * WgWaves<KS>::NW), H.lds_bytes, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -458,7 +467,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.groups = (const WgGroup*)((const char*)plan_dev + H.groups_off);
   k.xC = x.cstride; k.x_c0v = x.c0; k.dyC = dy.cstride; k.dy_c0v = dy.c0;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
-  k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
+  k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
   const bool bf = H.dtype == SRGANFD_BF16;
   if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
