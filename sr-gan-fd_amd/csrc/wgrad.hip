@@ -47,6 +47,14 @@ struct WgK {
 
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// two transposed 4-element reads -> one 8-element MFMA fragment: pure register concatenation (no VALU)
+__device__ __forceinline__ bf16x8 cat_frag(s16x4 lo, s16x4 hi) {
+  const u32x2 l = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  const u32x4 v = {l.x, l.y, h2.x, h2.y};
+  return __builtin_bit_cast(bf16x8, v);
+}
 
 template <int KS, int STRIDE> struct WgTile { static constexpr int TH = (STRIDE == 1) ? 8 : 4; };
 
@@ -54,7 +62,9 @@ template <int KS> struct WgWaves { static constexpr int NW = (KS == 3) ? 12 : (K
 
 // One wave = one (32 ci x 32 co) block x ONE kernel row (KS taps, KS*16 accumulator registers), so a
 // 3x3 workgroup runs 12 waves (3 per SIMD, <=168 VGPRs each) over the same staged tiles.
-template <typename T, int KS, int STRIDE>
+// XP / YP = LDS row pitch of the x / dy tiles in 32-channel units (compile-time so that every LDS address in
+// the MFMA loop is table + wave-uniform row offset + immediate).
+template <typename T, int KS, int STRIDE, int XP, int YP>
 __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a) {
   constexpr int TH = WgTile<KS, STRIDE>::TH;
   constexpr int NTHR = 64 * WgWaves<KS>::NW;
@@ -83,10 +93,11 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WgWave W = G.w[wave];
   const int r = lane & 31, h = lane >> 5;
-  const int xu_sh = G.x_units == 2 ? 1 : 0, yu_sh = G.dy_units == 2 ? 1 : 0;   // units are 1 or 2
-  const int xRowB = UB << xu_sh, dyRowB = UB << yu_sh;
+  const int xu_sh = G.x_units == 2 ? 1 : 0, yu_sh = G.dy_units == 2 ? 1 : 0;   // units staged by this group (1 or 2)
+  constexpr int xp_sh = XP == 2 ? 1 : 0, yp_sh = YP == 2 ? 1 : 0;                // pitch (swizzle follows the pitch)
+  constexpr int xRowB = UB * XP, dyRowB = UB * YP;
   char* ldsX = smem;
-  char* ldsY = smem + PR * PC * (UB * a.x_upad);   // x_upad = largest x_units of the launch
+  char* ldsY = smem + PR * PC * xRowB;
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
   const T* __restrict__ xg = (const T*)a.x + a.x_c0v + G.x_c0;
   const T* __restrict__ dyg = (const T*)a.dy + a.dy_c0v + G.dy_c0;
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
       if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-        v = *(const u32x4*)(xg + ((size_t)(n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + c16 * E16);
+        v = *(const u32x4*)(xg + (((n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + c16 * E16));   // 32-bit offsets (host-checked)
     }
     return v;
   };
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     if (item < xItems) {
       const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
       const int unit = c16 >> CPU_SH, w16 = c16 & (CPU - 1);
-      const int f = sizeof(T) == 2 ? swz(xu_sh, pix) : 0;
+      const int f = sizeof(T) == 2 ? swz(xp_sh, pix) : 0;
       *(u32x4*)(ldsX + pix * xRowB + ((unit ^ f) * UB) + w16 * 16) = v;
     }
   };
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     if (item < yItems) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.dyC + c16 * E16);
+      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (((n * a.Hout + oy) * a.Wout + ox) * a.dyC + c16 * E16));
     }
     return v;
   };
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     if (item < yItems) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int unit = c16 >> CPU_SH, w16 = c16 & (CPU - 1);
-      const int f = sizeof(T) == 2 ? swz(yu_sh, pix) : 0;
+      const int f = sizeof(T) == 2 ? swz(yp_sh, pix) : 0;
       *(u32x4*)(ldsY + pix * dyRowB + ((unit ^ f) * UB) + w16 * 16) = v;
     }
   };
@@ -194,9 +205,9 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) {
         const int x = 2 * P + dx + Lpix * STRIDE;   // pixel index mod 4 is what the swizzle needs
-        tabX[P][dx] = (Lpix * STRIDE + dx) * xRowB + ((W.ci_rel ^ swz(xu_sh, x)) * UB) + chb;
+        tabX[P][dx] = (Lpix * STRIDE + dx) * xRowB + ((W.ci_rel ^ swz(xp_sh, x)) * UB) + chb;
       }
-    tabY = Lpix * dyRowB + ((W.co_rel ^ swz(yu_sh, Lpix)) * UB) + chb;
+    tabY = Lpix * dyRowB + ((W.co_rel ^ swz(yp_sh, Lpix)) * UB) + chb;
   }
   const int ky = W.tap0 / KS;   // this wave's kernel row
 
@@ -224,21 +235,18 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
             const char* yb = ldsY + ay + hh * 16 * dyRowB;
             const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb));
             const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 4 * dyRowB));
-            const u16x8 bpk = {(unsigned short)blo[0], (unsigned short)blo[1], (unsigned short)blo[2], (unsigned short)blo[3],
-                               (unsigned short)bhi[0], (unsigned short)bhi[1], (unsigned short)bhi[2], (unsigned short)bhi[3]};
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bpk);
+            const bf16x8 bfrag = cat_frag(blo, bhi);
             if (W.bias_slab >= 0) {
-              bsum += bf2f((unsigned short)blo[0]) + bf2f((unsigned short)blo[1]) + bf2f((unsigned short)blo[2]) + bf2f((unsigned short)blo[3]) +
-                      bf2f((unsigned short)bhi[0]) + bf2f((unsigned short)bhi[1]) + bf2f((unsigned short)bhi[2]) + bf2f((unsigned short)bhi[3]);
+              const u32x2 l = __builtin_bit_cast(u32x2, blo), h2 = __builtin_bit_cast(u32x2, bhi);
+              bsum += __uint_as_float(l.x << 16) + __uint_as_float(l.x & 0xffff0000u) + __uint_as_float(l.y << 16) + __uint_as_float(l.y & 0xffff0000u) +
+                      __uint_as_float(h2.x << 16) + __uint_as_float(h2.x & 0xffff0000u) + __uint_as_float(h2.y << 16) + __uint_as_float(h2.y & 0xffff0000u);
             }
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
               const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
               const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
               const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
-              const u16x8 pk = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
-                                (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
-              acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), bfrag, acc[dx], 0, 0, 0);
+              acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat_frag(lo, hi), bfrag, acc[dx], 0, 0, 0);
             }
           }
         } else {
@@ -442,11 +450,11 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
   return SRGANFD_OK;
 }
 
-template <typename T, int KS, int STRIDE>
-static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
-  auto kern = wgrad_kernel<T, KS, STRIDE>;
+template <typename T, int KS, int STRIDE, int XP, int YP>
+static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP>;
   static int attr_lds = 0;
-  if (H.lds_bytes > attr_lds) {
+  if (H.lds_bytes > attr_lds && !g_dry_run) {
     SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
     attr_lds = H.lds_bytes;
   }
@@ -454,12 +462,19 @@ static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
+template <typename T, int KS, int STRIDE>
+static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  if (H.x_upad == 2) return H.dy_upad == 2 ? launch_wgrad2<T, KS, STRIDE, 2, 2>(H, k, stream) : launch_wgrad2<T, KS, STRIDE, 2, 1>(H, k, stream);
+  return H.dy_upad == 2 ? launch_wgrad2<T, KS, STRIDE, 1, 2>(H, k, stream) : launch_wgrad2<T, KS, STRIDE, 1, 1>(H, k, stream);
+}
 
 int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads, const float* scalars,
                void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!plan_host || !plan_dev || !x.ptr || !dy.ptr || !grads || !workspace) return set_err(SRGANFD_EINVAL, "wgrad: null pointer");
   const WgHeader& H = *(const WgHeader*)plan_host;
   if (H.magic != kWgMagic) return set_err(SRGANFD_EINVAL, "wgrad: bad plan");
+  if ((size_t)H.N * H.Hin * H.Win * (size_t)x.cstride >= 0x7fffffffULL || (size_t)H.N * H.Hout * H.Wout * (size_t)dy.cstride >= 0x7fffffffULL)
+    return set_err(SRGANFD_EINVAL, "wgrad: tensors too large for 32-bit element offsets");
   const size_t need = (size_t)(H.bias_slab_off + H.nbias_slabs * 64) * sizeof(float);
   if (workspace_bytes < need) return set_err(SRGANFD_ENOSPC, "wgrad: workspace %zu < %zu", workspace_bytes, need);
   WgK k;
