@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--num-rrdb", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0, help="kernel timing experiments (results invalid)")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,9 @@ def main():
     from sr_gan_fd_amd import profiling
     from sr_gan_fd_amd.trainer import GeneratorTrainer
 
+    if args.debug_flags:
+        from sr_gan_fd_amd import _abi
+        _abi.lib().srganfd_set_debug(args.debug_flags)
     B, h = args.batch, args.lr_size
     torch.manual_seed(0)                      # identical weights on every rank (bsrgan_config.py:35-37 seeds at import)
     g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)

@@ -35,6 +35,9 @@ int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
 void srganfd_set_dry_run(int on);
+/* timing experiments only: bit 0 skip activation loads, bit 1 skip weight loads, bit 2 skip the epilogue of
+ * the conv kernel (results are wrong when non-zero; never set in production). */
+void srganfd_set_debug(int flags);
 
 /* A channel-slice view of an NHWC activation buffer: element (n,y,x,c) lives at
  * ptr[((n*H + y)*W + x)*cstride + c0 + c]. */

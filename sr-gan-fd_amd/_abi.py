@@ -70,6 +70,7 @@ SYMBOLS = {
     "srganfd_last_error": (C.c_char_p, []),
     "srganfd_abi_version": (C.c_int, []),
     "srganfd_set_dry_run": (None, [C.c_int]),
+    "srganfd_set_debug": (None, [C.c_int]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -5,6 +5,7 @@
 namespace srganfd {
 thread_local char g_err[512] = {0};
 int g_dry_run = 0;
+int g_debug = 0;
 int set_err(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -44,6 +45,7 @@ extern "C" {
 const char* srganfd_last_error(void) { return g_err; }
 int srganfd_abi_version(void) { return 1; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
+void srganfd_set_debug(int flags) { g_debug = flags; }
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }
 

@@ -43,6 +43,7 @@ struct WgK {
   const WgGroup* groups;
   int xC, x_c0v, dyC, dy_c0v;
   int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y, ngroups;
+  int dbg;   // timing experiments only (srganfd_set_debug): 1 no global loads, 4 no slab store, 8 no LDS commit, 16 no LDS reads, 32 no barriers
 };
 
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   auto load_x = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < xItems) {
+    if (item < xItems && !(a.dbg & 1)) {
       const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   auto load_y = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < yItems) {
+    if (item < yItems && !(a.dbg & 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (((n * a.Hout + oy) * a.Wout + ox) * a.dyC + c16 * E16));
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   int tile = split;
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += a.S) {
-    __syncthreads();  // previous tile's LDS reads done
-    commit(tile);
-    __syncthreads();
+    if (!(a.dbg & 32)) __syncthreads();  // previous tile's LDS reads done
+    if (!(a.dbg & 8)) commit(tile);
+    if (!(a.dbg & 32)) __syncthreads();
     if (tile + a.S < a.ntiles) prefetch(tile + a.S);
-    if (W.active) {
+    if (W.active && !(a.dbg & 16)) {
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
         if constexpr (sizeof(T) == 2) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
       }
     }
   }
-  if (W.active) {
+  if (W.active && !(a.dbg & 4)) {
     float* slab = a.slabs + (size_t)(W.slab_base + split * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
@@ -277,33 +278,49 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
 }
 
 // Deterministic slab reduction + layout change to the NCHW fp32 parameter gradient.
+// One block = one (task, tap): its 32x32 fp32 tile is read as one float4 per thread and slab, eight slabs in
+// flight per thread (independent accumulators, fixed summation order -> bitwise reproducible).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgTask* __restrict__ tasks, const float* __restrict__ slabs,
                                                            const float* __restrict__ bslabs, float* __restrict__ grads,
                                                            const float* __restrict__ scalars, int ntap_wave) {
   const WgTask T = tasks[blockIdx.y];
   const int KT = T.ksize * T.ksize;
+  const int tl = blockIdx.x;              // tap
   float alpha = T.alpha;
   if (T.alpha_off >= 0) alpha *= scalars[T.alpha_off];
-  const int total = T.ntap * 1024;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int col = e & 31, row = (e >> 5) & 31, tl = e >> 10;
-    const int co = T.co_base + col, ci = T.ci_base + row;
-    if (co < T.co_dst && ci < T.ci_dst) {
-      float s = 0.f;
-      const float* p = slabs + (size_t)T.slab_base * (ntap_wave * 1024) + e;
-      for (int k = 0; k < T.nslabs; ++k) s += p[(size_t)k * (ntap_wave * 1024)];
-      float* d = grads + T.dw_off + ((size_t)co * T.ci_dst + ci) * KT + T.tap0 + tl;
-      *d = alpha * s + (T.beta != 0.f ? T.beta * *d : 0.f);
+  const size_t slab_stride = (size_t)ntap_wave * 1024;
+  const int row = threadIdx.x >> 3, col4 = (threadIdx.x & 7) * 4;
+  const f32x4* p = (const f32x4*)(slabs + (size_t)T.slab_base * slab_stride + tl * 1024 + row * 32 + col4);
+  const size_t st4 = slab_stride / 4;
+  f32x4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= T.nslabs; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * st4];
+  }
+  for (; k < T.nslabs; ++k) s[0] += p[(size_t)k * st4];
+  const f32x4 tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  const int ci = T.ci_base + row;
+  if (ci < T.ci_dst) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = T.co_base + col4 + q;
+      if (co < T.co_dst) {
+        float* d = grads + T.dw_off + ((size_t)co * T.ci_dst + ci) * KT + T.tap0 + tl;
+        *d = alpha * tot[q] + (T.beta != 0.f ? T.beta * *d : 0.f);
+      }
     }
   }
-  if (T.bias_slab >= 0 && T.db_off >= 0 && blockIdx.x == 0 && threadIdx.x < 32) {
+  if (T.bias_slab >= 0 && T.db_off >= 0 && tl == 0 && threadIdx.x < 32) {
     const int co = T.co_base + threadIdx.x;
     if (co < T.co_dst) {
-      float s = 0.f;
-      const float* p = bslabs + (size_t)T.bias_slab * 64;
-      for (int k = 0; k < T.nslabs; ++k) s += p[k * 64 + threadIdx.x] + p[k * 64 + 32 + threadIdx.x];
+      float sb = 0.f;
+      const float* pb = bslabs + (size_t)T.bias_slab * 64;
+      for (int kk = 0; kk < T.nslabs; ++kk) sb += pb[kk * 64 + threadIdx.x] + pb[kk * 64 + 32 + threadIdx.x];
       float* d = grads + T.db_off + co;
-      *d = alpha * s + (T.beta != 0.f ? T.beta * *d : 0.f);
+      *d = alpha * sb + (T.beta != 0.f ? T.beta * *d : 0.f);
     }
   }
 }
@@ -393,7 +410,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.ntasks = (int)pb.tasks.size();
   // pixel-tile splits: aim at ~2 workgroups per CU over the whole launch
   int S = s->splits;
-  if (S <= 0) { S = (512 + H.ngroups - 1) / H.ngroups; if (S < 1) S = 1; }
+  if (S <= 0) { S = (256 + H.ngroups - 1) / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, one round
   if (S > H.ntiles) S = H.ntiles;
   if (S > 4096) S = 4096;
   H.S = S;
@@ -482,7 +499,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.groups = (const WgGroup*)((const char*)plan_dev + H.groups_off);
   k.xC = x.cstride; k.x_c0v = x.c0; k.dyC = dy.cstride; k.dy_c0v = dy.c0;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
-  k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
+  k.dbg = g_debug; k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
   const bool bf = H.dtype == SRGANFD_BF16;
   if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
@@ -490,7 +507,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
   if (rc != SRGANFD_OK) return rc;
   const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
-  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3((H.ntap_wave * 1024 + 255) / 256, H.ntasks), dim3(256), 0, stream, tasks_dev,
+  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(H.ntap_wave, H.ntasks), dim3(256), 0, stream, tasks_dev,
                      (const float*)k.slabs, (const float*)k.bslabs, grads, scalars, H.ntap_wave);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
