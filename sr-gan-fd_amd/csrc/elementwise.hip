@@ -24,6 +24,156 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
   return r;  // valid on thread 0
 }
 
+// ---- 16-byte vector access (8 bf16 / 4 f32 channels per lane): every view-to-view kernel below has a
+// vector form used whenever channel count, view offset and buffer stride are multiples of VecN<T>.
+template <typename T> struct VecN { static constexpr int N = 16 / (int)sizeof(T); };
+template <typename T> __device__ __forceinline__ void ldv(const void* p, size_t i, float* o) {
+  if constexpr (sizeof(T) == 2) {
+    const u32x4 r = *(const u32x4*)((const bf16_t*)p + i);
+    const unsigned w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3];
+    o[0] = __uint_as_float(w0 << 16); o[1] = __uint_as_float(w0 & 0xffff0000u);
+    o[2] = __uint_as_float(w1 << 16); o[3] = __uint_as_float(w1 & 0xffff0000u);
+    o[4] = __uint_as_float(w2 << 16); o[5] = __uint_as_float(w2 & 0xffff0000u);
+    o[6] = __uint_as_float(w3 << 16); o[7] = __uint_as_float(w3 & 0xffff0000u);
+  } else {
+    const f32x4 r = *(const f32x4*)((const float*)p + i);
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+  }
+}
+template <typename T> __device__ __forceinline__ void stv(void* p, size_t i, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    u32x4 o;
+    o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    o[2] = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    o[3] = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(u32x4*)((bf16_t*)p + i) = o;
+  } else {
+    const f32x4 o = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)((float*)p + i) = o;
+  }
+}
+
+// generic 2-D resampling on vectors: op 0 nearest-x2 backward, 1 bilinear-x2 forward, 2 bilinear-x2 backward, 3 maxpool2, 4 relu
+__device__ __forceinline__ void bil_taps(int d, int n, int& i0, int& i1, float& w0, float& w1);
+__device__ __forceinline__ int bil_bwd_taps(int k, int n, int* d, float* wt);
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int n, int h, int w, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  // output extents: op0/2 -> (h, w) low-res ; op1 -> (2h, 2w) ; op3 -> (h/2, w/2) ; op4 -> (h, w)
+  const int oh = OP == 1 ? 2 * h : (OP == 3 ? h / 2 : h), ow = OP == 1 ? 2 * w : (OP == 3 ? w / 2 : w);
+  const size_t total = (size_t)n * oh * ow * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    size_t p = i / cv;
+    const int ox = (int)(p % ow); p /= ow;
+    const int oy = (int)(p % oh);
+    const size_t img = p / oh;
+    float acc[N], t[N];
+    if constexpr (OP == 0) {          // sum of the 2x2 high-res pixels
+      const size_t bq = (img * 2 * h + 2 * oy) * 2 * w + 2 * ox;
+      ldv<T>(a, bq * aC + a0 + ch, acc);
+      ldv<T>(a, (bq + 1) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += t[q];
+      ldv<T>(a, (bq + 2 * w) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += t[q];
+      ldv<T>(a, (bq + 2 * w + 1) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += t[q];
+    } else if constexpr (OP == 1) {   // bilinear forward
+      int ya, yb, xa, xb; float wya, wyb, wxa, wxb;
+      bil_taps(oy, h, ya, yb, wya, wyb);
+      bil_taps(ox, w, xa, xb, wxa, wxb);
+      const size_t r0 = (img * h + ya) * w, r1 = (img * h + yb) * w;
+      ldv<T>(a, (r0 + xa) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = wya * wxa * t[q];
+      ldv<T>(a, (r0 + xb) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wya * wxb * t[q];
+      ldv<T>(a, (r1 + xa) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wyb * wxa * t[q];
+      ldv<T>(a, (r1 + xb) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wyb * wxb * t[q];
+    } else if constexpr (OP == 2) {   // bilinear backward (gather form)
+      int dys[6], dxs[6]; float wys[6], wxs[6];
+      const int ny = bil_bwd_taps(oy, h, dys, wys), nx = bil_bwd_taps(ox, w, dxs, wxs);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = 0.f;
+      for (int ia = 0; ia < ny; ++ia)
+        for (int ib = 0; ib < nx; ++ib) {
+          ldv<T>(a, ((img * 2 * h + dys[ia]) * 2 * w + dxs[ib]) * aC + a0 + ch, t);
+          const float ww = wys[ia] * wxs[ib];
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc[q] += ww * t[q];
+        }
+    } else if constexpr (OP == 3) {   // 2x2 max pool
+      const size_t bq = (img * h + 2 * oy) * w + 2 * ox;
+      ldv<T>(a, bq * aC + a0 + ch, acc);
+      ldv<T>(a, (bq + 1) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = fmaxf(acc[q], t[q]);
+      ldv<T>(a, (bq + w) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = fmaxf(acc[q], t[q]);
+      ldv<T>(a, (bq + w + 1) * aC + a0 + ch, t);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = fmaxf(acc[q], t[q]);
+    } else {                           // relu copy
+      ldv<T>(a, ((img * h + oy) * w + ox) * aC + a0 + ch, acc);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = fmaxf(acc[q], 0.f);
+    }
+    stv<T>(b, ((img * oh + oy) * ow + ox) * (size_t)bC + b0 + ch, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lrelu_bwd_vec_kernel(const void* __restrict__ dy, int dC, int d0, const void* __restrict__ act, int aC, int a0,
+                                                            const void* __restrict__ skip, int sC, int s0, void* out, int oC, int o0, size_t npix, int c, float slope) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float g[N], z[N], sk[N];
+    ldv<T>(dy, p * dC + d0 + ch, g);
+    ldv<T>(act, p * aC + a0 + ch, z);
+    if (skip) {
+      ldv<T>(skip, p * sC + s0 + ch, sk);
+#pragma unroll
+      for (int q = 0; q < N; ++q) z[q] -= sk[q];
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) g[q] *= z[q] > 0.f ? 1.f : slope;
+    stv<T>(out, p * oC + o0 + ch, g);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_vec_kernel(const void* __restrict__ x, int xC, int x0, void* y, int yC, int y0, size_t npix, int c, float a, float b) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float vx[N], vy[N];
+    ldv<T>(x, p * xC + x0 + ch, vx);
+    if (b != 0.f) ldv<T>(y, p * yC + y0 + ch, vy);
+#pragma unroll
+    for (int q = 0; q < N; ++q) vx[q] = a * vx[q] + (b != 0.f ? b * vy[q] : 0.f);
+    stv<T>(y, p * yC + y0 + ch, vx);
+  }
+}
+
 // ---- NCHW fp32 -> NHWC T view, zero padded to cpad channels (BSRGAN.forward input, model.py:366) ----
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* dst, int dC, int d0, int n, int c, int hw, int cpad,
@@ -39,6 +189,31 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* dst, in
       if (mean) v = (v - mean[ch]) / stdv[ch];
     }
     st<T>(dst, p * dC + d0 + ch, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* __restrict__ src, void* dst, int dC, int d0, int n, int c, int hw, int cpad,
+                                                               const float* __restrict__ mean, const float* __restrict__ stdv) {
+  constexpr int N = VecN<T>::N;
+  const int cv = cpad / N;
+  const size_t total = (size_t)n * hw * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ck = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    const size_t img = p / hw, pix = p % hw;
+    float v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int ch = ck + q;
+      float t = 0.f;
+      if (ch < c) {
+        t = src[(img * c + ch) * hw + pix];
+        if (mean) t = (t - mean[ch]) / stdv[ch];
+      }
+      v[q] = t;
+    }
+    stv<T>(dst, p * dC + d0 + ck, v);
   }
 }
 
@@ -236,6 +411,30 @@ __global__ __launch_bounds__(256) void l1_views_partial_kernel(const void* __res
   const float r = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
+template <typename T>
+__global__ __launch_bounds__(256) void l1_views_vec_partial_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
+                                                                   size_t npix, int c, int relu, float* __restrict__ partial) {
+  constexpr int N = VecN<T>::N;
+  __shared__ float sh[4];
+  float s = 0.f;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float va[N], vb[N];
+    ldv<T>(a, p * aC + a0 + ch, va);
+    ldv<T>(b, p * bC + b0 + ch, vb);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      float x = va[q], y = vb[q];
+      if (relu) { x = fmaxf(x, 0.f); y = fmaxf(y, 0.f); }
+      s += fabsf(x - y);
+    }
+  }
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
 // BCE-with-logits against a constant label map (train_bsrgan.py:301,403-404): loss and sigmoid mean
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ x, size_t n, float target, float gscale,
                                                           float* __restrict__ grad, float* __restrict__ partial, float* __restrict__ partial_sig) {
@@ -361,6 +560,16 @@ static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 81
 int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s) {
   if (!src || !dst.ptr || n <= 0 || c <= 0 || cpad < c || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "nchw_to_nhwc: bad args");
   const size_t total = (size_t)n * h * w * cpad;
+  {
+    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    if (cpad % vn == 0 && dst.c0 % vn == 0 && dst.cstride % vn == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
+      DISPATCH_T(dtype,
+                 SRGANFD_LAUNCH(nchw_to_nhwc_vec_kernel<bf16_t>, dim3(grid_for(total / vn, 256, 65536)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv),
+                 SRGANFD_LAUNCH(nchw_to_nhwc_vec_kernel<float>, dim3(grid_for(total / vn, 256, 65536)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
+      SRGANFD_HIP_CHECK(hipGetLastError());
+      return SRGANFD_OK;
+    }
+  }
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv),
              SRGANFD_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
@@ -392,18 +601,46 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
 #define RS(K, TOTAL) DISPATCH_T(dtype, \
     SRGANFD_LAUNCH(K<bf16_t>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c), \
     SRGANFD_LAUNCH(K<float>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
-  if (op == 0) { RS(up2_nearest_bwd_kernel, lo); }
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const bool vec = c % vn == 0 && a.c0 % vn == 0 && b.c0 % vn == 0 && a.cstride % vn == 0 && b.cstride % vn == 0 &&
+                   ((uintptr_t)a.ptr & 15) == 0 && ((uintptr_t)b.ptr & 15) == 0;
+#define RSV(OP, TOTAL) DISPATCH_T(dtype, \
+    SRGANFD_LAUNCH((resample_vec_kernel<bf16_t, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c), \
+    SRGANFD_LAUNCH((resample_vec_kernel<float, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
+  if (vec) {
+    if (op == 0) { RSV(0, lo); }
+    else if (op == 1) { RSV(1, lo * 4); }
+    else if (op == 2) { RSV(2, lo); }
+    else if (op == 3) { RSV(3, lo / 4); }
+    else if (op == 4) { RSV(4, lo); }
+    else return set_err(SRGANFD_EINVAL, "resample: bad op %d", op);
+  }
+  else if (op == 0) { RS(up2_nearest_bwd_kernel, lo); }
   else if (op == 1) { RS(up2_bilinear_fwd_kernel, lo * 4); }
   else if (op == 2) { RS(up2_bilinear_bwd_kernel, lo); }
   else if (op == 3) { RS(maxpool2_kernel, lo / 4); }
   else if (op == 4) { RS(relu_copy_kernel, lo); }
   else return set_err(SRGANFD_EINVAL, "resample: bad op %d", op);
 #undef RS
+#undef RSV
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int dtype, size_t npix, int c, float slope, hipStream_t s) {
   if (!dy.ptr || !act.ptr || !out.ptr) return set_err(SRGANFD_EINVAL, "lrelu_bwd: null");
+  {
+    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    auto ok = [&](const srganfd_view& v) { return !v.ptr || (v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0); };
+    if (c % vn == 0 && ok(dy) && ok(act) && ok(skip) && ok(out)) {
+      DISPATCH_T(dtype,
+                 SRGANFD_LAUNCH(lrelu_bwd_vec_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope),
+                 SRGANFD_LAUNCH(lrelu_bwd_vec_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope));
+      SRGANFD_HIP_CHECK(hipGetLastError());
+      return SRGANFD_OK;
+    }
+  }
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
                                 skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope),
@@ -414,6 +651,17 @@ int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd
 }
 int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s) {
   if (!x.ptr || !y.ptr) return set_err(SRGANFD_EINVAL, "axpby: null");
+  {
+    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    auto ok = [&](const srganfd_view& v) { return v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0; };
+    if (c % vn == 0 && ok(x) && ok(y)) {
+      DISPATCH_T(dtype,
+                 SRGANFD_LAUNCH(axpby_vec_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b),
+                 SRGANFD_LAUNCH(axpby_vec_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
+      SRGANFD_HIP_CHECK(hipGetLastError());
+      return SRGANFD_OK;
+    }
+  }
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(axpby_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b),
              SRGANFD_LAUNCH(axpby_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
@@ -435,6 +683,12 @@ int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c,
   if (!a.ptr || !b.ptr || !out || !ws) return set_err(SRGANFD_EINVAL, "l1_views: bad args");
   const size_t n = npix * c;
   const unsigned g = grid_for(n, 256, kRedBlocks);
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  if (c % vn == 0 && a.c0 % vn == 0 && b.c0 % vn == 0 && a.cstride % vn == 0 && b.cstride % vn == 0 && ((uintptr_t)a.ptr & 15) == 0 && ((uintptr_t)b.ptr & 15) == 0) {
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(l1_views_vec_partial_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws),
+               SRGANFD_LAUNCH(l1_views_vec_partial_kernel<float>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
+  } else
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(l1_views_partial_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws),
              SRGANFD_LAUNCH(l1_views_partial_kernel<float>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
