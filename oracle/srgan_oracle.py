@@ -360,3 +360,72 @@ def gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: T
         "d_gt_probability": float(torch.sigmoid(gt_out.detach()).mean()),
         "d_sr_probability": float(torch.sigmoid(sr_out.detach()).mean()),
     }
+
+
+# ----------------------------------------------------------------------------------------------
+# A-ESRGAN attention U-Net discriminator (BASELINE config 5)
+# ----------------------------------------------------------------------------------------------
+AESRGAN_SN_LAYERS = ("conv1", "conv2", "conv3", "gating", "cat_1.convU", "conv4", "cat_2.convU", "conv5",
+                     "cat_3.convU", "conv6", "conv7", "conv8")
+
+
+def aesrgan_unet_forward(x: Tensor, P: Params, training: bool = True, update_state: bool = True,
+                         return_attention: bool = False):
+    """UNetDiscriminatorAesrgan.forward -- A-ESRGAN/model.py:311-338 with add_attn.forward :239-254 and
+    unetCat.forward :265-275.  P uses the reference's state_dict keys (``conv1.weight_orig/_u/_v``,
+    ``attn_1.W.0.weight``, ``attn_1.W.1.running_mean`` ...).  In training mode the spectral-norm u/v and the
+    BatchNorm running statistics in P are advanced exactly like the reference modules do."""
+    def sn_w(layer: str) -> Tensor:
+        w, u, v = spectral_norm_weight(P[f"{layer}.weight_orig"], P[f"{layer}.weight_u"], P[f"{layer}.weight_v"], training)
+        if training and update_state:
+            P[f"{layer}.weight_u"], P[f"{layer}.weight_v"] = u, v
+        return w
+
+    def lrelu(t: Tensor) -> Tensor:
+        return F.leaky_relu(t, LRELU_SLOPE)
+
+    def attn(xf: Tensor, g: Tensor, pre: str):
+        theta = F.conv2d(xf, P[f"{pre}.theta.weight"], None, stride=2)
+        phi = F.conv2d(g, P[f"{pre}.phi.weight"], P[f"{pre}.phi.bias"])
+        phi = F.interpolate(phi, size=theta.shape[2:], mode="bilinear", align_corners=False)
+        f = F.relu(theta + phi)
+        sig = torch.sigmoid(F.conv2d(f, P[f"{pre}.psi.weight"], P[f"{pre}.psi.bias"]))
+        sig = F.interpolate(sig, size=xf.shape[2:], mode="bilinear", align_corners=False)
+        y = sig.expand_as(xf) * xf
+        wy = F.conv2d(y, P[f"{pre}.W.0.weight"], P[f"{pre}.W.0.bias"])
+        rm, rv = P[f"{pre}.W.1.running_mean"], P[f"{pre}.W.1.running_var"]
+        if training and update_state:
+            rm, rv = rm.clone(), rv.clone()
+        wy = F.batch_norm(wy, rm if (training and update_state) or not training else None,
+                          rv if (training and update_state) or not training else None,
+                          P[f"{pre}.W.1.weight"], P[f"{pre}.W.1.bias"], training, 0.1, 1e-5)
+        if training and update_state:
+            P[f"{pre}.W.1.running_mean"], P[f"{pre}.W.1.running_var"] = rm, rv
+            P[f"{pre}.W.1.num_batches_tracked"] = P[f"{pre}.W.1.num_batches_tracked"] + 1
+        return wy, sig
+
+    def cat(in1: Tensor, in2: Tensor, pre: str) -> Tensor:
+        up = F.interpolate(in2, scale_factor=2, mode="bilinear", align_corners=False)
+        out2 = lrelu(F.conv2d(up, sn_w(f"{pre}.convU"), None, padding=1))
+        off = out2.shape[2] - in1.shape[2]
+        out1 = F.pad(in1, 2 * [off // 2, off // 2])
+        return torch.cat([out1, out2], 1)
+
+    x0 = lrelu(F.conv2d(x, P["conv0.weight"], P["conv0.bias"], padding=1))
+    x1 = lrelu(F.conv2d(x0, sn_w("conv1"), None, stride=2, padding=1))
+    x2 = lrelu(F.conv2d(x1, sn_w("conv2"), None, stride=2, padding=1))
+    x3 = lrelu(F.conv2d(x2, sn_w("conv3"), None, stride=2, padding=1))
+    gated = lrelu(F.conv2d(x3, sn_w("gating"), None, padding=1))
+    a1, s1 = attn(x2, gated, "attn_1")
+    a2, s2 = attn(x1, gated, "attn_2")
+    a3, s3 = attn(x0, gated, "attn_3")
+    t = cat(a1, x3, "cat_1")
+    x4 = lrelu(F.conv2d(t, sn_w("conv4"), None, padding=1))
+    t = cat(a2, x4, "cat_2")
+    x5 = lrelu(F.conv2d(t, sn_w("conv5"), None, padding=1))
+    t = cat(a3, x5, "cat_3")
+    x6 = lrelu(F.conv2d(t, sn_w("conv6"), None, padding=1))
+    out = lrelu(F.conv2d(x6, sn_w("conv7"), None, padding=1))
+    out = lrelu(F.conv2d(out, sn_w("conv8"), None, padding=1))
+    out = F.conv2d(out, P["conv9.weight"], P["conv9.bias"], padding=1)
+    return (out, (s1, s2, s3)) if return_attention else out

@@ -27,6 +27,7 @@ __all__ = [
     "DiscriminatorUNet", "BSRGAN", "RRDBNet", "ContentLoss",
     "discriminator_unet", "bsrgan_x2", "bsrgan_x4", "content_loss",
     "rrdbnet_x1", "rrdbnet_x2", "rrdbnet_x4", "rrdbnet_x8",
+    "UNetDiscriminatorAesrgan", "uNetDiscriminatorAesrgan",
 ]
 
 
@@ -168,6 +169,64 @@ class ContentLoss(nn.Module):
         assert sr_tensor.size() == gt_tensor.size(), "Two tensor must have the same size"
         from .engine import content_loss_apply
         return content_loss_apply(self, sr_tensor, gt_tensor)
+
+
+class add_attn(nn.Module):
+    """Parameter container of the attention gate, A-ESRGAN/model.py:228-254."""
+
+    def __init__(self, x_channels, g_channels=256):
+        super().__init__()
+        self.W = nn.Sequential(nn.Conv2d(x_channels, x_channels, kernel_size=1, stride=1, padding=0), nn.BatchNorm2d(x_channels))
+        self.theta = nn.Conv2d(x_channels, x_channels, kernel_size=2, stride=2, padding=0, bias=False)
+        self.phi = nn.Conv2d(g_channels, x_channels, kernel_size=1, stride=1, padding=0, bias=True)
+        self.psi = nn.Conv2d(x_channels, out_channels=1, kernel_size=1, stride=1, padding=0, bias=True)
+
+
+class unetCat(nn.Module):
+    """Parameter container of A-ESRGAN/model.py:258-275."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.convU = spectral_norm(nn.Conv2d(dim_in, dim_out, 3, 1, 1, bias=False))
+
+
+class UNetDiscriminatorAesrgan(nn.Module):
+    """A-ESRGAN/model.py:279-345: attention U-Net discriminator with spectral normalisation (BASELINE config 5).
+    Same constructor arguments, state_dict keys and construction order (hence the same init RNG stream)."""
+
+    def __init__(self, num_in_ch, num_feat=64, skip_connection=True):
+        super().__init__()
+        norm = spectral_norm
+        self.conv0 = nn.Conv2d(num_in_ch, num_feat, kernel_size=3, stride=1, padding=1)
+        self.conv1 = norm(nn.Conv2d(num_feat, num_feat * 2, 3, 2, 1, bias=False))
+        self.conv2 = norm(nn.Conv2d(num_feat * 2, num_feat * 4, 3, 2, 1, bias=False))
+        self.conv3 = norm(nn.Conv2d(num_feat * 4, num_feat * 8, 3, 2, 1, bias=False))
+        self.gating = norm(nn.Conv2d(num_feat * 8, num_feat * 4, 1, 1, 1, bias=False))
+        self.attn_1 = add_attn(x_channels=num_feat * 4, g_channels=num_feat * 4)
+        self.attn_2 = add_attn(x_channels=num_feat * 2, g_channels=num_feat * 4)
+        self.attn_3 = add_attn(x_channels=num_feat, g_channels=num_feat * 4)
+        self.cat_1 = unetCat(dim_in=num_feat * 8, dim_out=num_feat * 4)
+        self.cat_2 = unetCat(dim_in=num_feat * 4, dim_out=num_feat * 2)
+        self.cat_3 = unetCat(dim_in=num_feat * 2, dim_out=num_feat)
+        self.conv4 = norm(nn.Conv2d(num_feat * 8, num_feat * 4, 3, 1, 1, bias=False))
+        self.conv5 = norm(nn.Conv2d(num_feat * 4, num_feat * 2, 3, 1, 1, bias=False))
+        self.conv6 = norm(nn.Conv2d(num_feat * 2, num_feat, 3, 1, 1, bias=False))
+        self.conv7 = norm(nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=False))
+        self.conv8 = norm(nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=False))
+        self.conv9 = nn.Conv2d(num_feat, 1, 3, 1, 1)
+        self.compute_dtype = torch.bfloat16
+        self.ly1 = self.ly2 = self.ly3 = None
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .engine_a import aesrgan_discriminator_apply
+        return aesrgan_discriminator_apply(self, x)
+
+    def getAttentionLayers(self):
+        return self.ly1, self.ly2, self.ly3
+
+
+def uNetDiscriminatorAesrgan() -> UNetDiscriminatorAesrgan:
+    return UNetDiscriminatorAesrgan(3)
 
 
 def discriminator_unet(**kwargs: Any) -> DiscriminatorUNet:

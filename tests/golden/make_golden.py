@@ -32,16 +32,30 @@ def _stub_torchvision():
     sys.modules["torchvision.models.feature_extraction"].create_feature_extractor = None
 
 
+def _stub_basicsr():
+    for name in ("basicsr", "basicsr.utils", "basicsr.utils.registry"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+    class _Reg:
+        def register(self, *a, **k):
+            return (lambda c: c) if not a else a[0]
+    sys.modules["basicsr.utils.registry"].ARCH_REGISTRY = _Reg()
+
+
 def load_ref(subdir):
     _stub_torchvision()
+    _stub_basicsr()
     path = os.path.join(REF, subdir)
     sys.path.insert(0, path)
     try:
         sys.modules.pop("model", None)
+        sys.modules.pop("aesrgan_config", None)
         mod = importlib.import_module("model")
     finally:
         sys.path.remove(path)
         sys.modules.pop("model", None)
+        sys.modules.pop("aesrgan_config", None)
     return mod
 
 
@@ -278,6 +292,45 @@ def gold_g_only_steps(MB, ME):
     save("g_only_steps.npz", **out)
 
 
+def gold_aesrgan_discriminator(MA):
+    """UNetDiscriminatorAesrgan (A-ESRGAN/model.py:279-345): two training forwards (SN u/v + BatchNorm running
+    stats advance), backward of BCE vs ones, eval forward, input gradient with frozen parameters."""
+    out = {}
+    torch.manual_seed(0)
+    d = MA.UNetDiscriminatorAesrgan(3)
+    x = torch.rand(2, 3, 64, 64)
+    out["x"] = np_(x)
+    out["wsum0"] = sd_checksums(d.state_dict())
+    d.train()
+    for it in range(2):
+        logits = d(x)
+        out[f"train{it}_logits"] = np_(logits)
+        sd = d.state_dict()
+        out[f"train{it}_statesum"] = {k: checksum(v) for k, v in sd.items()
+                                      if k.endswith(("_u", "_v", "running_mean", "running_var"))}
+        out[f"train{it}_attn3"] = np_(d.ly3)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    loss.backward()
+    out["bce_ones"] = np.array(loss.item())
+    named = dict(d.named_parameters())
+    out["gsum"] = {k: checksum(p.grad) for k, p in named.items()}
+    for k in ("conv0.weight", "conv9.weight", "conv9.bias", "attn_1.W.1.weight", "attn_1.W.1.bias", "attn_3.psi.weight",
+              "attn_2.theta.weight", "attn_3.phi.bias", "gating.weight_orig"):
+        out[f"grad/{k}"] = np_(named[k].grad)
+    d.eval()
+    with torch.no_grad():
+        out["eval_logits"] = np_(d(x))
+    d.train()
+    xin = x.clone().requires_grad_(True)
+    for p in d.parameters():
+        p.requires_grad = False
+    lg = d(xin)
+    torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    out["train2_dx"] = np_(xin.grad)
+    out["train2_logits"] = np_(lg)
+    save("aesrgan_discriminator.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     MB = load_ref("BSRGAN")
@@ -287,6 +340,7 @@ def main():
     gold_discriminator(MB)
     gold_gan_steps(MB)
     gold_g_only_steps(MB, ME)
+    gold_aesrgan_discriminator(load_ref("A-ESRGAN"))
 
 
 if __name__ == "__main__":

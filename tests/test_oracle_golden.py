@@ -175,3 +175,40 @@ def test_psnr_definition():
     y = lambda t: ((t * torch.tensor([65.481, 128.553, 24.966]).view(1, 3, 1, 1)).sum(1, keepdim=True) + 16.0) / 255.0
     mse = ((y(a).double() * 255 - y(b).double() * 255) ** 2 + 1e-8).mean(dim=[1, 2, 3])
     assert torch.allclose(O.psnr_y(a, b), 10 * torch.log10(255.0 ** 2 / mse), rtol=1e-6)
+
+
+def test_aesrgan_discriminator(golden_dir):
+    """UNetDiscriminatorAesrgan (A-ESRGAN/model.py:279-345) oracle vs vectors captured from the reference"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "aesrgan_discriminator.npz")
+    torch.manual_seed(0)
+    d = M.UNetDiscriminatorAesrgan(3)
+    _check_table(table(g, "wsum0"), d.state_dict(), what="A-ESRGAN D")
+    P = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    names = [k for k, _ in d.named_parameters()]
+    for k in names:
+        P[k].requires_grad_(True)
+    x = torch.tensor(g["x"])
+    for it in range(2):
+        logits, (s1, s2, s3) = O.aesrgan_unet_forward(x, P, training=True, return_attention=True)
+        _close(logits.detach(), g[f"train{it}_logits"], what=f"logits {it}")
+        _close(s3.detach(), g[f"train{it}_attn3"], what="attention map 3")
+        for k, want in table(g, f"train{it}_statesum").items():
+            assert np.allclose(checksum(P[k]), want, rtol=1e-4, atol=1e-5 * abs(want[1]) + 1e-9), f"state {k}"
+    loss = O.bce_with_logits_mean(logits, 1.0)
+    assert abs(loss.item() - float(g["bce_ones"])) < 1e-6
+    grads = dict(zip(names, torch.autograd.grad(loss, [P[k] for k in names])))
+    for k in ("conv0.weight", "conv9.weight", "conv9.bias", "attn_1.W.1.weight", "attn_1.W.1.bias", "attn_3.psi.weight",
+              "attn_2.theta.weight", "attn_3.phi.bias", "gating.weight_orig"):
+        _close(grads[k], g[f"grad/{k}"], tol=5e-4, what=f"grad {k}")
+    for k, want in table(g, "gsum").items():
+        # a bias in front of BatchNorm has a mathematically zero gradient (pure rounding noise): absolute floor
+        assert np.allclose(checksum(grads[k]), want, rtol=5e-3, atol=5e-4 * abs(want[1]) + 1e-6), f"grad checksum {k}"
+    with torch.no_grad():
+        _close(O.aesrgan_unet_forward(x, P, training=False), g["eval_logits"], what="eval logits")
+    xin = x.clone().requires_grad_(True)
+    lg = O.aesrgan_unet_forward(xin, P, training=True)
+    _close(lg.detach(), g["train2_logits"], what="logits 2")
+    dx, = torch.autograd.grad(O.bce_with_logits_mean(lg, 1.0), xin)
+    _close(dx, g["train2_dx"], tol=5e-4, what="dx")
