@@ -104,7 +104,9 @@ typedef struct {
   int32_t co_off, ci_off;
   int32_t transposed;     /* 0 forward, 1 data-gradient (flip taps, swap roles),
                              2+2*py+px: parity class (py,px) of a 4x4 stride-2 data gradient, packed as a
-                             2x2-tap operand: tap (a,b) <- source tap (ty,tx), ty = py ? 2-2a : 3-2a */
+                             2x2-tap operand: tap (a,b) <- source tap (ty,tx), ty = py ? 2-2a : 3-2a;
+                             6+2*py+px: same for a 3x3 stride-2 pad-1 conv (A-ESRGAN/model.py:287-291);
+                             10+2*a+b: tap (a,b) of a 2x2 stride-2 conv (:236) as a 1x1 operand */
   float scale;
 } srganfd_pack_seg;
 
@@ -210,6 +212,29 @@ int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                      int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
+
+/* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
+/* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);
+ * bwd=1: a = dy (ho x wo) -> b = dx (hi x wi), deterministic gather. */
+int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t hi,
+                            int32_t wi, int32_t ho, int32_t wo, int32_t c, void* stream);
+/* out = relu(a + b)  (model.py:246) */
+int srganfd_add_relu(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, void* stream);
+/* in-place sigmoid of an fp32 map (model.py:248) and its backward out = ds * s * (1 - s) */
+int srganfd_sigmoid(float* x, int64_t numel, void* stream);
+int srganfd_sigmoid_bwd(const float* ds, const float* s, float* out, int64_t numel, void* stream);
+/* attention gate y = gate[p] * x[p][c] (model.py:252).  bwd=1: y is dy; dx = gate * dy, dgate[p] = sum_c dy * x */
+int srganfd_gate_mul(int32_t bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate,
+                     int32_t dtype, int64_t npix, int32_t c, void* stream);
+/* nn.BatchNorm2d (model.py:233).  save: 4*c floats [mean | invstd | scale | shift]; workspace: 512*c + 3*c floats.
+ * training=1: batch statistics, running stats updated with `momentum` (unbiased variance); 0: running stats. */
+int srganfd_batchnorm_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          int32_t training, float* save, float* workspace, void* stream);
+/* dgamma/dbeta = acc * old + new; dx from the training-mode formula */
+int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c,
+                          const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
+                          float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,15 @@ SYMBOLS = {
     "srganfd_spectral_norm_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "srganfd_adam_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "srganfd_resize_bilinear": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "srganfd_add_relu": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "srganfd_sigmoid": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "srganfd_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "srganfd_gate_mul": (C.c_int, [C.c_int32, View, C.c_void_p, View, View, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "srganfd_batchnorm_fwd": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                        C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_batchnorm_bwd": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                        C.c_void_p, C.c_void_p]),
 }
 
 LOSS_WS_FLOATS = 2049

@@ -36,6 +36,15 @@ int spectral_norm_grad_impl(const float* G, const float* W, const float* u, cons
                             float beta, float* ws, hipStream_t s);
 int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                   float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
+int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s);
+int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s);
+int sigmoid_impl(float* x, size_t n, hipStream_t s);
+int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hipStream_t s);
+int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s);
+int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
+                       float momentum, float eps, int training, float* save, float* ws, hipStream_t s);
+int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
+                       float* dgamma, float* dbeta, float acc, float* ws, hipStream_t s);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -115,6 +124,32 @@ int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp
                      float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream) {
   return adam_ema_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay,
                        ema_mode, (hipStream_t)stream);
+}
+
+int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                            int32_t c, void* stream) {
+  return resize_bilinear_impl(bwd, a, b, dtype, n, hi, wi, ho, wo, c, (hipStream_t)stream);
+}
+int srganfd_add_relu(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, void* stream) {
+  return add_relu_impl(a, b, out, dtype, (size_t)npix, c, (hipStream_t)stream);
+}
+int srganfd_sigmoid(float* x, int64_t numel, void* stream) { return sigmoid_impl(x, (size_t)numel, (hipStream_t)stream); }
+int srganfd_sigmoid_bwd(const float* ds, const float* s, float* out, int64_t numel, void* stream) {
+  return sigmoid_bwd_impl(ds, s, out, (size_t)numel, (hipStream_t)stream);
+}
+int srganfd_gate_mul(int32_t bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int32_t dtype, int64_t npix,
+                     int32_t c, void* stream) {
+  return gate_mul_impl(bwd, x, gate, y, dx, dgate, dtype, (size_t)npix, c, (hipStream_t)stream);
+}
+int srganfd_batchnorm_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, int32_t training, float* save, float* workspace,
+                          void* stream) {
+  return batchnorm_fwd_impl(x, y, dtype, (size_t)npix, c, gamma, beta, running_mean, running_var, momentum, eps, training, save, workspace,
+                            (hipStream_t)stream);
+}
+int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                          const float* save, float* dgamma, float* dbeta, float acc, float* workspace, void* stream) {
+  return batchnorm_bwd_impl(x, dy, dx, dtype, (size_t)npix, c, gamma, save, dgamma, dbeta, acc, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

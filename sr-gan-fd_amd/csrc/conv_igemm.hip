@@ -408,6 +408,8 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
     if constexpr (bf) { if (wide) return launch_conv<T, 4, 2, 1, 4, 2>(k, a->cout, s); }
     return launch_conv<T, 4, 2, 1, 4, 1>(k, a->cout, s);
   }
+  if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1>(k, a->cout, s);
+  if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1>(k, a->cout, s);
   if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1>(k, a->cout, s);
   return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
 }

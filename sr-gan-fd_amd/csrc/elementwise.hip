@@ -5,6 +5,7 @@
 // All kernels are grid-stride, vectorised where the layout allows, and accumulate in fp32.
 // Reductions are two-stage (per-block partials, then one block) -> bitwise reproducible, no atomics.
 #include "common.hpp"
+#include <initializer_list>
 
 namespace srganfd {
 
@@ -546,6 +547,250 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
   }
 }
 
+// ---- A-ESRGAN attention gates (A-ESRGAN/model.py:239-254): general bilinear resize, relu(a+b), sigmoid,
+// gate multiply, BatchNorm2d (training statistics, running stats, backward) ----
+// F.interpolate(mode="bilinear", align_corners=False) with an explicit output size (ATen area_pixel source index)
+__device__ __forceinline__ void resize_taps(int d, int in, float scale, int& i0, int& i1, float& w0, float& w1) {
+  float src = scale * ((float)d + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+  w0 = 1.f - w1;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int n, int hi, int wi,
+                                                         int ho, int wo, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
+  const size_t total = (size_t)n * ho * wo * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    size_t p = i / cv;
+    const int ox = (int)(p % wo); p /= wo;
+    const int oy = (int)(p % ho);
+    const size_t img = p / ho;
+    int ya, yb, xa, xb; float wya, wyb, wxa, wxb;
+    resize_taps(oy, hi, sy, ya, yb, wya, wyb);
+    resize_taps(ox, wi, sx, xa, xb, wxa, wxb);
+    float acc[N], t[N];
+    ldv<T>(a, ((img * hi + ya) * wi + xa) * (size_t)aC + a0 + ch, t);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = wya * wxa * t[q];
+    ldv<T>(a, ((img * hi + ya) * wi + xb) * (size_t)aC + a0 + ch, t);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] += wya * wxb * t[q];
+    ldv<T>(a, ((img * hi + yb) * wi + xa) * (size_t)aC + a0 + ch, t);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] += wyb * wxa * t[q];
+    ldv<T>(a, ((img * hi + yb) * wi + xb) * (size_t)aC + a0 + ch, t);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] += wyb * wxb * t[q];
+    stv<T>(b, ((img * ho + oy) * wo + ox) * (size_t)bC + b0 + ch, acc);
+  }
+}
+// backward as a deterministic gather: input pixel k collects every output pixel whose two taps include k
+__device__ __forceinline__ int resize_bwd_range(int k, int in, int out, float scale, int& lo) {
+  // outputs d with src(d) in (k-1, k+1): d in ((k-0.5)/scale - 0.5 - 1, (k+1.5)/scale - 0.5 + 1)
+  int l = (int)floorf(((float)k - 0.5f) / scale - 0.5f) - 1, h = (int)ceilf(((float)k + 1.5f) / scale - 0.5f) + 1;
+  if (k == 0) l = 0;   // clamped sources
+  if (l < 0) l = 0;
+  if (h > out - 1) h = out - 1;
+  lo = l;
+  return h;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const void* __restrict__ dy, int yC, int y0, void* dx, int xC, int x0, int n, int hi, int wi,
+                                                         int ho, int wo, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
+  const size_t total = (size_t)n * hi * wi * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    size_t p = i / cv;
+    const int x = (int)(p % wi); p /= wi;
+    const int y = (int)(p % hi);
+    const size_t img = p / hi;
+    int ylo, xlo;
+    const int yhi = resize_bwd_range(y, hi, ho, sy, ylo), xhi = resize_bwd_range(x, wi, wo, sx, xlo);
+    float acc[N], t[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int ya, yb; float wya, wyb;
+      resize_taps(oy, hi, sy, ya, yb, wya, wyb);
+      const float wy = (ya == y ? wya : 0.f) + (yb == y ? wyb : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int xa, xb; float wxa, wxb;
+        resize_taps(ox, wi, sx, xa, xb, wxa, wxb);
+        const float wx = (xa == x ? wxa : 0.f) + (xb == x ? wxb : 0.f);
+        if (wx == 0.f) continue;
+        ldv<T>(dy, ((img * ho + oy) * wo + ox) * (size_t)yC + y0 + ch, t);
+        const float ww = wy * wx;
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] += ww * t[q];
+      }
+    }
+    stv<T>(dx, ((img * hi + y) * wi + x) * (size_t)xC + x0 + ch, acc);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add_relu_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
+                                                       void* out, int oC, int o0, size_t npix, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float va[N], vb[N];
+    ldv<T>(a, p * aC + a0 + ch, va);
+    ldv<T>(b, p * bC + b0 + ch, vb);
+#pragma unroll
+    for (int q = 0; q < N; ++q) va[q] = fmaxf(va[q] + vb[q], 0.f);
+    stv<T>(out, p * oC + o0 + ch, va);
+  }
+}
+__global__ __launch_bounds__(256) void sigmoid_kernel(float* x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, float* out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = s[i]; out[i] = ds[i] * v * (1.f - v); }
+}
+// y[p][c] = gate[p] * x[p][c]
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const void* __restrict__ x, int xC, int x0, const float* __restrict__ gate, void* y, int yC, int y0,
+                                                       size_t npix, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float v[N];
+    ldv<T>(x, p * xC + x0 + ch, v);
+    const float gv = gate[p];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] *= gv;
+    stv<T>(y, p * yC + y0 + ch, v);
+  }
+}
+// dx[p][c] = gate[p] * dy[p][c] ; dgate[p] = sum_c dy[p][c] * x[p][c]   (c/N lanes of a wave per pixel, c/N a power of two <= 64)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const void* __restrict__ x, int xC, int x0, const float* __restrict__ gate,
+                                                       const void* __restrict__ dy, int dC, int d0, void* dx, int oC, int o0, float* __restrict__ dgate,
+                                                       size_t npix, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;                       // lanes per pixel
+  const size_t total = npix * cv;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t iters = (total + stride - 1) / stride;
+  for (size_t it = 0; it < iters; ++it) {
+    const size_t i = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < total;
+    const int ch = ok ? (int)(i % cv) * N : 0;
+    const size_t p = ok ? i / cv : 0;
+    float vx[N], vd[N];
+    float part = 0.f;
+    if (ok) {
+      ldv<T>(x, p * xC + x0 + ch, vx);
+      ldv<T>(dy, p * dC + d0 + ch, vd);
+      const float gv = gate[p];
+#pragma unroll
+      for (int q = 0; q < N; ++q) { part += vd[q] * vx[q]; vd[q] *= gv; }
+      stv<T>(dx, p * oC + o0 + ch, vd);
+    }
+    for (int o = cv >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (ok && (i % cv) == 0) dgate[p] = part;
+  }
+}
+// BatchNorm2d.  Statistics: each block sums a pixel range for every channel -> partial[block][2][C]; the finish
+// kernel (one block) turns them into mean / invstd / (scale, shift), updates the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const void* __restrict__ x, int xC, int x0, const void* __restrict__ g, int gC, int g0,
+                                                         const float* __restrict__ save, size_t npix, int c, float* __restrict__ partial) {
+  // forward statistics (g == nullptr): sum x, sum x^2.  backward (g = dy): sum dy, sum dy * xhat (xhat from save)
+  __shared__ float sh[2][256];
+  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+  const int lanes = 256 / c > 0 ? 256 / c : 1;          // pixel lanes per channel (c <= 256)
+  const int ch = threadIdx.x % c, pl = threadIdx.x / c;
+  float s0 = 0.f, s1 = 0.f;
+  if (pl < lanes) {
+    const float mean = (g && save) ? save[ch] : 0.f, invstd = (g && save) ? save[c + ch] : 1.f;
+    for (size_t p = p0 + pl; p < p1; p += lanes) {
+      const float xv = ld<T>(x, p * xC + x0 + ch);
+      if (g) { const float dv = ld<T>(g, p * gC + g0 + ch); s0 += dv; s1 += dv * (xv - mean) * invstd; }
+      else { s0 += xv; s1 += xv * xv; }
+    }
+  }
+  sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x < c) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int l = 0; l < lanes; ++l) { a0 += sh[0][l * c + threadIdx.x]; a1 += sh[1][l * c + threadIdx.x]; }
+    partial[((size_t)blockIdx.x * 2 + 0) * c + threadIdx.x] = a0;
+    partial[((size_t)blockIdx.x * 2 + 1) * c + threadIdx.x] = a1;
+  }
+}
+__global__ __launch_bounds__(256) void bn_fwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                                                            int training, float* __restrict__ save) {
+  const int ch = threadIdx.x;
+  if (ch >= c) return;
+  float mean, var;
+  if (training) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * c + ch]; s1 += partial[((size_t)b * 2 + 1) * c + ch]; }
+    mean = s0 / npix;
+    var = fmaxf(s1 / npix - mean * mean, 0.f);
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * var * (npix / (npix - 1.f));
+  } else {
+    mean = running_mean[ch]; var = running_var[ch];
+  }
+  const float invstd = rsqrtf(var + eps);
+  const float sc = gamma[ch] * invstd;
+  save[ch] = mean; save[c + ch] = invstd; save[2 * c + ch] = sc; save[3 * c + ch] = beta[ch] - mean * sc;
+}
+// dx = dy*A + x*B + C0 per channel; coefficient triple + parameter gradients from the partial sums
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
+                                                            const float* __restrict__ save, float* dgamma, float* dbeta, float acc, float* __restrict__ coef) {
+  const int ch = threadIdx.x;
+  if (ch >= c) return;
+  float db = 0.f, dg = 0.f;
+  for (int b = 0; b < nblk; ++b) { db += partial[((size_t)b * 2 + 0) * c + ch]; dg += partial[((size_t)b * 2 + 1) * c + ch]; }
+  dgamma[ch] = dg + (acc != 0.f ? acc * dgamma[ch] : 0.f);
+  dbeta[ch] = db + (acc != 0.f ? acc * dbeta[ch] : 0.f);
+  const float mean = save[ch], invstd = save[c + ch], gi = gamma[ch] * invstd;
+  coef[ch] = gi;                                              // A
+  coef[c + ch] = -gi * invstd * dg / npix;                    // B
+  coef[2 * c + ch] = gi * (-db / npix + mean * invstd * dg / npix);  // C0
+}
+// out = a*ca[c] + b*cb[c] + c0[c]  (b, cb optional): BatchNorm apply (forward: a=x, ca=scale, c0=shift) and backward
+template <typename T>
+__global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
+                                                          void* out, int oC, int o0, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                          const float* __restrict__ c0, size_t npix, int c) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const size_t total = npix * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cv) * N;
+    const size_t p = i / cv;
+    float va[N], vb[N];
+    ldv<T>(a, p * aC + a0 + ch, va);
+    if (b) ldv<T>(b, p * bC + b0 + ch, vb);
+#pragma unroll
+    for (int q = 0; q < N; ++q) va[q] = va[q] * ca[ch + q] + (b ? vb[q] * cb[ch + q] : 0.f) + c0[ch + q];
+    stv<T>(out, p * oC + o0 + ch, va);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 8192) {
   size_t g = (total + block - 1) / block;
@@ -737,6 +982,107 @@ int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   SRGANFD_LAUNCH(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2),
                      grad_scale, ema_decay, ema_mode);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+static bool vec_ok(int dtype, int c, std::initializer_list<srganfd_view> vs) {
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  if (c % vn) return false;
+  for (const auto& v : vs)
+    if (v.ptr && (v.c0 % vn || v.cstride % vn || ((uintptr_t)v.ptr & 15))) return false;
+  return true;
+}
+int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s) {
+  if (!a.ptr || !b.ptr || !vec_ok(dtype, c, {a, b})) return set_err(SRGANFD_EINVAL, "resize_bilinear: views must be 16-byte aligned channel multiples");
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  if (!bwd) {
+    const size_t total = (size_t)n * ho * wo * c / vn;
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(resize_fwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c),
+               SRGANFD_LAUNCH(resize_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
+  } else {
+    const size_t total = (size_t)n * hi * wi * c / vn;
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(resize_bwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c),
+               SRGANFD_LAUNCH(resize_bwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
+  }
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s) {
+  if (!a.ptr || !b.ptr || !out.ptr || !vec_ok(dtype, c, {a, b, out})) return set_err(SRGANFD_EINVAL, "add_relu: bad views");
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(add_relu_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c),
+             SRGANFD_LAUNCH(add_relu_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int sigmoid_impl(float* x, size_t n, hipStream_t s) {
+  if (!x) return set_err(SRGANFD_EINVAL, "sigmoid: null");
+  SRGANFD_LAUNCH(sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hipStream_t s) {
+  if (!ds || !sg || !out) return set_err(SRGANFD_EINVAL, "sigmoid_bwd: null");
+  SRGANFD_LAUNCH(sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, ds, sg, out, n);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s) {
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int cv = c / vn;
+  if (!x.ptr || !gate || !y.ptr || !vec_ok(dtype, c, {x, y, dx}) || cv > 64 || (cv & (cv - 1))) return set_err(SRGANFD_EINVAL, "gate_mul: bad args");
+  if (!bwd) {
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(gate_fwd_kernel<bf16_t>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, npix, c),
+               SRGANFD_LAUNCH(gate_fwd_kernel<float>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, npix, c));
+  } else {
+    if (!dx.ptr || !dgate) return set_err(SRGANFD_EINVAL, "gate_mul(bwd): null");
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(gate_bwd_kernel<bf16_t>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, dx.ptr, dx.cstride, dx.c0, dgate, npix, c),
+               SRGANFD_LAUNCH(gate_bwd_kernel<float>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, dx.ptr, dx.cstride, dx.c0, dgate, npix, c));
+  }
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+static constexpr int kBnBlocks = 256;   // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
+int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
+                       float momentum, float eps, int training, float* save, float* ws, hipStream_t s) {
+  if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, y}))
+    return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (channels <= 256, 16-byte aligned views)");
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  if (training) {
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws),
+               SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws));
+  }
+  SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, beta, rm, rv, momentum, eps, training, save);
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
+                            y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c),
+             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
+                            y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
+                       float* dgamma, float* dbeta, float acc, float* ws, hipStream_t s) {
+  if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, dy, dx}))
+    return set_err(SRGANFD_EINVAL, "batchnorm_bwd: bad args");
+  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  float* coef = ws + (size_t)kBnBlocks * 2 * c;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws),
+             SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws));
+  SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, save, dgamma, dbeta, acc, coef);
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
+                            dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c),
+             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
+                            dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

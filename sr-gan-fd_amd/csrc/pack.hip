@@ -38,10 +38,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const srganfd_pack_job* __res
         int KTs = KT;
         if (!S.transposed) { co = n + S.co_off; ci = kk + S.ci_off; t = tap; }
         else if (S.transposed == 1) { co = kk + S.co_off; ci = n + S.ci_off; t = KT - 1 - tap; }
-        else {  // parity class of the 4x4 stride-2 data gradient: this operand has 2x2 taps, the source 4x4
+        else if (S.transposed < 6) {  // parity class of the 4x4 stride-2 data gradient: this operand has 2x2 taps, the source 4x4
           const int py = (S.transposed - 2) >> 1, px = (S.transposed - 2) & 1, ta = tap >> 1, tb = tap & 1;
           const int ty = py ? 2 - 2 * ta : 3 - 2 * ta, tx = px ? 2 - 2 * tb : 3 - 2 * tb;
           co = kk + S.co_off; ci = n + S.ci_off; t = ty * 4 + tx; KTs = 16;
+        } else if (S.transposed < 10) {  // parity class of a 3x3 stride-2 pad-1 data gradient as a 2x2-tap operand (pad 0):
+          // even output rows see only kernel row 1 (tap a=0), odd rows see kernel rows 2 (a=0) and 0 (a=1)
+          const int py = (S.transposed - 6) >> 1, px = (S.transposed - 6) & 1, ta = tap >> 1, tb = tap & 1;
+          const int ty = py ? (ta ? 0 : 2) : (ta ? -1 : 1), tx = px ? (tb ? 0 : 2) : (tb ? -1 : 1);
+          co = kk + S.co_off; ci = n + S.ci_off; KTs = 9;
+          t = ty * 3 + tx;
+          if (ty < 0 || tx < 0) co = S.co_src;   // unused tap -> zero
+        } else {  // 10 + 2a + b: tap (a,b) of a 2x2 stride-2 conv as a 1x1 data-gradient operand
+          const int ab = S.transposed - 10;
+          co = kk + S.co_off; ci = n + S.ci_off; t = ab; KTs = 4;
         }
         if (co < S.co_src && ci < S.ci_src) {
           v = params[S.src_off + ((long long)co * S.ci_src + ci) * KTs + t] * S.scale;

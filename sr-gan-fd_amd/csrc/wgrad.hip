@@ -338,7 +338,8 @@ struct PlanBuild {
 
 static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs, PlanBuild& pb) {
   if (!s || !convs || s->nconv <= 0) return set_err(SRGANFD_EINVAL, "wgrad: null shape/convs");
-  if (!((s->ksize == 3 && s->stride == 1) || (s->ksize == 4 && s->stride == 2) || (s->ksize == 1 && s->stride == 1)))
+  if (!((s->ksize == 3 && s->stride == 1) || (s->ksize == 4 && s->stride == 2) || (s->ksize == 1 && s->stride == 1) ||
+        (s->ksize == 3 && s->stride == 2) || (s->ksize == 2 && s->stride == 2)))
     return set_err(SRGANFD_EINVAL, "wgrad: unsupported ksize=%d stride=%d", s->ksize, s->stride);
   const int hl = s->h_in << (s->up ? 1 : 0), wl = s->w_in << (s->up ? 1 : 0);
   if ((hl + 2 * s->pad - s->ksize) / s->stride + 1 != s->h_out || (wl + 2 * s->pad - s->ksize) / s->stride + 1 != s->w_out)
@@ -362,7 +363,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.ntiles = s->n * H.tiles_x * H.tiles_y;
   struct Bucket { int xb, yb; std::vector<int> tasks; std::vector<int> ci_abs, co_abs; };
   std::vector<Bucket> buckets;
-  const int xdiv = (s->ksize == 4) ? 1 : 2;
+  const int xdiv = (s->stride == 2) ? 1 : 2;   // stride-2 patches are 4x larger: one 32-channel x unit per workgroup
   for (int c = 0; c < s->nconv; ++c) {
     const srganfd_wgrad_conv& cv = convs[c];
     if (cv.cin <= 0 || cv.cin % 32 || cv.cout <= 0 || cv.cout % 32 || cv.ci_lo % 32 || cv.co_lo % 32 || cv.ci_lo < 0 || cv.co_lo < 0 ||
@@ -502,8 +503,10 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.dbg = g_debug; k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
   const bool bf = H.dtype == SRGANFD_BF16;
-  if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
+  if (H.ks == 3 && H.stride == 1) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
+  else if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 2>(H, k, stream) : launch_wgrad<float, 3, 2>(H, k, stream);
   else if (H.ks == 4) rc = bf ? launch_wgrad<bf16_t, 4, 2>(H, k, stream) : launch_wgrad<float, 4, 2>(H, k, stream);
+  else if (H.ks == 2) rc = bf ? launch_wgrad<bf16_t, 2, 2>(H, k, stream) : launch_wgrad<float, 2, 2>(H, k, stream);
   else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
   if (rc != SRGANFD_OK) return rc;
   const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);

@@ -1,0 +1,142 @@
+"""GPU parity of the A-ESRGAN attention U-Net discriminator (BASELINE config 5 discriminator) and the kernels
+it adds (stride-2 3x3 / 2x2 convs, padded 1x1 conv, general bilinear resize, BatchNorm, attention gate)
+against vectors captured from the reference (A-ESRGAN/model.py:228-345)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import checksum, load_golden, table
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _rel_l2(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("sizes", [((10, 10), (8, 8)), ((10, 10), (32, 32)), ((6, 10), (16, 24)), ((8, 8), (16, 16))])
+def test_resize_bilinear(sizes):
+    from sr_gan_fd_amd import _abi as A
+    (hi, wi), (ho, wo) = sizes
+    torch.manual_seed(0)
+    n, c = 2, 32
+    x = torch.randn(n, c, hi, wi, requires_grad=True)
+    y = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    L, st = A.lib(), A.stream_ptr()
+    xa = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    yb = torch.empty(n, ho, wo, c, device="cuda")
+    A.check(L.srganfd_resize_bilinear(0, A.view(xa), A.view(yb), A.F32, n, hi, wi, ho, wo, c, st))
+    dya = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dxb = torch.empty(n, hi, wi, c, device="cuda")
+    A.check(L.srganfd_resize_bilinear(1, A.view(dya), A.view(dxb), A.F32, n, hi, wi, ho, wo, c, st))
+    torch.cuda.synchronize()
+    assert _rel(yb.permute(0, 3, 1, 2), y) < 1e-5
+    assert _rel(dxb.permute(0, 3, 1, 2), x.grad) < 1e-5
+
+
+def test_batchnorm_and_gate():
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(1)
+    n, c, h, w = 2, 64, 12, 20
+    L, st = A.lib(), A.stream_ptr()
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(n, c, h, w, requires_grad=True)
+    y = bn(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xa = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    yb, dxb = torch.empty_like(xa), torch.empty_like(xa)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    save, ws = torch.empty(4 * c, device="cuda"), torch.empty(512 * 256 + 768, device="cuda")
+    gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    A.check(L.srganfd_batchnorm_fwd(A.view(xa), A.view(yb), A.F32, n * h * w, c, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                    0.1, 1e-5, 1, save.data_ptr(), ws.data_ptr(), st))
+    dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    dya = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    A.check(L.srganfd_batchnorm_bwd(A.view(xa), A.view(dya), A.view(dxb), A.F32, n * h * w, c, gam.data_ptr(), save.data_ptr(), dg.data_ptr(),
+                                    db.data_ptr(), 0.0, ws.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert _rel(yb.permute(0, 3, 1, 2), y) < 1e-5
+    assert _rel(rm, bn.running_mean) < 1e-5 and _rel(rv, bn.running_var) < 1e-5
+    assert _rel(dxb.permute(0, 3, 1, 2), x.grad) < 1e-4
+    assert _rel(dg, bn.weight.grad) < 1e-4 and _rel(db, bn.bias.grad) < 1e-4
+    # gate
+    xg = torch.randn(n, c, h, w, requires_grad=True)
+    g = torch.rand(n, 1, h, w, requires_grad=True)
+    yy = g.expand_as(xg) * xg
+    yy.backward(dy)
+    xa = xg.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    ga = g.detach().reshape(-1).cuda()
+    yb = torch.empty_like(xa)
+    A.check(L.srganfd_gate_mul(0, A.view(xa), ga.data_ptr(), A.view(yb), A.NULL_VIEW, None, A.F32, n * h * w, c, st))
+    dgate = torch.empty(n * h * w, device="cuda")
+    A.check(L.srganfd_gate_mul(1, A.view(xa), ga.data_ptr(), A.view(dya), A.view(dxb), dgate.data_ptr(), A.F32, n * h * w, c, st))
+    torch.cuda.synchronize()
+    assert _rel(yb.permute(0, 3, 1, 2), yy) < 1e-6
+    assert _rel(dxb.permute(0, 3, 1, 2), xg.grad) < 1e-6
+    assert _rel(dgate.view(n, 1, h, w), g.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aesrgan_discriminator(golden_dir, dtype):
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "aesrgan_discriminator.npz")
+    f32 = dtype == torch.float32
+    torch.manual_seed(0)
+    d = M.UNetDiscriminatorAesrgan(3)
+    d.compute_dtype = dtype
+    d.cuda().train()
+    x = torch.tensor(g["x"]).cuda()
+    for it in range(2):
+        logits = d(x)
+        e = _rel(logits, g[f"train{it}_logits"])
+        print(f"A-ESRGAN D {dtype} train fwd {it}: logits err {e:.2e}, attention-map err {_rel(d.ly3, g[f'train{it}_attn3']):.2e}")
+        assert e < (1e-3 if f32 else 5e-2)
+        assert _rel(d.ly3, g[f"train{it}_attn3"]) < (1e-3 if f32 else 5e-2)
+        sd = d.state_dict()
+        for k, want in table(g, f"train{it}_statesum").items():
+            tol = 1e-3 if (f32 or k.endswith(("_u", "_v"))) else 3e-2     # BN statistics see bf16 activations
+            assert np.allclose(checksum(sd[k]), want, rtol=tol, atol=tol * abs(want[1]) + 1e-7), f"state {k}: {checksum(sd[k])} vs {want}"
+    assert int(d.attn_1.W[1].num_batches_tracked) == 2
+    loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    assert abs(loss.item() - float(g["bce_ones"])) < (1e-3 if f32 else 5e-2)
+    loss.backward()
+    named = dict(d.named_parameters())
+    worst = 0.0
+    for k in ("conv0.weight", "conv9.weight", "conv9.bias", "attn_1.W.1.weight", "attn_1.W.1.bias", "attn_3.psi.weight",
+              "attn_2.theta.weight", "attn_3.phi.bias", "gating.weight_orig"):
+        e = _rel(named[k].grad, g[f"grad/{k}"])
+        worst = max(worst, e)
+        assert e < (2e-3 if f32 else 2e-1), f"grad {k}: {e:.2e}"
+    print(f"A-ESRGAN D {dtype}: worst sampled grad err {worst:.2e}")
+    if f32:
+        for k, want in table(g, "gsum").items():
+            got = checksum(named[k].grad)
+            assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * abs(want[1]) + 1e-6), f"grad checksum {k}: {got} vs {want}"
+    d.eval()
+    with torch.no_grad():
+        assert _rel(d(x), g["eval_logits"]) < (1e-3 if f32 else 5e-2)
+    d.train()
+    for p in d.parameters():
+        p.requires_grad = False
+    xin = x.clone().requires_grad_(True)
+    lg = d(xin)
+    assert _rel(lg, g["train2_logits"]) < (1e-3 if f32 else 5e-2)
+    F.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    e, e2 = _rel(xin.grad, g["train2_dx"]), _rel_l2(xin.grad, g["train2_dx"])
+    print(f"A-ESRGAN D {dtype}: input-gradient max err {e:.2e}, L2 err {e2:.2e}")
+    assert (e < 2e-3) if f32 else (e2 < 1.5e-1)
