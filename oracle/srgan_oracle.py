@@ -321,12 +321,14 @@ def g_only_step(G: Params, opt: AdamState, lr_img: Tensor, gt: Tensor, *, upscal
 def gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: Tensor, gt: Tensor, *,
              upscale: int, g_lr: float, d_lr: float, betas: Tuple[float, float], eps: float,
              pixel_weight: float, content_weight: float, adversarial_weight: float,
-             content_fn=None, train_generator: bool = True) -> Dict[str, float]:
-    """One GAN iteration -- BSRGAN/train_bsrgan.py:387-483, exact order:
+             content_fn=None, train_generator: bool = True, d_forward=None) -> Dict[str, float]:
+    """One GAN iteration -- BSRGAN/train_bsrgan.py:387-483 (same statements in A-ESRGAN/train_aesrgan.py:396-483;
+    ``d_forward(x, D, training=True)`` selects the discriminator, default DiscriminatorUNet), exact order:
     D(gt) fwd+bwd, G fwd, D(sr.detach()) fwd+bwd (accumulate), D step, freeze D, pixel/content/adv
     with the UPDATED D (SN u/v advance a third time), G bwd + step.  content_fn(sr, gt) returns the
     detached (1,5) tensor or None (-> 0)."""
     gn, dn = g_param_names(G), d_param_names(D)
+    discriminator_unet_forward = d_forward or globals()["discriminator_unet_forward"]
     _leafify(D, dn)
     _leafify(G, gn)
     # ---- D step ----

@@ -17,6 +17,7 @@ from torch import Tensor
 
 from . import _abi as A
 from .engine import generator_engine
+from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
 from .parallel import allreduce_sum_
 from .trainer import FlatAdamEMA
@@ -28,7 +29,10 @@ class GanTrainer:
                  content_weight: float = 1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None):
         # defaults = BSRGAN/bsrgan_config.py:137-159
         self.g, self.d, self.content = g_model, d_model, content_criterion
-        self.ge, self.de = generator_engine(g_model), discriminator_engine(d_model)
+        # either discriminator of the reference: DiscriminatorUNet (BSRGAN / Real-ESRGAN) or the A-ESRGAN attention U-Net
+        # (A-ESRGAN/train_aesrgan.py:396-483 runs the same statements around it); both engines share one interface
+        d_engine = aesrgan_engine if type(d_model).__name__ == "UNetDiscriminatorAesrgan" else discriminator_engine
+        self.ge, self.de = generator_engine(g_model), d_engine(d_model)
         dev = next(g_model.parameters()).device
         self.dev = dev
         self.g_opt = FlatAdamEMA(self.ge.fp.sync(dev), g_lr, betas, eps, weight_decay, ema_decay)

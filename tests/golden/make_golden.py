@@ -192,22 +192,19 @@ def gold_discriminator(MB):
     save("discriminator.npz", **out)
 
 
-def gold_gan_steps(MB):
-    """Two iterations of BSRGAN/train_bsrgan.py:387-483 with the reference modules, torch.optim.Adam,
-    AveragedModel and an (inert on CPU) GradScaler; content loss stubbed to zeros (no VGG weights)."""
+def _gan_iterations(d, g, fname, *, g_lr, d_lr, pixel_w, adv_w, d_probe):
+    """Two iterations of the reference GAN loop (BSRGAN/train_bsrgan.py:387-483; identical statements in
+    A-ESRGAN/train_aesrgan.py:396-483) around reference modules, torch.optim.Adam, AveragedModel and an (inert on
+    CPU) GradScaler; content loss stubbed to zeros (no VGG weights)."""
     from torch.optim.swa_utils import AveragedModel
     out = {}
-    torch.manual_seed(0)
-    d = MB.discriminator_unet(in_channels=3, out_channels=1, channels=64)
-    g = MB.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
-    scaled_init(g, 3.0, 0.5)
     decay = 0.999
     ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - decay) * a + decay * p)
-    d_opt = torch.optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)
-    g_opt = torch.optim.Adam(g.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
+    d_opt = torch.optim.Adam(d.parameters(), d_lr, (0.9, 0.999), 1e-4, 0.0)
+    g_opt = torch.optim.Adam(g.parameters(), g_lr, (0.9, 0.999), 1e-4, 0.0)
     bce = torch.nn.BCEWithLogitsLoss()
     l1 = torch.nn.L1Loss()
-    pw, cw, aw = torch.Tensor([20.0]), torch.Tensor([1.0]), torch.Tensor([0.5])
+    pw, cw, aw = torch.Tensor([pixel_w]), torch.Tensor([1.0]), torch.Tensor([adv_w])
     d.train()
     g.train()
     B, h = 2, 16
@@ -253,8 +250,27 @@ def gold_gan_steps(MB):
         out[f"it{it}_wsum_d"] = sd_checksums(d.state_dict())
         out[f"it{it}_wsum_ema"] = sd_checksums(ema.state_dict())
         out[f"it{it}_g_conv4_bias"] = np_(g.conv4.bias)
-        out[f"it{it}_d_conv4_weight"] = np_(d.conv4.weight)
-    save("gan_steps.npz", **out)
+        out[f"it{it}_d_probe"] = np_(dict(d.named_parameters())[d_probe])
+    save(fname, **out)
+
+
+def gold_gan_steps(MB):
+    torch.manual_seed(0)
+    d = MB.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    g = MB.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(g, 3.0, 0.5)
+    # bsrgan_config.py:137-151
+    _gan_iterations(d, g, "gan_steps.npz", g_lr=8e-5, d_lr=2e-4, pixel_w=20.0, adv_w=0.5, d_probe="conv4.weight")
+
+
+def gold_aesrgan_gan_steps(MA):
+    """BASELINE config 5 pairing: RRDBNet x4 generator (A-ESRGAN/model.py:479-553) + attention U-Net discriminator."""
+    torch.manual_seed(0)
+    d = MA.uNetDiscriminatorAesrgan()
+    g = MA.BSRGAN(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2, upscale_factor=4)
+    scaled_init(g, 3.0, 0.5)
+    # aesrgan_config.py:137-155
+    _gan_iterations(d, g, "aesrgan_gan_steps.npz", g_lr=5e-5, d_lr=1e-5, pixel_w=10.0, adv_w=0.1, d_probe="conv9.weight")
 
 
 def gold_g_only_steps(MB, ME):
@@ -340,7 +356,9 @@ def main():
     gold_discriminator(MB)
     gold_gan_steps(MB)
     gold_g_only_steps(MB, ME)
-    gold_aesrgan_discriminator(load_ref("A-ESRGAN"))
+    MA = load_ref("A-ESRGAN")
+    gold_aesrgan_discriminator(MA)
+    gold_aesrgan_gan_steps(MA)
 
 
 if __name__ == "__main__":

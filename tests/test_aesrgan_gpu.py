@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import checksum, load_golden, table
+from tests.util import checksum, load_golden, scaled_init, table
 
 pytestmark = pytest.mark.gpu
 
@@ -151,3 +151,37 @@ def test_aesrgan_discriminator(golden_dir, dtype):
         assert e2 < 1e-3 and frac < 5e-3 and e < 2e-2
     else:
         assert e2 < 1.5e-1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aesrgan_gan_steps_fused_trainer(golden_dir, dtype):
+    """GanTrainer.step with the attention U-Net discriminator == two iterations of A-ESRGAN/train_aesrgan.py:396-483
+    (golden captured from the reference modules; content loss stubbed to 0; aesrgan_config.py:137-155 hyper-parameters)"""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    g = load_golden(golden_dir, "aesrgan_gan_steps.npz")
+    f32 = dtype == torch.float32
+    torch.manual_seed(0)
+    d = M.uNetDiscriminatorAesrgan()
+    gen = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(gen, 3.0, 0.5)
+    d.compute_dtype = gen.compute_dtype = dtype
+    gen.cuda().train()
+    d.cuda().train()
+    tr = GanTrainer(gen, d, None, g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1)
+    for it in range(2):
+        s = tr.step(torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()).cpu().numpy()
+        want = g[f"it{it}_scalars"]  # d_loss, pixel, content, adv, D(gt), D(sr)
+        got = [s[0] + s[1], s[2], 0.0, s[3], s[4], s[5]]
+        print(f"A-ESRGAN GAN {dtype} it{it}: got {got} want {list(want)}")
+        assert np.allclose(got, want, rtol=1e-3 if f32 else 3e-2, atol=1e-5)
+        assert _rel(tr.sr, g[f"it{it}_sr"]) < (1e-3 if f32 else 3e-2)
+        if not f32:
+            continue
+        assert _rel(gen.conv4.bias, g[f"it{it}_g_conv4_bias"]) < 1e-3
+        assert _rel(d.conv9.weight, g[f"it{it}_d_probe"]) < 1e-3
+        # iteration 1 carries the LeakyReLU-mask sensitivity measured in tests/test_oracle_golden.py::test_aesrgan_gan_steps
+        at = 2e-4 if it == 0 else 2e-2
+        for sd, key in ((gen.state_dict(), f"it{it}_wsum_g"), (d.state_dict(), f"it{it}_wsum_d")):
+            for k, want_c in table(g, key).items():
+                assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=at * abs(want_c[1]) + 1e-9), f"{key} {k}: {checksum(sd[k])} vs {want_c}"

@@ -174,7 +174,7 @@ def test_gan_steps_fused_trainer(golden_dir):
         assert np.allclose(got, want, rtol=1e-3, atol=1e-5)
         assert _rel(tr.sr, g[f"it{it}_sr"]) < 1e-3
         assert _rel(gen.conv4.bias, g[f"it{it}_g_conv4_bias"]) < 1e-3
-        assert _rel(d.conv4.weight, g[f"it{it}_d_conv4_weight"]) < 1e-3
+        assert _rel(d.conv4.weight, g[f"it{it}_d_probe"]) < 1e-3
         for sd, key in ((gen.state_dict(), f"it{it}_wsum_g"), (d.state_dict(), f"it{it}_wsum_d")):
             for k, want_c in table(g, key).items():
                 assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=2e-4 * abs(want_c[1])), f"{key} {k}"
