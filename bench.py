@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- SR training images/sec of the MI355X-native hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload g_only|gan] [--batch B] [--lr-size S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload g_only|gan|aesrgan_gan] [--batch B] [--lr-size S]
 
 One "step" = one training iteration of the reference (``train()`` body) on one synthetic batch that is
 already resident in HBM.  Default workload = BASELINE.json configs[1]: BSRGAN RRDBNet x4 (23 RRDB)
 generator-only, L1 pixel loss, batch 32 per GPU, 128x128 -> 512x512, bf16 MFMA with fp32 master
 weights, Adam + EMA inside the timed region.  N > 1: one process per GPU (torchrun), weak scaling
-(batch 32 per GPU), one RCCL all-reduce of the flat gradient per step.
+(batch 32 per GPU), one RCCL all-reduce of the flat gradient per step.  ``--workload gan`` = configs[2]/[3] (full GAN
+step, U-Net discriminator + VGG-19 content loss); ``--workload aesrgan_gan`` = configs[4] per GPU (RRDBNet + A-ESRGAN
+attention U-Net discriminator, 192 -> 768, aesrgan_config.py hyper-parameters).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     -- dominant kernel, achieved TFLOP/s from HIP-event brackets around its launches in the
@@ -26,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # algorithmic FLOP per image, SURVEY.md 8(d): 1 MAC = 2 FLOP, backward = 2x forward
-FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9}
+FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9}
+BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192}     # the input size those figures are quoted at
 
 
 # HBM-side bytes per launch of the dominant kernels, from separate `rocprofv3 --pmc TCC_EA0_RDREQ_sum
@@ -77,9 +80,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan"])
+    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan", "aesrgan_gan"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--lr-size", type=int, default=128)
+    ap.add_argument("--lr-size", type=int, default=0, help="LR image side (default 128; 192 for aesrgan_gan)")
     ap.add_argument("--num-rrdb", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -109,7 +112,10 @@ def main():
     if args.debug_flags:
         from sr_gan_fd_amd import _abi
         _abi.lib().srganfd_set_debug(args.debug_flags)
+    if not args.lr_size:
+        args.lr_size = BASE_LR_SIZE[args.workload]
     B, h = args.batch, args.lr_size
+    flop_img = FLOP_PER_IMG[args.workload] * (h / BASE_LR_SIZE[args.workload]) ** 2 * (args.num_rrdb / 23.0 if args.workload == "g_only" else 1.0)
     torch.manual_seed(0)                      # identical weights on every rank (bsrgan_config.py:35-37 seeds at import)
     g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)
     g.compute_dtype = torch.bfloat16
@@ -120,12 +126,15 @@ def main():
         step_fn = trainer.step
     else:
         from sr_gan_fd_amd.gan import GanTrainer
-        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        aes = args.workload == "aesrgan_gan"
+        d = M.uNetDiscriminatorAesrgan() if aes else M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
         cl = M.ContentLoss(NODES, MEAN, STD)      # seeded random VGG-19 weights (no ImageNet download offline)
         d.compute_dtype = cl.compute_dtype = torch.bfloat16
         d.to(dev)
         cl.to(dev)
-        trainer = GanTrainer(g, d, cl, process_group=pg)
+        # bsrgan_config.py:137-151 defaults / aesrgan_config.py:137-155
+        kw = dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1) if aes else {}
+        trainer = GanTrainer(g, d, cl, process_group=pg, **kw)
         step_fn = trainer.step
 
     gen = torch.Generator(device=dev)
@@ -160,15 +169,16 @@ def main():
     value = B * world * args.steps / dt
 
     out = {
-        "metric": "SR training images/sec (128->512 x4, bf16)", "value": round(value, 3), "unit": "img/s",
+        "metric": "SR training images/sec (%d->%d x4, bf16)" % (h, 4 * h), "value": round(value, 3), "unit": "img/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": ("BSRGAN RRDBNet x4 generator-only (L1), 23 RRDB, batch %d/GPU, %d->%d" % (B, h, 4 * h))
-                   if args.workload == "g_only" else
-                   ("BSRGAN full GAN step (RRDBNet + U-Net D + VGG19 content), batch %d/GPU, %d->%d" % (B, h, 4 * h)),
+        "config": {"workload": {"g_only": "BSRGAN RRDBNet x4 generator-only (L1), %d RRDB, batch %d/GPU, %d->%d",
+                                "gan": "BSRGAN full GAN step (RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
+                                "aesrgan_gan": "A-ESRGAN full GAN step (RRDBNet %d RRDB + attention U-Net D + VGG19 content), batch %d/GPU, %d->%d",
+                                }[args.workload] % (args.num_rrdb, B, h, 4 * h),
                    "global_batch": B * world, "num_rrdb": args.num_rrdb, "parallelism": "dp%d" % world,
-                   "flop_per_image": FLOP_PER_IMG[args.workload]},
-        "step_tflops_per_gpu": round(value / world * FLOP_PER_IMG[args.workload] * (args.num_rrdb / 23.0) / 1e12, 2),
+                   "flop_per_image": flop_img},
+        "step_tflops_per_gpu": round(value / world * flop_img / 1e12, 2),
     }
     if rank == 0:
         if rec is not None:
@@ -198,9 +208,12 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     opt = O.AdamState(G, O.g_param_names(G))
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
     n_it = 9
-    if workload == "gan":
-        n_it = 4
-        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    d_forward, hp = None, dict(g_lr=8e-5, d_lr=2e-4, pixel_weight=20.0, adversarial_weight=0.5)
+    if workload != "g_only":
+        n_it = 4 if workload == "gan" else 3
+        if workload == "aesrgan_gan":
+            d_forward, hp = O.aesrgan_unet_forward, dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1)
+        d = M.uNetDiscriminatorAesrgan() if workload == "aesrgan_gan" else M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
         D = {k: v.detach().clone() for k, v in d.state_dict().items()}
         d_opt = O.AdamState(D, O.d_param_names(D))
         cl = M.ContentLoss(NODES, MEAN, STD)
@@ -212,8 +225,8 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
         if workload == "g_only":
             O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
         else:
-            O.gan_step(G, D, opt, d_opt, lr_img, gt, upscale=4, g_lr=8e-5, d_lr=2e-4, betas=(0.9, 0.999), eps=1e-4,
-                       pixel_weight=20.0, content_weight=1.0, adversarial_weight=0.5, content_fn=content_fn)
+            O.gan_step(G, D, opt, d_opt, lr_img, gt, upscale=4, betas=(0.9, 0.999), eps=1e-4, content_weight=1.0,
+                       content_fn=content_fn, d_forward=d_forward, **hp)
         times.append(time.perf_counter() - t0)
         log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
     t = min(times[1:])

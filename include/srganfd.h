@@ -226,7 +226,7 @@ int srganfd_sigmoid_bwd(const float* ds, const float* s, float* out, int64_t num
 /* attention gate y = gate[p] * x[p][c] (model.py:252).  bwd=1: y is dy; dx = gate * dy, dgate[p] = sum_c dy * x */
 int srganfd_gate_mul(int32_t bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate,
                      int32_t dtype, int64_t npix, int32_t c, void* stream);
-/* nn.BatchNorm2d (model.py:233).  save: 4*c floats [mean | invstd | scale | shift]; workspace: 512*c + 3*c floats.
+/* nn.BatchNorm2d (model.py:233).  save: 4*c floats [mean | invstd | scale | shift]; workspace: 2048*c + 3*c floats.
  * training=1: batch statistics, running stats updated with `momentum` (unbiased variance); 0: running stats. */
 int srganfd_batchnorm_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,

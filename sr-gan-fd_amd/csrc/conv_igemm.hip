@@ -122,7 +122,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   const int oy0 = ty * C::TH, ox0 = tx * C::TW;
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
-  const T* __restrict__ xg = (const T*)a.x;
+  // 64-bit per-image base (block-uniform, scalar registers) + 32-bit offsets inside the image (host-checked)
+  const T* __restrict__ xg = (const T*)a.x + (size_t)n * a.Hin * a.Win * a.xC;
 
   // per-thread source offsets (elements) of the X staging items; -1 = zero padding
   int xoff[C::XI];
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     const int py = pix / C::PC, px = pix % C::PC;
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !(a.dbg & 1);
-    xoff[i] = ok ? ((n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + a.x_c0 + c16 * C::E16 : -1;
+    xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + a.x_c0 + c16 * C::E16 : -1;
   }
   // LDS destination of staging item i = ldsx0 + i * (PIX_PER_I * PIXB): the swizzle term is i-invariant
   int ldsx0;
@@ -280,14 +281,14 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     constexpr int ITEMS = C::TH * 32 * CP;
     constexpr int EI = (ITEMS + NTHR - 1) / NTHR;
     const int cbase = nb * C::NB;
-    const int img = n * a.HoutF;
+    const size_t img = (size_t)n * a.HoutF * a.WoutF;   // pixels before this image (block-uniform)
 #pragma unroll 2
     for (int e = 0; e < EI; ++e) {
       const int item = tid + e * NTHR;
       const int pix = item / CP, ck = item % CP;
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (item < ITEMS && oy < a.Hout && ox < a.Wout) {
-        const int p = (img + oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;   // host guarantees 32-bit offsets
+        const int p = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;   // pixel inside the image: 32-bit offsets (host-checked)
         float v[C::E16];
         const f32x4* tp = (const f32x4*)(tile + pix * C::NB + ck * C::E16);
         {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
         }
         const int cch = cbase + ck * C::E16;
         auto load16 = [&](const void* base, int Cs, int c0, float* out) {
-          const T* src = (const T*)base + (p * Cs + c0 + cch);
+          const T* src = (const T*)base + img * Cs + (p * Cs + c0 + cch);
           if constexpr (sizeof(T) == 2) {
             const u32x4 raw = *(const u32x4*)src;
             const unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
           }
         };
         auto store16 = [&](void* base, int Cs, int c0, const float* vv) {
-          T* dstp = (T*)base + (p * Cs + c0 + cch);
+          T* dstp = (T*)base + img * Cs + (p * Cs + c0 + cch);
           if constexpr (sizeof(T) == 2) {
             u32x4 o;
             o[0] = (unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16);
@@ -433,12 +434,12 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   if (a->x.cstride % align || a->x.c0 % align) return set_err(SRGANFD_EINVAL, "conv2d: x view not 16-byte aligned");
   if (a->x.c0 + a->cin > a->x.cstride) return set_err(SRGANFD_EINVAL, "conv2d: x view exceeds buffer channels");
   if (a->y.c0 + a->cout_store > a->y.cstride) return set_err(SRGANFD_EINVAL, "conv2d: y view exceeds buffer channels");
-  if ((size_t)a->n * a->h_in * a->w_in * (size_t)a->x.cstride >= 0x7fffffffULL)
-    return set_err(SRGANFD_EINVAL, "conv2d: input too large for 32-bit element offsets");
-  const size_t opix = (size_t)a->n * (sub ? (size_t)a->out_h_full * a->out_w_full : (size_t)a->h_out * a->w_out);
+  if ((size_t)a->h_in * a->w_in * (size_t)a->x.cstride >= 0x7fffffffULL)
+    return set_err(SRGANFD_EINVAL, "conv2d: one input image is too large for 32-bit element offsets");
+  const size_t opix = sub ? (size_t)a->out_h_full * a->out_w_full : (size_t)a->h_out * a->w_out;   // per image
   auto fits = [&](const srganfd_view& v) { return !v.ptr || opix * (size_t)v.cstride < 0x7fffffffULL; };
   if (!fits(a->y) || !fits(a->y2) || !fits(a->r1) || !fits(a->r2) || !fits(a->mask))
-    return set_err(SRGANFD_EINVAL, "conv2d: output-side tensor too large for 32-bit element offsets");
+    return set_err(SRGANFD_EINVAL, "conv2d: one output-side image is too large for 32-bit element offsets");
   ConvK k;
   k.x = a->x.ptr; k.y = a->y.ptr; k.y2 = a->y2.ptr; k.y2C = a->y2.cstride; k.y2_c0 = a->y2.c0;
   k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;

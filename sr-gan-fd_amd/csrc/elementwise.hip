@@ -708,46 +708,89 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const void* __restrict__ 
     if (ok && (i % cv) == 0) dgate[p] = part;
   }
 }
-// BatchNorm2d.  Statistics: each block sums a pixel range for every channel -> partial[block][2][C]; the finish
-// kernel (one block) turns them into mean / invstd / (scale, shift), updates the running statistics.
+// BatchNorm2d.  Statistics: 16-byte loads, thread = one channel chunk, pixels strided over the grid (coalesced);
+// each block writes partial[block][2][C]; the finish kernel (one 1024-thread block) reduces them in a fixed order
+// (deterministic), turns them into mean / invstd / (scale, shift) and updates the running statistics.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const void* __restrict__ x, int xC, int x0, const void* __restrict__ g, int gC, int g0,
                                                          const float* __restrict__ save, size_t npix, int c, float* __restrict__ partial) {
   // forward statistics (g == nullptr): sum x, sum x^2.  backward (g = dy): sum dy, sum dy * xhat (xhat from save)
-  __shared__ float sh[2][256];
-  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-  const int lanes = 256 / c > 0 ? 256 / c : 1;          // pixel lanes per channel (c <= 256)
-  const int ch = threadIdx.x % c, pl = threadIdx.x / c;
-  float s0 = 0.f, s1 = 0.f;
-  if (pl < lanes) {
-    const float mean = (g && save) ? save[ch] : 0.f, invstd = (g && save) ? save[c + ch] : 1.f;
-    for (size_t p = p0 + pl; p < p1; p += lanes) {
-      const float xv = ld<T>(x, p * xC + x0 + ch);
-      if (g) { const float dv = ld<T>(g, p * gC + g0 + ch); s0 += dv; s1 += dv * (xv - mean) * invstd; }
-      else { s0 += xv; s1 += xv * xv; }
+  constexpr int N = VecN<T>::N;
+  __shared__ float sh[2][256 * N];
+  const int cv = c / N;                                 // 16-byte chunks per pixel (host: 256 % cv == 0)
+  const int lanes = 256 / cv;                           // pixels per block pass
+  const int chunk = threadIdx.x % cv, pl = threadIdx.x / cv, ch = chunk * N;
+  float s0[N], s1[N], mean[N], invstd[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    s0[q] = 0.f; s1[q] = 0.f;
+    mean[q] = (g && save) ? save[ch + q] : 0.f;
+    invstd[q] = (g && save) ? save[c + ch + q] : 1.f;
+  }
+  const size_t step = (size_t)gridDim.x * lanes;
+  if (g) {
+    for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += step) {
+      float xv[N], dv[N];
+      ldv<T>(x, p * xC + x0 + ch, xv);
+      ldv<T>(g, p * gC + g0 + ch, dv);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { s0[q] += dv[q]; s1[q] += dv[q] * (xv[q] - mean[q]) * invstd[q]; }
+    }
+  } else {
+    size_t p = (size_t)blockIdx.x * lanes + pl;
+    for (; p + step < npix; p += 2 * step) {            // two loads in flight
+      float xa[N], xb[N];
+      ldv<T>(x, p * xC + x0 + ch, xa);
+      ldv<T>(x, (p + step) * xC + x0 + ch, xb);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { s0[q] += xa[q] + xb[q]; s1[q] += xa[q] * xa[q] + xb[q] * xb[q]; }
+    }
+    if (p < npix) {
+      float xa[N];
+      ldv<T>(x, p * xC + x0 + ch, xa);
+#pragma unroll
+      for (int q = 0; q < N; ++q) { s0[q] += xa[q]; s1[q] += xa[q] * xa[q]; }
     }
   }
-  sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
+#pragma unroll
+  for (int q = 0; q < N; ++q) { sh[0][(pl * cv + chunk) * N + q] = s0[q]; sh[1][(pl * cv + chunk) * N + q] = s1[q]; }
   __syncthreads();
-  if (threadIdx.x < c) {
+  if ((int)threadIdx.x < c) {
     float a0 = 0.f, a1 = 0.f;
     for (int l = 0; l < lanes; ++l) { a0 += sh[0][l * c + threadIdx.x]; a1 += sh[1][l * c + threadIdx.x]; }
     partial[((size_t)blockIdx.x * 2 + 0) * c + threadIdx.x] = a0;
     partial[((size_t)blockIdx.x * 2 + 1) * c + threadIdx.x] = a1;
   }
 }
-__global__ __launch_bounds__(256) void bn_fwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-                                                            int training, float* __restrict__ save) {
+// sums partial[b][2][c] over b with all 1024 threads (fixed order), result in tot[2][256]
+__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ partial, int nblk, int c, float (*tot)[256]) {
+  __shared__ float sh[2][1024];
+  const int ch = threadIdx.x % c, l = threadIdx.x / c, lanes = 1024 / c;
+  float a0 = 0.f, a1 = 0.f;
+  if (l < lanes) {
+#pragma unroll 8
+    for (int b = l; b < nblk; b += lanes) { a0 += partial[((size_t)b * 2 + 0) * c + ch]; a1 += partial[((size_t)b * 2 + 1) * c + ch]; }
+  }
+  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  if ((int)threadIdx.x < c) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < lanes; ++k) { t0 += sh[0][k * c + threadIdx.x]; t1 += sh[1][k * c + threadIdx.x]; }
+    tot[0][threadIdx.x] = t0; tot[1][threadIdx.x] = t1;
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void bn_fwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                                                             int training, float* __restrict__ save) {
+  __shared__ float tot[2][256];
+  if (training) bn_reduce_partials(partial, nblk, c, tot);
   const int ch = threadIdx.x;
   if (ch >= c) return;
   float mean, var;
   if (training) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * c + ch]; s1 += partial[((size_t)b * 2 + 1) * c + ch]; }
-    mean = s0 / npix;
-    var = fmaxf(s1 / npix - mean * mean, 0.f);
+    mean = tot[0][ch] / npix;
+    var = fmaxf(tot[1][ch] / npix - mean * mean, 0.f);
     running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
     running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * var * (npix / (npix - 1.f));
   } else {
@@ -758,12 +801,13 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_kernel(const float* __restr
   save[ch] = mean; save[c + ch] = invstd; save[2 * c + ch] = sc; save[3 * c + ch] = beta[ch] - mean * sc;
 }
 // dx = dy*A + x*B + C0 per channel; coefficient triple + parameter gradients from the partial sums
-__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
-                                                            const float* __restrict__ save, float* dgamma, float* dbeta, float acc, float* __restrict__ coef) {
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
+                                                             const float* __restrict__ save, float* dgamma, float* dbeta, float acc, float* __restrict__ coef) {
+  __shared__ float tot[2][256];
+  bn_reduce_partials(partial, nblk, c, tot);
   const int ch = threadIdx.x;
   if (ch >= c) return;
-  float db = 0.f, dg = 0.f;
-  for (int b = 0; b < nblk; ++b) { db += partial[((size_t)b * 2 + 0) * c + ch]; dg += partial[((size_t)b * 2 + 1) * c + ch]; }
+  const float db = tot[0][ch], dg = tot[1][ch];
   dgamma[ch] = dg + (acc != 0.f ? acc * dgamma[ch] : 0.f);
   dbeta[ch] = db + (acc != 0.f ? acc * dbeta[ch] : 0.f);
   const float mean = save[ch], invstd = save[c + ch], gi = gamma[ch] * invstd;
@@ -771,22 +815,30 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
   coef[c + ch] = -gi * invstd * dg / npix;                    // B
   coef[2 * c + ch] = gi * (-db / npix + mean * invstd * dg / npix);  // C0
 }
-// out = a*ca[c] + b*cb[c] + c0[c]  (b, cb optional): BatchNorm apply (forward: a=x, ca=scale, c0=shift) and backward
+// out = a*ca[c] + b*cb[c] + c0[c]  (b, cb optional): BatchNorm apply (forward: a=x, ca=scale, c0=shift) and backward.
+// Thread = one fixed channel chunk (coefficients live in registers), pixels strided over the grid.
 template <typename T>
 __global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
                                                           void* out, int oC, int o0, const float* __restrict__ ca, const float* __restrict__ cb,
                                                           const float* __restrict__ c0, size_t npix, int c) {
   constexpr int N = VecN<T>::N;
-  const int cv = c / N;
-  const size_t total = npix * cv;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = (int)(i % cv) * N;
-    const size_t p = i / cv;
+  const int cv = c / N, lanes = 256 / cv;               // host: 256 % cv == 0
+  const int ch = (threadIdx.x % cv) * N, pl = threadIdx.x / cv;
+  float fa[N], fb[N], f0[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) { fa[q] = ca[ch + q]; fb[q] = b ? cb[ch + q] : 0.f; f0[q] = c0[ch + q]; }
+  const size_t step = (size_t)gridDim.x * lanes;
+  for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += step) {
     float va[N], vb[N];
     ldv<T>(a, p * aC + a0 + ch, va);
-    if (b) ldv<T>(b, p * bC + b0 + ch, vb);
+    if (b) {
+      ldv<T>(b, p * bC + b0 + ch, vb);
 #pragma unroll
-    for (int q = 0; q < N; ++q) va[q] = va[q] * ca[ch + q] + (b ? vb[q] * cb[ch + q] : 0.f) + c0[ch + q];
+      for (int q = 0; q < N; ++q) va[q] = va[q] * fa[q] + vb[q] * fb[q] + f0[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < N; ++q) va[q] = va[q] * fa[q] + f0[q];
+    }
     stv<T>(out, p * oC + o0 + ch, va);
   }
 }
@@ -1048,40 +1100,42 @@ int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, sr
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
-static constexpr int kBnBlocks = 256;   // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
+static constexpr int kBnBlocks = 1024;  // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
+static inline bool bn_chunks_ok(int dtype, int c) { const int cv = c / (dtype == SRGANFD_BF16 ? 8 : 4); return cv > 0 && 256 % cv == 0; }
+static inline unsigned bn_grid(size_t npix, int dtype, int c) { const int lanes = 256 / (c / (dtype == SRGANFD_BF16 ? 8 : 4)); return grid_for((npix + lanes - 1) / lanes, 1, 16384); }
 int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
                        float momentum, float eps, int training, float* save, float* ws, hipStream_t s) {
-  if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, y}))
-    return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (channels <= 256, 16-byte aligned views)");
+  if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, y}) || !bn_chunks_ok(dtype, c))
+    return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (channels <= 256 and a power-of-two number of 16-byte chunks, aligned views)");
   const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
   if (training) {
     DISPATCH_T(dtype,
                SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws),
                SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws));
   }
-  SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, beta, rm, rv, momentum, eps, training, save);
+  SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, beta, rm, rv, momentum, eps, training, save);
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
+             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
                             y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c),
-             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
+             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
                             y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
                        float* dgamma, float* dbeta, float acc, float* ws, hipStream_t s) {
-  if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, dy, dx}))
+  if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, dy, dx}) || !bn_chunks_ok(dtype, c))
     return set_err(SRGANFD_EINVAL, "batchnorm_bwd: bad args");
   const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
   float* coef = ws + (size_t)kBnBlocks * 2 * c;
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws),
              SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws));
-  SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, save, dgamma, dbeta, acc, coef);
+  SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, save, dgamma, dbeta, acc, coef);
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
+             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
                             dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c),
-             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
+             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
                             dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
       if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-        v = *(const u32x4*)(xg + (((n * a.Hin + (gy >> a.up)) * a.Win + (gx >> a.up)) * a.xC + c16 * E16));   // 32-bit offsets (host-checked)
+        v = *(const u32x4*)(xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + c16 * E16));   // 64-bit image base + 32-bit offset (host-checked)
     }
     return v;
   };
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     if (item < yItems && !(a.dbg & 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (((n * a.Hout + oy) * a.Wout + ox) * a.dyC + c16 * E16));
+      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dyC + c16 * E16));
     }
     return v;
   };
@@ -491,8 +491,8 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   if (!plan_host || !plan_dev || !x.ptr || !dy.ptr || !grads || !workspace) return set_err(SRGANFD_EINVAL, "wgrad: null pointer");
   const WgHeader& H = *(const WgHeader*)plan_host;
   if (H.magic != kWgMagic) return set_err(SRGANFD_EINVAL, "wgrad: bad plan");
-  if ((size_t)H.N * H.Hin * H.Win * (size_t)x.cstride >= 0x7fffffffULL || (size_t)H.N * H.Hout * H.Wout * (size_t)dy.cstride >= 0x7fffffffULL)
-    return set_err(SRGANFD_EINVAL, "wgrad: tensors too large for 32-bit element offsets");
+  if ((size_t)H.Hin * H.Win * (size_t)x.cstride >= 0x7fffffffULL || (size_t)H.Hout * H.Wout * (size_t)dy.cstride >= 0x7fffffffULL)
+    return set_err(SRGANFD_EINVAL, "wgrad: one image is too large for 32-bit element offsets");
   const size_t need = (size_t)(H.bias_slab_off + H.nbias_slabs * 64) * sizeof(float);
   if (workspace_bytes < need) return set_err(SRGANFD_ENOSPC, "wgrad: workspace %zu < %zu", workspace_bytes, need);
   WgK k;

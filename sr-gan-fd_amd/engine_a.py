@@ -153,7 +153,7 @@ class AesrganDiscriminatorEngine:
         B["cat1"], B["cat2"], B["cat3"] = new(*R[2], 8 * nf), new(*R[1], 4 * nf), new(*R[0], 2 * nf)
         B["b3"], B["x4"], B["b4"], B["x5"], B["b5"] = new(*R[2], 8 * nf), new(*R[2], 4 * nf), new(*R[1], 4 * nf), new(*R[1], 2 * nf), new(*R[0], 2 * nf)
         B["x6"], B["c7"], B["c8"] = new(*R[0], nf), new(*R[0], nf), new(*R[0], nf)
-        sp.bn_ws = torch.empty(512 * 256 + 3 * 256, dtype=torch.float32, device=device)
+        sp.bn_ws = torch.empty(2048 * 256 + 3 * 256, dtype=torch.float32, device=device)
         lre = dict(act=A.ACT_LRELU, slope=0.2)
         cv = lambda *a, **k: ("conv", ops.conv_args(dtc, *a, **k))
         call = lambda fn: ("call", fn)

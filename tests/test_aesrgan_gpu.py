@@ -61,7 +61,7 @@ def test_batchnorm_and_gate():
     xa = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
     yb, dxb = torch.empty_like(xa), torch.empty_like(xa)
     rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
-    save, ws = torch.empty(4 * c, device="cuda"), torch.empty(512 * 256 + 768, device="cuda")
+    save, ws = torch.empty(4 * c, device="cuda"), torch.empty(2048 * 256 + 768, device="cuda")
     gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
     A.check(L.srganfd_batchnorm_fwd(A.view(xa), A.view(yb), A.F32, n * h * w, c, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                     0.1, 1e-5, 1, save.data_ptr(), ws.data_ptr(), st))
