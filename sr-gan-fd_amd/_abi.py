@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrganfd_hip.so")
+LIB_PATH = os.environ.get("SRGANFD_LIB") or os.path.join(_HERE, "libsrganfd_hip.so")   # SRGANFD_LIB: A/B kernel builds (tools/)
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2

@@ -34,6 +34,7 @@ struct WgTask {
 struct WgHeader {
   int magic, dtype, N, Hin, Win, up, ks, stride, pad, Hout, Wout;
   int ngroups, ntasks, S, x_upad, dy_upad, lds_bytes, ntiles, tiles_x, tiles_y, ntap_wave;
+  int dma_ok, pad_;   // LDS-DMA double buffering: bf16, every group stages the full pitch, two buffers fit
   long long nslabs_total, bias_slab_off /* floats */, nbias_slabs;
   long long groups_off, tasks_off, total_bytes;
 };
@@ -57,16 +58,41 @@ __device__ __forceinline__ bf16x8 cat_frag(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS [dst, dst + 1 KiB) (dst wave-uniform).
+// Inline asm on purpose: hipcc orders every later LDS read behind a __builtin_amdgcn_global_load_lds with a
+// vmcnt(0), which serialises the copy with the MFMA phase it is meant to overlap; an asm statement is outside its
+// wait-count bookkeeping, so the kernel waits explicitly (s_waitcnt vmcnt(0) before the barrier that publishes the buffer).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst));   // no "memory" clobber: it pins every by-reference lambda capture to scratch,
+                                                        // and scratch loads share vmcnt with the copies; ordering comes from the
+                                                        // explicit vmcnt(0) + barrier that publish a buffer
+}
+
 template <int KS, int STRIDE> struct WgTile { static constexpr int TH = (STRIDE == 1) ? 8 : 4; };
 
 template <int KS> struct WgWaves { static constexpr int NW = (KS == 3) ? 12 : (KS == 4 ? 8 : 4); };
+// DMA builds add loader wavefronts (one per SIMD) that only issue the LDS-DMA pieces of the next tile.  Measured on the
+// dense-block launch (B=32, 128x128): register staging 357 us; every wave issuing its share right after the barrier
+// 355 us (the copy's issue time and the LDS-bound MFMA phase add up: all waves sit in the same phase between two
+// barriers); the shares spread over the MFMA rows 396 us; four specialised loaders beside the compute waves 314 us.
+static constexpr int kLoaderWaves = 4;
 
 // One wave = one (32 ci x 32 co) block x ONE kernel row (KS taps, KS*16 accumulator registers), so a
 // 3x3 workgroup runs 12 waves (3 per SIMD, <=168 VGPRs each) over the same staged tiles.
 // XP / YP = LDS row pitch of the x / dy tiles in 32-channel units (compile-time so that every LDS address in
 // the MFMA loop is table + wave-uniform row offset + immediate).
-template <typename T, int KS, int STRIDE, int XP, int YP>
-__global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a) {
+// DMA = 1 (bf16, every group stages exactly XP / YP units): the tiles are double-buffered in LDS and filled by LDS-DMA
+// (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, so the LDS image is lane-linear and the 64-byte-unit swizzle
+// is applied to the per-lane SOURCE address); tile t+1 lands while tile t is in the MFMA phase, one barrier per tile,
+// no staging registers.  DMA = 0: global -> register -> LDS staging through one buffer.
+template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
+__global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) void wgrad_kernel(const WgK a) {
   constexpr int TH = WgTile<KS, STRIDE>::TH;
   constexpr int NTHR = 64 * WgWaves<KS>::NW;
   constexpr int NT = KS;
@@ -78,7 +104,7 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   // staging items per thread for the largest group (2 units each side)
   constexpr int XI = (PR * PC * 2 * CPU + NTHR - 1) / NTHR;
   constexpr int YI = (TH * 32 * 2 * CPU + NTHR - 1) / NTHR;
-  constexpr bool kPrefetch = sizeof(T) == 2;   // bf16: next tile's loads are issued before the MFMA phase
+  constexpr bool kPrefetch = sizeof(T) == 2 && !DMA;   // bf16 register staging: next tile's loads are issued before the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // 1-D grid.  Blocks b and b+8 share an XCD (private L2): remap so that each XCD owns a contiguous range of
   // work ids, with the channel group as the FAST index -- the workgroups that stream the same pixel tiles
@@ -92,11 +118,12 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   const WgGroup& G = a.groups[grp];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WgWave W = G.w[wave];
+  const WgWave W = G.w[wave < WgWaves<KS>::NW ? wave : 0];
   const int r = lane & 31, h = lane >> 5;
   const int xu_sh = G.x_units == 2 ? 1 : 0, yu_sh = G.dy_units == 2 ? 1 : 0;   // units staged by this group (1 or 2)
   constexpr int xp_sh = XP == 2 ? 1 : 0, yp_sh = YP == 2 ? 1 : 0;                // pitch (swizzle follows the pitch)
   constexpr int xRowB = UB * XP, dyRowB = UB * YP;
+  constexpr int kBufBytes = PR * PC * xRowB + TH * 32 * dyRowB;   // one (x tile, dy tile) buffer
   char* ldsX = smem;
   char* ldsY = smem + PR * PC * xRowB;
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
@@ -188,6 +215,50 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
     }
   };
 
+  // LDS-DMA fill (DMA builds only).  Item = one 16-byte chunk; a piece = one wave instruction = 64 consecutive items =
+  // 1 KiB of the lane-linear image.  Chunk (pixel, unit', w16) of the image holds source unit (unit' ^ swizzle(pixel));
+  // padding chunks are zero-filled with ds_write.  Pieces [0, XPIECES) fill the x tile, the rest the dy tile.
+  constexpr int XITEMS = PR * PC * (CPU << xp_sh), YITEMS = TH * 32 * (CPU << yp_sh);
+  constexpr int XPIECES = (XITEMS + 63) / 64, NPIECE = XPIECES + (YITEMS + 63) / 64;
+  constexpr int NSLOT = (NPIECE + kLoaderWaves - 1) / kLoaderWaves;   // pieces per loader wave and tile
+  auto dma_piece = [&](int n, int oy0, int ox0, int buf, int piece) __attribute__((always_inline)) {
+    char* bx = smem + buf * kBufBytes;
+    char* by = bx + PR * PC * xRowB;
+    constexpr int XSH = CPU_SH + xp_sh, YSH = CPU_SH + yp_sh;
+    if (piece < XPIECES) {
+      const int item = piece * 64 + lane;
+      if (item < XITEMS) {
+        const int pix = item >> XSH, c16 = item & ((CPU << xp_sh) - 1);
+        const int unit = (c16 >> CPU_SH) ^ swz(xp_sh, pix), w16 = c16 & (CPU - 1);
+        const int py = pix / PC, px = pix - py * PC;
+        const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
+        if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl) {
+          const T* src = xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + unit * 32 + w16 * E16);
+          glds16(src, lds_addr(bx) + (unsigned)(piece * 1024));
+        } else {
+          *(u32x4*)(bx + item * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    } else if (piece < NPIECE) {
+      const int item = (piece - XPIECES) * 64 + lane;
+      if (item < YITEMS) {
+        const int pix = item >> YSH, c16 = item & ((CPU << yp_sh) - 1);
+        const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
+        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+        if (oy < a.Hout && ox < a.Wout) {
+          const T* src = dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dyC + unit * 32 + w16 * E16);
+          glds16(src, lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
+        } else {
+          *(u32x4*)(by + item * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  };
+  auto dma_slots = [&](int n, int oy0, int ox0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) dma_piece(n, oy0, ox0, buf, (wave - WgWaves<KS>::NW) + kLoaderWaves * k);   // unrolled: the address arithmetic of all pieces overlaps
+  };
+
   // ---- lane-constant LDS address tables (keeps the MFMA loop almost free of address VALU work) ----
   // ds_read_b64_tr_b16 lane roles inside a 16-lane group: lane 4q+p supplies row q (pixel), columns
   // 4p..4p+3 (channels); lane i receives channel i of the 4 pixels.  This lane's first block row is pixel
@@ -213,12 +284,35 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
   const int ky = W.tap0 / KS;   // this wave's kernel row
 
   int tile = split;
-  if (tile < a.ntiles) prefetch(tile);
+  int cur = 0;
+  if constexpr (DMA) {
+    if (wave >= WgWaves<KS>::NW) {
+      // ---- loader wavefronts: tile t+1 -> buffer cur^1 while the compute waves run tile t out of buffer cur ----
+      int n, oy0, ox0;
+      if (tile < a.ntiles && !(a.dbg & 1)) { tile_origin(tile, n, oy0, ox0); dma_slots(n, oy0, ox0, 0); }
+      for (; tile < a.ntiles; tile += a.S) {
+        // own DMAs landed (vmcnt) and zero fills written (lgkmcnt in the barrier's fence); past the barrier the buffer
+        // is published and nobody reads buffer cur^1 any more (its MFMA phase precedes this barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + a.S < a.ntiles && !(a.dbg & 1)) { tile_origin(tile + a.S, n, oy0, ox0); dma_slots(n, oy0, ox0, cur ^ 1); }
+        cur ^= 1;
+      }
+      return;
+    }
+  } else if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += a.S) {
-    if (!(a.dbg & 32)) __syncthreads();  // previous tile's LDS reads done
-    if (!(a.dbg & 8)) commit(tile);
-    if (!(a.dbg & 32)) __syncthreads();
-    if (tile + a.S < a.ntiles) prefetch(tile + a.S);
+    if constexpr (DMA) {
+      __syncthreads();
+      ldsX = smem + cur * kBufBytes;
+      ldsY = ldsX + PR * PC * xRowB;
+      cur ^= 1;
+    } else {
+      if (!(a.dbg & 32)) __syncthreads();  // previous tile's LDS reads done
+      if (!(a.dbg & 8)) commit(tile);
+      if (!(a.dbg & 32)) __syncthreads();
+      if (tile + a.S < a.ntiles) prefetch(tile + a.S);
+    }
     if (W.active && !(a.dbg & 16)) {
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
@@ -278,48 +372,42 @@ __global__ __launch_bounds__(64 * WgWaves<KS>::NW) void wgrad_kernel(const WgK a
 }
 
 // Deterministic slab reduction + layout change to the NCHW fp32 parameter gradient.
-// One block = one (task, tap): its 32x32 fp32 tile is read as one float4 per thread and slab, eight slabs in
-// flight per thread (independent accumulators, fixed summation order -> bitwise reproducible).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgTask* __restrict__ tasks, const float* __restrict__ slabs,
-                                                           const float* __restrict__ bslabs, float* __restrict__ grads,
-                                                           const float* __restrict__ scalars, int ntap_wave) {
+// One block = one (task, tap); one thread = one element of its 32x32 fp32 tile (1024 threads: a launch has only
+// taps x tasks ~ 230 blocks, so the memory parallelism has to come from threads), eight slabs in flight per thread
+// (independent accumulators, fixed summation order -> bitwise reproducible).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgTask* __restrict__ tasks, const float* __restrict__ slabs,
+                                                            const float* __restrict__ bslabs, float* __restrict__ grads,
+                                                            const float* __restrict__ scalars, int ntap_wave) {
   const WgTask T = tasks[blockIdx.y];
   const int KT = T.ksize * T.ksize;
   const int tl = blockIdx.x;              // tap
   float alpha = T.alpha;
   if (T.alpha_off >= 0) alpha *= scalars[T.alpha_off];
   const size_t slab_stride = (size_t)ntap_wave * 1024;
-  const int row = threadIdx.x >> 3, col4 = (threadIdx.x & 7) * 4;
-  const f32x4* p = (const f32x4*)(slabs + (size_t)T.slab_base * slab_stride + tl * 1024 + row * 32 + col4);
-  const size_t st4 = slab_stride / 4;
-  f32x4 s[8];
+  const int row = threadIdx.x >> 5, col = threadIdx.x & 31;
+  const float* p = slabs + (size_t)T.slab_base * slab_stride + tl * 1024 + threadIdx.x;
+  float s[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
   int k = 0;
   for (; k + 8 <= T.nslabs; k += 8) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * st4];
+    for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * slab_stride];
   }
-  for (; k < T.nslabs; ++k) s[0] += p[(size_t)k * st4];
-  const f32x4 tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  const int ci = T.ci_base + row;
-  if (ci < T.ci_dst) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = T.co_base + col4 + q;
-      if (co < T.co_dst) {
-        float* d = grads + T.dw_off + ((size_t)co * T.ci_dst + ci) * KT + T.tap0 + tl;
-        *d = alpha * tot[q] + (T.beta != 0.f ? T.beta * *d : 0.f);
-      }
-    }
+  for (; k < T.nslabs; ++k) s[0] += p[(size_t)k * slab_stride];
+  const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  const int ci = T.ci_base + row, co = T.co_base + col;
+  if (ci < T.ci_dst && co < T.co_dst) {
+    float* d = grads + T.dw_off + ((size_t)co * T.ci_dst + ci) * KT + T.tap0 + tl;
+    *d = alpha * tot + (T.beta != 0.f ? T.beta * *d : 0.f);
   }
   if (T.bias_slab >= 0 && T.db_off >= 0 && tl == 0 && threadIdx.x < 32) {
-    const int co = T.co_base + threadIdx.x;
-    if (co < T.co_dst) {
+    const int cob = T.co_base + threadIdx.x;
+    if (cob < T.co_dst) {
       float sb = 0.f;
       const float* pb = bslabs + (size_t)T.bias_slab * 64;
       for (int kk = 0; kk < T.nslabs; ++kk) sb += pb[kk * 64 + threadIdx.x] + pb[kk * 64 + 32 + threadIdx.x];
-      float* d = grads + T.db_off + co;
+      float* d = grads + T.db_off + cob;
       *d = alpha * sb + (T.beta != 0.f ? T.beta * *d : 0.f);
     }
   }
@@ -442,6 +530,8 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   const int PR = (kTH - 1) * s->stride + s->ksize, PC = 31 * s->stride + s->ksize;
   H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
   if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
+  H.dma_ok = (s->dtype == SRGANFD_BF16 && 2 * H.lds_bytes <= 160 * 1024) ? 1 : 0;
+  for (auto& g : pb.groups) if (g.x_units != H.x_upad || g.dy_units != H.dy_upad) H.dma_ok = 0;
   H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
   H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;
   H.total_bytes = (H.tasks_off + (long long)sizeof(WgTask) * H.ntasks + 15) & ~15LL;
@@ -468,17 +558,25 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
   return SRGANFD_OK;
 }
 
-template <typename T, int KS, int STRIDE, int XP, int YP>
-static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
-  auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP>;
+template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
+static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP, DMA>;
   static int attr_lds = 0;
-  if (H.lds_bytes > attr_lds && !g_dry_run) {
-    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, H.lds_bytes));
-    attr_lds = H.lds_bytes;
+  const int lds = DMA ? 2 * H.lds_bytes : H.lds_bytes;
+  if (lds > attr_lds && !g_dry_run) {
+    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds = lds;
   }
-  SRGANFD_LAUNCH(kern, dim3(H.S * H.ngroups), dim3(64 * WgWaves<KS>::NW), H.lds_bytes, stream, k);
+  SRGANFD_LAUNCH(kern, dim3(H.S * H.ngroups), dim3(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))), lds, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
+}
+template <typename T, int KS, int STRIDE, int XP, int YP>
+static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    if (H.dma_ok && !(g_debug & 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
+  }
+  return launch_wgrad3<T, KS, STRIDE, XP, YP, false>(H, k, stream);
 }
 template <typename T, int KS, int STRIDE>
 static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
@@ -510,7 +608,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
   if (rc != SRGANFD_OK) return rc;
   const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
-  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(H.ntap_wave, H.ntasks), dim3(256), 0, stream, tasks_dev,
+  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(H.ntap_wave, H.ntasks), dim3(1024), 0, stream, tasks_dev,
                      (const float*)k.slabs, (const float*)k.bslabs, grads, scalars, H.ntap_wave);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;

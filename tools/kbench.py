@@ -26,6 +26,18 @@ def run(name, n, h, w, cin, cout, xC, x0, yC, y0, reps=30, mask=False, dt=torch.
 
 if __name__ == "__main__":
     N = 32
+    if "--batch" in sys.argv:
+        for n in (4, 8, 16, 32, 64):
+            run(f"N={n} fwd cin=160 cout=32 concat buffer", n, 128, 128, 160, 32, 192, 0, 192, 160)
+            run(f"N={n} cin=192 cout=64 x:192 y:192(next)", n, 128, 128, 192, 64, 192, 0, 192, 0)
+        sys.exit(0)
+    if "--quick" in sys.argv:
+        for cin in (64, 96, 128, 160):
+            run(f"fwd cin={cin} cout=32 concat buffer", N, 128, 128, cin, 32, 192, 0, 192, 64 + (cin - 64))
+        run("dgrad-like cin=192 cout=32 + mask", N, 128, 128, 192, 32, 192, 0, 192, 160, mask=True)
+        run("cin=192 cout=64 x:192 y:192(next)", N, 128, 128, 192, 64, 192, 0, 192, 0)
+        run("cin=64 cout=64 dense 512^2 N=8", 8, 512, 512, 64, 64, 64, 0, 64, 0)
+        sys.exit(0)
     for cin in (64, 128, 160):
         run(f"cin={cin} cout=32 x:192ch y:192ch(slice)", N, 128, 128, cin, 32, 192, 0, 192, 160)
         run(f"cin={cin} cout=32 x:dense y:dense", N, 128, 128, cin, 32, cin, 0, 32, 0)
