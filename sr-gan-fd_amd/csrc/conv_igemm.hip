@@ -239,11 +239,13 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
       }
     };
     if constexpr (sizeof(T) == 2) {
+      __builtin_amdgcn_s_setprio(1);   // waves in their MFMA phase win issue arbitration over waves that are staging (+1-3 %)
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
         for (int s2 = 0; s2 < C::KSTEPS; ++s2) col_body(kx, s2);
       }
+      __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll 1
       for (int kx = 0; kx < KS; ++kx) {

@@ -26,6 +26,8 @@ def run(name, n, h, w, cin, cout, xC, x0, yC, y0, reps=30, mask=False, dt=torch.
 
 if __name__ == "__main__":
     N = 32
+    if "--dbg" in sys.argv:
+        A.lib().srganfd_set_debug(int(sys.argv[sys.argv.index("--dbg") + 1]))
     if "--batch" in sys.argv:
         for n in (4, 8, 16, 32, 64):
             run(f"N={n} fwd cin=160 cout=32 concat buffer", n, 128, 128, 160, 32, 192, 0, 192, 160)
