@@ -12,8 +12,10 @@ step, U-Net discriminator + VGG-19 content loss); ``--workload aesrgan_gan`` = c
 attention U-Net discriminator, 192 -> 768, aesrgan_config.py hyper-parameters).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- dominant kernel, achieved TFLOP/s from HIP-event brackets around its launches in the
-                  timed region vs the dense bf16 MFMA peak,
+  roofline     -- dominant kernel class (largest total time) from HIP-event brackets around its launches in the timed
+                  region, against the roof its arithmetic intensity puts it under: algorithmic bytes / time vs the
+                  8 TB/s HBM peak when FLOP/byte is below the ridge (312), else algorithmic FLOP / time vs the dense
+                  bf16 MFMA peak; both fractions are in the object,
   cpu_baseline -- the CPU oracle (oracle/srgan_oracle.py, torch-CPU fp32) timed on this host on a
                   bounded sample (batch 1) of the same workload.
 """
@@ -27,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0      # HBM3E peak (same guide)
 # algorithmic FLOP per image, SURVEY.md 8(d): 1 MAC = 2 FLOP, backward = 2x forward
 FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9}
 BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192}     # the input size those figures are quoted at
@@ -182,7 +185,7 @@ def main():
     }
     if rank == 0:
         if rec is not None:
-            out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS)
+            out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS, PEAK_HBM_GBPS)
             if args.workload == "g_only" and B == 32 and h == 128:   # PMC figures were taken on this exact workload
                 out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get(out["roofline"]["kernel"])
             out["kernel_classes"] = profiling.summary(rec)

@@ -406,7 +406,7 @@ class TrunkEngine:
                     A.check(rc, "conv2d")
         else:
             for a in sp.fw:
-                rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d"))
+                rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d"))
         if self.full:
             out = torch.empty(N, self.out_ch, sp.hs, sp.ws, dtype=torch.float32, device=dev)
             A.check(L.srganfd_nhwc_to_nchw(A.view(sp.srp), A.F32, N, self.out_ch, sp.hs, sp.ws, out.data_ptr(), 1, st), "nhwc_to_nchw")
@@ -442,7 +442,7 @@ class TrunkEngine:
                         A.check(rc, "conv2d(dgrad)")
                 else:
                     a = item[1]
-                    rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
+                    rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
             elif kind == "wgrad":
                 _, plan, xv, dyv, goff = item
                 run = lambda: A.check(L.srganfd_conv2d_wgrad(plan.host, plan.dev.data_ptr(), xv, dyv, gptr + 4 * goff, None,
@@ -450,7 +450,7 @@ class TrunkEngine:
                 if rec is None:
                     run()
                 else:
-                    rec.bracket(plan.label, plan.flops, run)
+                    rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
             else:
                 item[1]()
         dx = None

@@ -368,7 +368,7 @@ class AesrganDiscriminatorEngine:
             if rc:
                 A.check(rc, what)
         else:
-            rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), what))
+            rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), what))
 
     def forward(self, x: Tensor, training: bool) -> Tensor:
         _require_gpu(x)
@@ -432,7 +432,7 @@ class AesrganDiscriminatorEngine:
                 if rec is None:
                     run()
                 else:
-                    rec.bracket(plan.label, plan.flops, run)
+                    rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
                 if sn_index is not None:
                     co, ci = self._wshape(name)
                     off = 4 * self._poff(name + ".weight_orig")

@@ -260,7 +260,7 @@ class DiscriminatorEngine:
                     if rc:
                         A.check(rc, "conv2d")
                 else:
-                    rec.bracket(profiling.conv_label(item), profiling.conv_flops(item), lambda: A.check(L.srganfd_conv2d(C.byref(item), st), "conv2d"))
+                    rec.bracket(profiling.conv_label(item), profiling.conv_work(item), lambda: A.check(L.srganfd_conv2d(C.byref(item), st), "conv2d"))
             else:
                 item()
         self.token += 1
@@ -288,7 +288,7 @@ class DiscriminatorEngine:
                     if rc:
                         A.check(rc, "conv2d(dgrad)")
                 else:
-                    rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
+                    rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
             elif kind == "wgrad":
                 if not need_wgrad:
                     continue
@@ -299,7 +299,7 @@ class DiscriminatorEngine:
                 if rec is None:
                     run()
                 else:
-                    rec.bracket(plan.label, plan.flops, run)
+                    rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
                 if sn_index is not None:
                     co, ci, k, _ = self.dims[name]
                     off = 4 * self._poff(f"{name}.0.weight_orig")
@@ -427,7 +427,7 @@ class ContentLossEngine:
                 if rec is None:
                     A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(vgg)")
                 else:
-                    rec.bracket(profiling.conv_label(a), profiling.conv_flops(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(vgg)"))
+                    rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(vgg)"))
                 if tap:
                     half_b = N * h * w * co * out.element_size()
                     A.check(L.srganfd_l1_loss_views(A.View(out.data_ptr(), co, 0), A.View(out.data_ptr() + half_b, co, 0), dtc, N * h * w, co, 0, 1.0,

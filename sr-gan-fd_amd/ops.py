@@ -115,6 +115,10 @@ class WgradPlan:
             w.alpha, w.beta, w.alpha_off = c.get("alpha", 1.0), c.get("beta", 0.0), c.get("alpha_off", -1)
         ho, wo = s.h_out, s.w_out
         self.flops = sum(2.0 * n * ho * wo * ksize * ksize * c["co_dst"] * c["ci_dst"] for c in convs)
+        es = 2 if dtype == A.BF16 else 4
+        # algorithmic bytes: x and dy read once, fp32 gradients written once
+        self.nbytes = float(n * h_in * w_in * x_channels * es + n * ho * wo * dy_channels * es
+                            + sum(4.0 * ksize * ksize * c["co_dst"] * c["ci_dst"] for c in convs))
         self.label = f"wgrad_kernel<{'bf16' if dtype == A.BF16 else 'f32'},KS={ksize},S={stride}>+reduce"
         L = A.lib()
         nbytes = L.srganfd_wgrad_plan_bytes(C.byref(s), carr)

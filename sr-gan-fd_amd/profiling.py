@@ -16,12 +16,14 @@ class Recorder:
     def __init__(self):
         self.items: List[tuple] = []
 
-    def bracket(self, label: str, flops: float, fn) -> None:
+    def bracket(self, label: str, work, fn) -> None:
+        """work = (algorithmic FLOP, algorithmic HBM bytes) of the launch"""
+        flops, nbytes = work if isinstance(work, tuple) else (work, 0.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.items.append((label, flops, e0, e1))
+        self.items.append((label, flops, nbytes, e0, e1))
 
 
 def enable() -> Recorder:
@@ -52,26 +54,56 @@ def conv_flops(a) -> float:
     return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
 
 
+def conv_work(a) -> tuple:
+    """(algorithmic FLOP, algorithmic bytes) of one fused-conv launch: every input pixel's cin channels read once, every
+    output pixel's cout_store channels written once, plus the epilogue tensors (residuals, mask read; pre-skip copy
+    written); weights are negligible.  Element size 2 (bf16) / 4 (f32; also the fp32 SR / logits outputs)."""
+    es = 2 if a.dtype == 0 else 4
+    pin = a.n * a.h_in * a.w_in * a.cin * es
+    pout = a.n * a.h_out * a.w_out * a.cout_store
+    nb = pin + pout * (4 if a.y_f32 else es)
+    for v in (a.r1, a.r2, a.mask, a.y2):
+        if v.ptr:
+            nb += pout * es
+    return conv_flops(a), float(nb)
+
+
 def summary(rec: Recorder) -> Dict[str, dict]:
     torch.cuda.synchronize()
     agg: Dict[str, dict] = {}
-    for label, flops, e0, e1 in rec.items:
-        d = agg.setdefault(label, {"launches": 0, "ms": 0.0, "flop": 0.0})
+    for label, flops, nbytes, e0, e1 in rec.items:
+        d = agg.setdefault(label, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
         d["launches"] += 1
         d["ms"] += e0.elapsed_time(e1)
         d["flop"] += flops
+        d["bytes"] += nbytes
     for d in agg.values():
         d["avg_us"] = round(d["ms"] * 1e3 / d["launches"], 2)
         d["tflops"] = round(d["flop"] / (d["ms"] * 1e-3) / 1e12, 1) if d["ms"] > 0 else 0.0
+        d["gbps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 else 0.0
+        d["flop_per_byte"] = round(d["flop"] / d["bytes"], 1) if d["bytes"] > 0 else None
         d["ms"] = round(d["ms"], 3)
         d["flop"] = float(f"{d['flop']:.6g}")
+        d["bytes"] = float(f"{d['bytes']:.6g}")
     return agg
 
 
-def roofline(rec: Recorder, peak_tflops: float) -> dict:
+def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> dict:
+    """Dominant kernel class (largest total time) against the roof that bounds it: its arithmetic intensity (algorithmic
+    FLOP / algorithmic bytes) below the ridge peak_tflops / peak_gbps means HBM-bound, else MFMA-bound.  Both fractions
+    are reported; `achieved` / `peak` / `frac` are those of the binding roof."""
     agg = summary(rec)
     label, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
-    return {"bound": "mfma", "kernel": label, "achieved": d["tflops"], "peak": peak_tflops, "unit": "TFLOP/s",
-            "frac": round(d["tflops"] / peak_tflops, 4), "traffic": None,
-            "avg_launch_us": d["avg_us"], "launches": d["launches"],
-            "flop_per_launch": float(f"{d['flop'] / d['launches']:.6g}")}
+    ridge = peak_tflops * 1e12 / (peak_gbps * 1e9)
+    ai = d["flop_per_byte"]
+    hbm = ai is not None and ai < ridge
+    out = {"bound": "hbm" if hbm else "mfma", "kernel": label}
+    if hbm:
+        out.update(achieved=d["gbps"], peak=peak_gbps, unit="GB/s", frac=round(d["gbps"] / peak_gbps, 4))
+    else:
+        out.update(achieved=d["tflops"], peak=peak_tflops, unit="TFLOP/s", frac=round(d["tflops"] / peak_tflops, 4))
+    out.update(traffic=None, avg_launch_us=d["avg_us"], launches=d["launches"],
+               flop_per_launch=float(f"{d['flop'] / d['launches']:.6g}"),
+               bytes_per_launch=float(f"{d['bytes'] / d['launches']:.6g}"), flop_per_byte=ai, ridge_flop_per_byte=round(ridge, 1),
+               mfma_frac=round(d["tflops"] / peak_tflops, 4), hbm_frac=round(d["gbps"] / peak_gbps, 4))
+    return out
