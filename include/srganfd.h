@@ -236,6 +236,15 @@ int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int3
                           const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
                           float* workspace, void* stream);
 
+/* ---- validation / data side ----
+ * random_crop (imgproc.py:846-886): the batch's common window (top, left, ph x pw) of NCHW fp32 images in one copy. */
+int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left,
+                      int32_t ph, int32_t pw, void* stream);
+/* PSNR per image (image_quality_assessment.py:361-395): NCHW fp32 in [0,1], crop_border pixels dropped on every side,
+ * y_only = BT.601 luma of RGB first (imgproc.py:757-767); out: n doubles (dB); workspace: n * 64 doubles. */
+int srganfd_psnr(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border,
+                 int32_t y_only, double* out, double* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

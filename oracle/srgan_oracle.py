@@ -244,6 +244,19 @@ def psnr_y(raw: Tensor, dst: Tensor, crop_border: int = 0, only_test_y_channel: 
     return 10 * torch.log10(255.0 ** 2 / mse)
 
 
+def random_crop(gt: Tensor, lr: Tensor, gt_image_size: int, upscale_factor: int, rng=None) -> Tuple[Tensor, Tensor]:
+    """random_crop -- BSRGAN/imgproc.py:846-886: ONE (top, left) for the whole batch from Python's `random` stream
+    (randint for the row first, then the column), LR window at the integer-divided position; outputs take lr's dtype."""
+    import random as _random
+    rng = rng or _random
+    h, w = gt.shape[2], gt.shape[3]
+    top = rng.randint(0, h - gt_image_size)
+    left = rng.randint(0, w - gt_image_size)
+    lt, ll, ls = top // upscale_factor, left // upscale_factor, gt_image_size // upscale_factor
+    return (gt[:, :, top:top + gt_image_size, left:left + gt_image_size].to(lr.dtype).clone(),
+            lr[:, :, lt:lt + ls, ll:ll + ls].clone())
+
+
 # ----------------------------------------------------------------------------------------------
 # Optimizer / EMA  (torch.optim.Adam single-tensor maths; swa_utils.AveragedModel)
 # ----------------------------------------------------------------------------------------------

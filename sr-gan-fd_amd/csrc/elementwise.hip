@@ -844,6 +844,66 @@ __global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// validation / data side
+// random_crop (imgproc.py:846-886): one (top, left) for the whole batch -> ONE strided copy instead of B slice copies
+__global__ __launch_bounds__(256) void crop_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int top,
+                                                        int left, int ph, int pw) {
+  const size_t total = (size_t)planes * ph * pw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % pw);
+    const size_t t = i / pw;
+    const int y = (int)(t % ph);
+    const size_t pl = t / ph;
+    dst[i] = src[(pl * h + top + y) * w + left + x];
+  }
+}
+// PSNR (image_quality_assessment.py:361-395): border crop, optional BT.601 luma in fp32 exactly as rgb_to_ycbcr_torch
+// (imgproc.py:757-767: matmul, + 16, / 255), then the squared error of the x255 values accumulated in fp64.
+// grid (blocks_per_image, n): partial[img][block]; the finish kernel sums them in a fixed order.
+__global__ __launch_bounds__(256) void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int c, int h, int w, int cb,
+                                                           int y_only, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  const int img = blockIdx.y;
+  const int hh = h - 2 * cb, ww = w - 2 * cb;
+  const size_t plane = (size_t)h * w;
+  const float* pa = a + (size_t)img * c * plane;
+  const float* pb = b + (size_t)img * c * plane;
+  double acc = 0.0;
+  const size_t npix = (size_t)hh * ww;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    const int y = (int)(i / ww) + cb, x = (int)(i % ww) + cb;
+    const size_t o = (size_t)y * w + x;
+    if (y_only) {
+      // torch.matmul of a (.., 3) row with the (3, 1) weight: fp32 fused multiply-add chain in channel order
+      float ya = pa[o] * 65.481f; ya = fmaf(pa[plane + o], 128.553f, ya); ya = fmaf(pa[2 * plane + o], 24.966f, ya); ya = (ya + 16.0f) / 255.f;
+      float yb = pb[o] * 65.481f; yb = fmaf(pb[plane + o], 128.553f, yb); yb = fmaf(pb[2 * plane + o], 24.966f, yb); yb = (yb + 16.0f) / 255.f;
+      const double d = (double)ya * 255.0 - (double)yb * 255.0;
+      acc += d * d + 1e-8;
+    } else {
+      for (int k = 0; k < c; ++k) {
+        const double d = (double)pa[k * plane + o] * 255.0 - (double)pb[k * plane + o] * 255.0;
+        acc += d * d + 1e-8;
+      }
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)img * gridDim.x + blockIdx.x] = sh[0];
+}
+__global__ void psnr_finish_kernel(const double* __restrict__ partial, int nblk, double count, double* __restrict__ out) {
+  const int img = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[(size_t)img * nblk + k];
+    out[img] = 10.0 * log10(255.0 * 255.0 / (s / count));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 8192) {
   size_t g = (total + block - 1) / block;
   if (g < 1) g = 1;
@@ -1137,6 +1197,24 @@ int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dty
                             dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c),
              SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
                             dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+static constexpr int kPsnrBlocks = 64;   // workspace: n * kPsnrBlocks doubles
+int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s) {
+  if (!src || !dst || n <= 0 || c <= 0 || top < 0 || left < 0 || ph <= 0 || pw <= 0 || top + ph > h || left + pw > w)
+    return set_err(SRGANFD_EINVAL, "crop: window %dx%d at (%d,%d) outside %dx%d", ph, pw, top, left, h, w);
+  SRGANFD_LAUNCH(crop_nchw_kernel, dim3(grid_for((size_t)n * c * ph * pw)), dim3(256), 0, s, src, dst, n * c, h, w, top, left, ph, pw);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s) {
+  if (!a || !b || !out || !ws || n <= 0 || c <= 0 || crop_border < 0 || h - 2 * crop_border <= 0 || w - 2 * crop_border <= 0 || (y_only && c != 3))
+    return set_err(SRGANFD_EINVAL, "psnr: bad args (Y channel needs 3-channel RGB input)");
+  SRGANFD_LAUNCH(psnr_partial_kernel, dim3(kPsnrBlocks, n), dim3(256), 0, s, a, b, c, h, w, crop_border, y_only, ws);
+  const double count = (double)(y_only ? 1 : c) * (h - 2 * crop_border) * (w - 2 * crop_border);
+  SRGANFD_LAUNCH(psnr_finish_kernel, dim3(n), dim3(64), 0, s, (const double*)ws, kPsnrBlocks, count, out);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

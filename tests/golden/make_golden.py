@@ -347,6 +347,39 @@ def gold_aesrgan_discriminator(MA):
     save("aesrgan_discriminator.npz", **out)
 
 
+def gold_validation():
+    """Validation / data side: _psnr_torch (BSRGAN/image_quality_assessment.py:361-395) and random_crop
+    (BSRGAN/imgproc.py:846-886), imported with an empty `cv2` stub module (neither function touches cv2)."""
+    import random
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    path = os.path.join(REF, "BSRGAN")
+    sys.path.insert(0, path)
+    try:
+        for m in ("imgproc", "image_quality_assessment"):
+            sys.modules.pop(m, None)
+        imgproc = importlib.import_module("imgproc")
+        iqa = importlib.import_module("image_quality_assessment")
+    finally:
+        sys.path.remove(path)
+    out = {}
+    torch.manual_seed(0)
+    a = torch.rand(3, 3, 40, 56)
+    b = (a + 0.05 * torch.randn_like(a)).clamp(0, 1)
+    out["psnr_a"], out["psnr_b"] = np_(a), np_(b)
+    out["psnr_y_cb4"] = np_(iqa._psnr_torch(a, b, 4, True))
+    out["psnr_rgb_cb4"] = np_(iqa._psnr_torch(a, b, 4, False))
+    out["psnr_y_cb0"] = np_(iqa.PSNR(0, True)(a, b))
+    gt = torch.rand(2, 3, 48, 64)
+    lr = torch.rand(2, 3, 12, 16)
+    out["crop_gt"], out["crop_lr"] = np_(gt), np_(lr)
+    for seed in (7, 11):
+        random.seed(seed)
+        pg, pl = imgproc.random_crop(gt, lr, 32, 4)
+        out[f"crop{seed}_gt"], out[f"crop{seed}_lr"] = np_(pg), np_(pl)
+    save("validation.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     MB = load_ref("BSRGAN")
@@ -359,6 +392,7 @@ def main():
     MA = load_ref("A-ESRGAN")
     gold_aesrgan_discriminator(MA)
     gold_aesrgan_gan_steps(MA)
+    gold_validation()
 
 
 if __name__ == "__main__":

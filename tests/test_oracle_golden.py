@@ -248,3 +248,19 @@ def test_aesrgan_gan_steps(golden_dir):
             assert np.allclose(checksum(G[k]), want_c, rtol=rt, atol=at * abs(want_c[1])), f"G {k}"
         for k, want_c in table(g, f"it{it}_wsum_d").items():
             assert np.allclose(checksum(D[k]), want_c, rtol=rt, atol=at * abs(want_c[1])), f"D {k}"
+
+
+def test_validation_side(golden_dir):
+    """_psnr_torch and random_crop restatements vs vectors captured from the reference (cv2 stubbed: neither uses it)"""
+    import random
+    from oracle import srgan_oracle as O
+    g = load_golden(golden_dir, "validation.npz")
+    a, b = torch.tensor(g["psnr_a"]), torch.tensor(g["psnr_b"])
+    assert np.allclose(O.psnr_y(a, b, 4, True).numpy(), g["psnr_y_cb4"], rtol=0, atol=1e-9)
+    assert np.allclose(O.psnr_y(a, b, 4, False).numpy(), g["psnr_rgb_cb4"], rtol=0, atol=1e-9)
+    assert np.allclose(O.psnr_y(a, b, 0, True).numpy(), g["psnr_y_cb0"], rtol=0, atol=1e-9)
+    gt, lr = torch.tensor(g["crop_gt"]), torch.tensor(g["crop_lr"])
+    for seed in (7, 11):
+        random.seed(seed)
+        pg, pl = O.random_crop(gt, lr, 32, 4)
+        assert np.array_equal(pg.numpy(), g[f"crop{seed}_gt"]) and np.array_equal(pl.numpy(), g[f"crop{seed}_lr"])
