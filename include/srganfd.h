@@ -212,6 +212,11 @@ int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                      int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
+/* Same update with the step count in device memory: *step_dev is advanced by one and the bias corrections are computed on
+ * the device (bc_dev: 2 floats of scratch), so that a captured hipGraph of the iteration can be replayed. */
+int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                         int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
 
 /* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
 /* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);

@@ -96,6 +96,8 @@ SYMBOLS = {
     "srganfd_add_relu": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "srganfd_sigmoid": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "srganfd_adam_ema_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "srganfd_crop_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "srganfd_psnr": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_gate_mul": (C.c_int, [C.c_int32, View, C.c_void_p, View, View, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),

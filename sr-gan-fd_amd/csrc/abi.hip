@@ -38,6 +38,8 @@ int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size
                   float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s);
 int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s);
+int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
 int sigmoid_impl(float* x, size_t n, hipStream_t s);
@@ -131,6 +133,12 @@ int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp
 int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                             int32_t c, void* stream) {
   return resize_bilinear_impl(bwd, a, b, dtype, n, hi, wi, ho, wo, c, (hipStream_t)stream);
+}
+int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay,
+                         int32_t ema_mode, void* stream) {
+  return adam_ema_dev_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step_dev, bc_dev, grad_scale,
+                           ema_decay, ema_mode, (hipStream_t)stream);
 }
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left, int32_t ph, int32_t pw,
                       void* stream) {

@@ -547,6 +547,35 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
   }
 }
 
+// Step counter and bias corrections in device memory (hipGraph replays cannot change kernel arguments): one thread
+// advances *step and writes bc = {1 - b1^t, sqrt(1 - b2^t)}; the Adam kernel then reads them.
+__global__ void adam_step_kernel(int* __restrict__ step, float b1, float b2, float* __restrict__ bc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = *step + 1;
+    *step = t;
+    bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+}
+__global__ __launch_bounds__(256) void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                           const float* __restrict__ bc, float gscale, float ema_decay, int ema_mode) {
+  const float bc1 = bc[0], bc2_sqrt = bc[1];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (ema_mode == 1) ema[i] = pi;
+    else if (ema_mode == 2) ema[i] = (1.f - ema_decay) * ema[i] + ema_decay * pi;
+  }
+}
+
 // ---- A-ESRGAN attention gates (A-ESRGAN/model.py:239-254): general bilinear resize, relu(a+b), sigmoid,
 // gate multiply, BatchNorm2d (training statistics, running stats, backward) ----
 // F.interpolate(mode="bilinear", align_corners=False) with an explicit output size (ATen area_pixel source index)
@@ -1094,6 +1123,16 @@ int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   SRGANFD_LAUNCH(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2),
                      grad_scale, ema_decay, ema_mode);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s) {
+  if (!p || !g || !m || !v || n == 0 || !step_dev || !bc_dev || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam(dev): bad args");
+  SRGANFD_LAUNCH(adam_step_kernel, dim3(1), dim3(64), 0, s, step_dev, b1, b2, bc_dev);
+  SRGANFD_LAUNCH(adam_ema_dev_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (const float*)bc_dev, grad_scale,
+                 ema_decay, ema_mode);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -35,6 +35,14 @@ class FlatAdamEMA:
         self.lr, self.betas, self.eps, self.wd, self.ema_decay = lr, betas, eps, weight_decay, ema_decay
         self.t = 0
         self.n_averaged = 0
+        self.step_dev: Optional[Tensor] = None     # device-side step counter (hipGraph replay), see graph.py
+        self.bc_dev: Optional[Tensor] = None
+
+    def use_device_step(self) -> None:
+        """Keep the step count in device memory from now on (a captured graph cannot change kernel arguments)."""
+        if self.step_dev is None:
+            self.step_dev = torch.tensor([self.t], dtype=torch.int32, device=self.flat.device)
+            self.bc_dev = torch.zeros(2, dtype=torch.float32, device=self.flat.device)
 
     def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True) -> None:
         self.t += 1
@@ -42,6 +50,12 @@ class FlatAdamEMA:
         if self.ema is not None and update_ema:
             mode = 1 if self.n_averaged == 0 else 2
             self.n_averaged += 1
+        if self.step_dev is not None:
+            A.check(A.lib().srganfd_adam_ema_dev(self.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                                 self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
+                                                 self.betas[0], self.betas[1], self.eps, self.wd, self.step_dev.data_ptr(),
+                                                 self.bc_dev.data_ptr(), grad_scale, self.ema_decay or 0.0, mode, A.stream_ptr()), "adam_ema_dev")
+            return
         A.check(A.lib().srganfd_adam_ema(self.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale,
