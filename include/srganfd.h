@@ -241,6 +241,16 @@ int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int3
                           const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
                           float* workspace, void* stream);
 
+/* BatchNorm2d followed by LeakyReLU(act_slope) in one pass (ESRGAN/model.py:98-126: conv -> BatchNorm2d -> LeakyReLU(0.2));
+ * backward takes `act` = that LeakyReLU's output and folds its derivative into dy.  Any channel count that splits into
+ * blocks of 256 (last block a power-of-two number of 16-byte chunks); workspace as above for 256 channels. */
+int srganfd_batchnorm_act_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int32_t training, float* save, float* workspace, float act_slope, void* stream);
+int srganfd_batchnorm_act_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c,
+                              const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
+                              float* workspace, srganfd_view act, float act_slope, void* stream);
+
 /* ---- validation / data side ----
  * random_crop (imgproc.py:846-886): the batch's common window (top, left, ph x pw) of NCHW fp32 images in one copy. */
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left,

@@ -444,3 +444,41 @@ def aesrgan_unet_forward(x: Tensor, P: Params, training: bool = True, update_sta
     out = lrelu(F.conv2d(out, sn_w("conv8"), None, padding=1))
     out = F.conv2d(out, P["conv9.weight"], P["conv9.bias"], padding=1)
     return (out, (s1, s2, s3)) if return_attention else out
+
+
+# ----------------------------------------------------------------------------------------------
+# ESRGAN discriminator
+# ----------------------------------------------------------------------------------------------
+ESRGAN_D_CONVS = (0, 2, 5, 8, 11, 14, 17, 20, 23, 26)      # indices of the convs inside `features`
+ESRGAN_D_STRIDES = (1, 2, 1, 2, 1, 2, 1, 2, 1, 2)
+
+
+def esrgan_discriminator_forward(x: Tensor, P: Params, training: bool = True, update_state: bool = True,
+                                 momentum: float = 0.1, eps: float = 1e-5) -> Tensor:
+    """Discriminator.forward -- ESRGAN/model.py:88-141: conv3x3(bias)+LeakyReLU, then nine (conv, BatchNorm2d,
+    LeakyReLU(0.2)) stages alternating 4x4 stride 2 / 3x3 stride 1, flatten (NCHW order), Linear(8192,100), LeakyReLU,
+    Linear(100,1).  Training mode normalises with batch statistics and advances running_mean / running_var (unbiased
+    variance, momentum 0.1) and num_batches_tracked in P, like nn.BatchNorm2d."""
+    out = x
+    for i, (fi, st) in enumerate(zip(ESRGAN_D_CONVS, ESRGAN_D_STRIDES)):
+        w = P[f"features.{fi}.weight"]
+        out = F.conv2d(out, w, P.get(f"features.{fi}.bias"), stride=st, padding=1)
+        if i > 0:
+            b = f"features.{fi + 1}"
+            if training:
+                mean = out.mean(dim=(0, 2, 3))
+                var = out.var(dim=(0, 2, 3), unbiased=False)
+                if update_state:
+                    n = out.numel() / out.shape[1]
+                    with torch.no_grad():
+                        P[b + ".running_mean"] = (1 - momentum) * P[b + ".running_mean"] + momentum * mean.detach()
+                        P[b + ".running_var"] = (1 - momentum) * P[b + ".running_var"] + momentum * var.detach() * n / (n - 1)
+                        P[b + ".num_batches_tracked"] = P[b + ".num_batches_tracked"] + 1
+            else:
+                mean, var = P[b + ".running_mean"], P[b + ".running_var"]
+            out = (out - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + eps)
+            out = out * P[b + ".weight"][None, :, None, None] + P[b + ".bias"][None, :, None, None]
+        out = F.leaky_relu(out, 0.2)
+    out = torch.flatten(out, 1)
+    out = F.leaky_relu(F.linear(out, P["classifier.0.weight"], P["classifier.0.bias"]), 0.2)
+    return F.linear(out, P["classifier.2.weight"], P["classifier.2.bias"])

@@ -46,9 +46,9 @@ int sigmoid_impl(float* x, size_t n, hipStream_t s);
 int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hipStream_t s);
 int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s);
 int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
-                       float momentum, float eps, int training, float* save, float* ws, hipStream_t s);
+                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s);
 int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
-                       float* dgamma, float* dbeta, float acc, float* ws, hipStream_t s);
+                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -163,11 +163,23 @@ int srganfd_batchnorm_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t
                           float* running_mean, float* running_var, float momentum, float eps, int32_t training, float* save, float* workspace,
                           void* stream) {
   return batchnorm_fwd_impl(x, y, dtype, (size_t)npix, c, gamma, beta, running_mean, running_var, momentum, eps, training, save, workspace,
-                            (hipStream_t)stream);
+                            1.f, (hipStream_t)stream);
+}
+int srganfd_batchnorm_act_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int32_t training, float* save,
+                              float* workspace, float act_slope, void* stream) {
+  return batchnorm_fwd_impl(x, y, dtype, (size_t)npix, c, gamma, beta, running_mean, running_var, momentum, eps, training, save, workspace,
+                            act_slope, (hipStream_t)stream);
 }
 int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
                           const float* save, float* dgamma, float* dbeta, float acc, float* workspace, void* stream) {
-  return batchnorm_bwd_impl(x, dy, dx, dtype, (size_t)npix, c, gamma, save, dgamma, dbeta, acc, workspace, (hipStream_t)stream);
+  srganfd_view none = {nullptr, 0, 0};
+  return batchnorm_bwd_impl(x, dy, dx, dtype, (size_t)npix, c, gamma, save, dgamma, dbeta, acc, workspace, none, 1.f, (hipStream_t)stream);
+}
+int srganfd_batchnorm_act_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                              const float* save, float* dgamma, float* dbeta, float acc, float* workspace, srganfd_view act,
+                              float act_slope, void* stream) {
+  return batchnorm_bwd_impl(x, dy, dx, dtype, (size_t)npix, c, gamma, save, dgamma, dbeta, acc, workspace, act, act_slope, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -742,7 +742,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const void* __restrict__ 
 // (deterministic), turns them into mean / invstd / (scale, shift) and updates the running statistics.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const void* __restrict__ x, int xC, int x0, const void* __restrict__ g, int gC, int g0,
-                                                         const float* __restrict__ save, size_t npix, int c, float* __restrict__ partial) {
+                                                         const float* __restrict__ save, size_t npix, int c, float* __restrict__ partial,
+                                                         const void* __restrict__ act, int actC, int act0, float act_slope) {
+  // act (optional, backward only): output of the LeakyReLU that followed the BatchNorm; dy is scaled by its derivative
   // forward statistics (g == nullptr): sum x, sum x^2.  backward (g = dy): sum dy, sum dy * xhat (xhat from save)
   constexpr int N = VecN<T>::N;
   __shared__ float sh[2][256 * N];
@@ -762,6 +764,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const void* __restrict_
       float xv[N], dv[N];
       ldv<T>(x, p * xC + x0 + ch, xv);
       ldv<T>(g, p * gC + g0 + ch, dv);
+      if (act) {
+        float av[N];
+        ldv<T>(act, p * actC + act0 + ch, av);
+#pragma unroll
+        for (int q = 0; q < N; ++q) dv[q] *= av[q] > 0.f ? 1.f : act_slope;
+      }
 #pragma unroll
       for (int q = 0; q < N; ++q) { s0[q] += dv[q]; s1[q] += dv[q] * (xv[q] - mean[q]) * invstd[q]; }
     }
@@ -849,7 +857,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
                                                           void* out, int oC, int o0, const float* __restrict__ ca, const float* __restrict__ cb,
-                                                          const float* __restrict__ c0, size_t npix, int c) {
+                                                          const float* __restrict__ c0, size_t npix, int c, float post_slope,
+                                                          const void* __restrict__ act, int actC, int act0, float act_slope) {
+  // post_slope: LeakyReLU applied to the result (1 = none).  act (optional): `a` is scaled by LeakyReLU'(act) first.
   constexpr int N = VecN<T>::N;
   const int cv = c / N, lanes = 256 / cv;               // host: 256 % cv == 0
   const int ch = (threadIdx.x % cv) * N, pl = threadIdx.x / cv;
@@ -860,6 +870,11 @@ __global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict
   for (size_t p = (size_t)blockIdx.x * lanes + pl; p < npix; p += step) {
     float va[N], vb[N];
     ldv<T>(a, p * aC + a0 + ch, va);
+    if (act) {
+      ldv<T>(act, p * actC + act0 + ch, vb);
+#pragma unroll
+      for (int q = 0; q < N; ++q) va[q] *= vb[q] > 0.f ? 1.f : act_slope;
+    }
     if (b) {
       ldv<T>(b, p * bC + b0 + ch, vb);
 #pragma unroll
@@ -867,6 +882,10 @@ __global__ __launch_bounds__(256) void chan_affine_kernel(const void* __restrict
     } else {
 #pragma unroll
       for (int q = 0; q < N; ++q) va[q] = va[q] * fa[q] + f0[q];
+    }
+    if (post_slope != 1.f) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) va[q] = va[q] > 0.f ? va[q] : va[q] * post_slope;
     }
     stv<T>(out, p * oC + o0 + ch, va);
   }
@@ -1202,40 +1221,53 @@ int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, sr
 static constexpr int kBnBlocks = 1024;  // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
 static inline bool bn_chunks_ok(int dtype, int c) { const int cv = c / (dtype == SRGANFD_BF16 ? 8 : 4); return cv > 0 && 256 % cv == 0; }
 static inline unsigned bn_grid(size_t npix, int dtype, int c) { const int lanes = 256 / (c / (dtype == SRGANFD_BF16 ? 8 : 4)); return grid_for((npix + lanes - 1) / lanes, 1, 16384); }
+// Channels are processed in blocks of <= 256 (the statistics kernels map one thread to one channel); `save` is
+// [block][mean | invstd | scale | shift] and is only read back by batchnorm_bwd_impl with the same blocking.
+static inline srganfd_view sub_view(srganfd_view v, int cb) { if (v.ptr) v.c0 += cb; return v; }
 int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
-                       float momentum, float eps, int training, float* save, float* ws, hipStream_t s) {
-  if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, y}) || !bn_chunks_ok(dtype, c))
-    return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (channels <= 256 and a power-of-two number of 16-byte chunks, aligned views)");
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
-  if (training) {
+                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s) {
+  if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || !vec_ok(dtype, c, {x, y}))
+    return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (16-byte aligned views)");
+  for (int cb = 0; cb < c; cb += 256) {
+    const int cc = c - cb < 256 ? c - cb : 256;
+    if (!bn_chunks_ok(dtype, cc)) return set_err(SRGANFD_EINVAL, "batchnorm_fwd: channel block of %d is not a power-of-two number of 16-byte chunks", cc);
+    const srganfd_view xs = sub_view(x, cb), ys = sub_view(y, cb);
+    float* sv = save + 4 * cb;
+    if (training) {
+      DISPATCH_T(dtype,
+                 SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f),
+                 SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f));
+    }
+    SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, beta + cb, rm + cb, rv + cb, momentum, eps, training, sv);
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws),
-               SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, c, ws));
+               SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
+                              ys.ptr, ys.cstride, ys.c0, (const float*)(sv + 2 * cc), (const float*)nullptr, (const float*)(sv + 3 * cc), npix, cc, act_slope, (const void*)nullptr, 0, 0, 1.f),
+               SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
+                              ys.ptr, ys.cstride, ys.c0, (const float*)(sv + 2 * cc), (const float*)nullptr, (const float*)(sv + 3 * cc), npix, cc, act_slope, (const void*)nullptr, 0, 0, 1.f));
   }
-  SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, beta, rm, rv, momentum, eps, training, save);
-  DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
-                            y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c),
-             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)nullptr, 0, 0,
-                            y.ptr, y.cstride, y.c0, (const float*)(save + 2 * c), (const float*)nullptr, (const float*)(save + 3 * c), npix, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
-                       float* dgamma, float* dbeta, float acc, float* ws, hipStream_t s) {
-  if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || c > 256 || !vec_ok(dtype, c, {x, dy, dx}) || !bn_chunks_ok(dtype, c))
+                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s) {
+  if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || !vec_ok(dtype, c, {x, dy, dx, act}))
     return set_err(SRGANFD_EINVAL, "batchnorm_bwd: bad args");
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
-  float* coef = ws + (size_t)kBnBlocks * 2 * c;
-  DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws),
-             SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, x.ptr, x.cstride, x.c0, (const void*)dy.ptr, dy.cstride, dy.c0, save, npix, c, ws));
-  SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, c, (float)npix, gamma, save, dgamma, dbeta, acc, coef);
-  DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
-                            dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c),
-             SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, (const void*)x.ptr, x.cstride, x.c0,
-                            dx.ptr, dx.cstride, dx.c0, (const float*)coef, (const float*)(coef + c), (const float*)(coef + 2 * c), npix, c));
+  for (int cb = 0; cb < c; cb += 256) {
+    const int cc = c - cb < 256 ? c - cb : 256;
+    if (!bn_chunks_ok(dtype, cc)) return set_err(SRGANFD_EINVAL, "batchnorm_bwd: channel block of %d is not a power-of-two number of 16-byte chunks", cc);
+    const srganfd_view xs = sub_view(x, cb), dys = sub_view(dy, cb), dxs = sub_view(dx, cb), as = sub_view(act, cb);
+    const float* sv = save + 4 * cb;
+    float* coef = ws + (size_t)kBnBlocks * 2 * cc;
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope),
+               SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope));
+    SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, sv, dgamma + cb, dbeta + cb, acc, coef);
+    DISPATCH_T(dtype,
+               SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
+                              dxs.ptr, dxs.cstride, dxs.c0, (const float*)coef, (const float*)(coef + cc), (const float*)(coef + 2 * cc), npix, cc, 1.f, (const void*)as.ptr, as.cstride, as.c0, act_slope),
+               SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
+                              dxs.ptr, dxs.cstride, dxs.c0, (const float*)coef, (const float*)(coef + cc), (const float*)(coef + 2 * cc), npix, cc, 1.f, (const void*)as.ptr, as.cstride, as.c0, act_slope));
+  }
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

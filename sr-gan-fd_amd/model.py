@@ -225,6 +225,32 @@ class UNetDiscriminatorAesrgan(nn.Module):
         return self.ly1, self.ly2, self.ly3
 
 
+class Discriminator(nn.Module):
+    """ESRGAN/model.py:88-141: VGG-style conv / BatchNorm2d / LeakyReLU stack (3x128x128 -> 512x4x4) and a two-layer
+    classifier; used by the relativistic GAN step of ESRGAN/train_esrgan.py:370-425.  Same ``features.*`` /
+    ``classifier.*`` state_dict keys; the sub-modules are parameter containers, forward/backward run on the HIP engine."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        layers = [nn.Conv2d(3, 64, (3, 3), (1, 1), (1, 1), bias=True), nn.LeakyReLU(0.2, True)]
+        cin = 64
+        for cout, k, s in ((64, 4, 2), (128, 3, 1), (128, 4, 2), (256, 3, 1), (256, 4, 2), (512, 3, 1), (512, 4, 2), (512, 3, 1), (512, 4, 2)):
+            layers += [nn.Conv2d(cin, cout, (k, k), (s, s), (1, 1), bias=False), nn.BatchNorm2d(cout), nn.LeakyReLU(0.2, True)]
+            cin = cout
+        self.features = nn.Sequential(*layers)
+        self.classifier = nn.Sequential(nn.Linear(512 * 4 * 4, 100), nn.LeakyReLU(0.2, True), nn.Linear(100, 1))
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .engine_e import esrgan_discriminator_apply
+        return esrgan_discriminator_apply(self, x)
+
+
+def discriminator() -> Discriminator:
+    """ESRGAN/model.py:293-296"""
+    return Discriminator()
+
+
 def uNetDiscriminatorAesrgan() -> UNetDiscriminatorAesrgan:
     return UNetDiscriminatorAesrgan(3)
 

@@ -347,6 +347,50 @@ def gold_aesrgan_discriminator(MA):
     save("aesrgan_discriminator.npz", **out)
 
 
+def gold_esrgan_discriminator(ME):
+    """Discriminator (ESRGAN/model.py:88-141): two training forwards (BatchNorm running statistics advance), backward of
+    BCE vs ones, eval forward, input gradient with frozen parameters.  BatchNorm affine parameters are randomised so
+    that gamma / beta gradients and the normalisation are exercised away from (1, 0)."""
+    out = {}
+    torch.manual_seed(0)
+    d = ME.discriminator()
+    with torch.no_grad():
+        for m in d.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x = torch.rand(4, 3, 128, 128)
+    out["x"] = np_(x)
+    out["wsum0"] = sd_checksums(d.state_dict())
+    d.train()
+    for it in range(2):
+        logits = d(x)
+        out[f"train{it}_logits"] = np_(logits)
+        out[f"train{it}_statesum"] = {k: checksum(v) for k, v in d.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    loss.backward()
+    out["bce_ones"] = np.array(loss.item())
+    named = dict(d.named_parameters())
+    out["gsum"] = {k: checksum(p.grad) for k, p in named.items()}
+    for k in ("features.0.weight", "features.0.bias", "features.3.weight", "features.3.bias", "features.27.weight", "classifier.0.bias",
+              "classifier.2.weight", "classifier.2.bias"):
+        out[f"grad/{k}"] = np_(named[k].grad)
+    for k in ("features.2.weight", "features.14.weight", "features.26.weight", "classifier.0.weight"):   # first rows only (fixture size)
+        out[f"gradrows/{k}"] = np_(named[k].grad[:2])
+    d.eval()
+    with torch.no_grad():
+        out["eval_logits"] = np_(d(x))
+    d.train()
+    xin = x.clone().requires_grad_(True)
+    for p in d.parameters():
+        p.requires_grad = False
+    lg = d(xin)
+    torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)).backward()
+    out["train2_dx"] = np_(xin.grad)
+    out["train2_logits"] = np_(lg)
+    save("esrgan_discriminator.npz", **out)
+
+
 def gold_validation():
     """Validation / data side: _psnr_torch (BSRGAN/image_quality_assessment.py:361-395) and random_crop
     (BSRGAN/imgproc.py:846-886), imported with an empty `cv2` stub module (neither function touches cv2)."""
@@ -393,6 +437,7 @@ def main():
     gold_aesrgan_discriminator(MA)
     gold_aesrgan_gan_steps(MA)
     gold_validation()
+    gold_esrgan_discriminator(ME)
 
 
 if __name__ == "__main__":

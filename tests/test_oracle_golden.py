@@ -264,3 +264,49 @@ def test_validation_side(golden_dir):
         random.seed(seed)
         pg, pl = O.random_crop(gt, lr, 32, 4)
         assert np.array_equal(pg.numpy(), g[f"crop{seed}_gt"]) and np.array_equal(pl.numpy(), g[f"crop{seed}_lr"])
+
+
+def _esrgan_d():
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    d = M.discriminator()
+    with torch.no_grad():
+        for m in d.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    return d
+
+
+def test_esrgan_discriminator(golden_dir):
+    """Discriminator (ESRGAN/model.py:88-141) oracle vs vectors captured from the reference"""
+    from oracle import srgan_oracle as O
+    g = load_golden(golden_dir, "esrgan_discriminator.npz")
+    d = _esrgan_d()
+    _check_table(table(g, "wsum0"), d.state_dict(), what="ESRGAN D")
+    P = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    names = [k for k, _ in d.named_parameters()]
+    for k in names:
+        P[k].requires_grad_(True)
+    x = torch.tensor(g["x"])
+    for it in range(2):
+        logits = O.esrgan_discriminator_forward(x, P, training=True)
+        _close(logits.detach(), g[f"train{it}_logits"], what=f"logits {it}")
+        for k, want in table(g, f"train{it}_statesum").items():
+            assert np.allclose(checksum(P[k]), want, rtol=1e-4, atol=1e-5 * abs(want[1]) + 1e-9), f"state {k}"
+    loss = O.bce_with_logits_mean(logits, 1.0)
+    assert abs(loss.item() - float(g["bce_ones"])) < 1e-6
+    grads = dict(zip(names, torch.autograd.grad(loss, [P[k] for k in names])))
+    for key in g.files:
+        if key.startswith("grad/"):
+            _close(grads[key[5:]], g[key], tol=1e-3, what=key)
+        elif key.startswith("gradrows/"):
+            _close(grads[key[9:]][:2], g[key], tol=1e-3, what=key)
+    with torch.no_grad():
+        _close(O.esrgan_discriminator_forward(x, P, training=False), g["eval_logits"], what="eval logits")
+    xin = x.clone().requires_grad_(True)
+    lg = O.esrgan_discriminator_forward(xin, P, training=True)
+    _close(lg.detach(), g["train2_logits"], what="logits 2")
+    dx, = torch.autograd.grad(O.bce_with_logits_mean(lg, 1.0), xin)
+    ref = torch.tensor(g["train2_dx"])
+    assert ((dx - ref).norm() / ref.norm()).item() < 1e-3        # L2: single LeakyReLU mask ties move isolated patches (see A-ESRGAN note)
