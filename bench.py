@@ -42,8 +42,8 @@ BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192}     # the input s
 # 32-channel 3x3 kernel, 403 MB for the 64-channel one, 453 MB for the dense-block weight gradient).
 PMC_TRAFFIC_BYTES = {
     "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": (1.548e6 + 5.271e5) * 64,
-    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": (2.549e6 + 1.622e6) * 64,
-    "wgrad_kernel<bf16,KS=3,S=1>+reduce": (5.78e6 + 5.907e5) * 64,
+    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": (2.538e6 + 1.622e6) * 64,
+    "wgrad_kernel<bf16,KS=3,S=1>+reduce": (4.339e6 + 5.907e5 + 2.959e5 + 1.112e5) * 64,
 }
 NODES = ["features.2", "features.7", "features.16", "features.25", "features.34"]   # bsrgan_config.py:130-132
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
