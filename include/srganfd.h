@@ -251,6 +251,19 @@ int srganfd_batchnorm_act_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, 
                               const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
                               float* workspace, srganfd_view act, float act_slope, void* stream);
 
+/* ---- differentiable VGG tap (ESRGAN/model.py:281-292: F.l1_loss between one feature node of SR and GT) ----
+ * out = scale * (*upstream or 1) * sign(a - b): the gradient of weight * mean|a - b| when scale = weight / numel. */
+int srganfd_l1_grad_views(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c,
+                          const float* upstream /* device scalar or NULL */, float scale, void* stream);
+/* MaxPool2d(2,2) backward fused with the derivative of the ReLU in front of it: x = the ReLU output (pre-pool,
+ * n x h x w x c), dy = gradient of the pooled map, dx = gradient w.r.t. the ReLU input (first maximum in row-major
+ * window order takes the gradient, as in ATen; zero where that maximum is not positive). */
+int srganfd_maxpool2_relu_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int32_t n, int32_t h,
+                              int32_t w, int32_t c, void* stream);
+/* fp32 NHWC -> NCHW with dst[n][c] = src[..][c] / ch_div[c] (backward of transforms.Normalize's division by std) */
+int srganfd_nhwc_to_nchw_scaled(srganfd_view src_f32, int32_t n, int32_t c, int32_t h, int32_t w, float* dst,
+                                const float* ch_div, void* stream);
+
 /* ---- validation / data side ----
  * random_crop (imgproc.py:846-886): the batch's common window (top, left, ph x pw) of NCHW fp32 images in one copy. */
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left,

@@ -482,3 +482,26 @@ def esrgan_discriminator_forward(x: Tensor, P: Params, training: bool = True, up
     out = torch.flatten(out, 1)
     out = F.leaky_relu(F.linear(out, P["classifier.0.weight"], P["classifier.0.bias"]), 0.2)
     return F.linear(out, P["classifier.2.weight"], P["classifier.2.bias"])
+
+
+def content_loss_single(sr: Tensor, gt: Tensor, P: Params, node: str, mean: Sequence[float], std: Sequence[float]) -> Tensor:
+    """ESRGAN ContentLoss.forward -- ESRGAN/model.py:281-292: normalise, run vgg19.features up to ONE node, F.l1_loss of the
+    two feature maps; differentiable w.r.t. sr.  The extractor graph is cut at the node (create_feature_extractor), so the
+    ReLU that follows it in torchvision's Sequential is not part of it: a conv node is observed pre-ReLU."""
+    last = int(node.split(".")[1])
+    m = torch.tensor(mean, dtype=sr.dtype).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=sr.dtype).view(1, 3, 1, 1)
+
+    def run(x: Tensor) -> Tensor:
+        x = (x - m) / s
+        for kind, idx, _ in vgg19_feature_layers():
+            if idx > last:
+                break
+            if kind == "conv":
+                x = F.conv2d(x, P[f"features.{idx}.weight"], P[f"features.{idx}.bias"], padding=1)
+                if idx != last:
+                    x = F.relu(x)
+            elif kind == "pool":
+                x = F.max_pool2d(x, 2, 2)
+        return x
+    return F.l1_loss(run(sr), run(gt))

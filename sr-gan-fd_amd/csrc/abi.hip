@@ -38,6 +38,9 @@ int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size
                   float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s);
 int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s);
+int l1_grad_views_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, const float* upstream, float scale, hipStream_t s);
+int maxpool2_relu_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, int n, int h, int w, int c, hipStream_t s);
+int nhwc_to_nchw_scaled_impl(srganfd_view src, int n, int c, int h, int w, float* dst, const float* ch_div, hipStream_t s);
 int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
                       int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
@@ -139,6 +142,17 @@ int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float*
                          int32_t ema_mode, void* stream) {
   return adam_ema_dev_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step_dev, bc_dev, grad_scale,
                            ema_decay, ema_mode, (hipStream_t)stream);
+}
+int srganfd_l1_grad_views(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, const float* upstream,
+                          float scale, void* stream) {
+  return l1_grad_views_impl(a, b, out, dtype, (size_t)npix, c, upstream, scale, (hipStream_t)stream);
+}
+int srganfd_maxpool2_relu_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c,
+                              void* stream) {
+  return maxpool2_relu_bwd_impl(x, dy, dx, dtype, n, h, w, c, (hipStream_t)stream);
+}
+int srganfd_nhwc_to_nchw_scaled(srganfd_view src_f32, int32_t n, int32_t c, int32_t h, int32_t w, float* dst, const float* ch_div, void* stream) {
+  return nhwc_to_nchw_scaled_impl(src_f32, n, c, h, w, dst, ch_div, (hipStream_t)stream);
 }
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left, int32_t ph, int32_t pw,
                       void* stream) {

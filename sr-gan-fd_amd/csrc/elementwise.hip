@@ -951,6 +951,60 @@ __global__ void psnr_finish_kernel(const double* __restrict__ partial, int nblk,
   }
 }
 
+// ---- differentiable VGG tap (ESRGAN/model.py:281-292): gradient of mean |a - b| w.r.t. a, max-pool backward with the
+// preceding ReLU's derivative folded in, and the relayout that also undoes the 1/std of the input normalisation ----
+template <typename T>
+__global__ __launch_bounds__(256) void l1_grad_views_kernel(const void* __restrict__ a, int aC, int a0, const void* __restrict__ b, int bC, int b0,
+                                                            void* out, int oC, int o0, size_t npix, int c, const float* __restrict__ upstream, float scale) {
+  const float sc = scale * (upstream ? *upstream : 1.f);
+  const size_t total = npix * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const float d = ld<T>(a, p * aC + a0 + ch) - ld<T>(b, p * bC + b0 + ch);
+    st<T>(out, p * oC + o0 + ch, d > 0.f ? sc : (d < 0.f ? -sc : 0.f));     // torch: sign(0) = 0
+  }
+}
+// x: pre-pool activation (a ReLU output), dy: gradient of the pooled map, dx: gradient w.r.t. the ReLU's INPUT.
+// The gradient goes to the first maximum of each 2x2 window in row-major order (ATen max_pool2d) and is zero where
+// that maximum is not positive (ReLU').
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const void* __restrict__ x, int xC, int x0, const void* __restrict__ dy, int yC, int y0,
+                                                                void* dx, int dC, int d0, int n, int h, int w, int c) {
+  const int ho = h / 2, wo = w / 2;
+  const size_t total = (size_t)n * ho * wo * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t p = i / c;
+    const int ox = (int)(p % wo); p /= wo;
+    const int oy = (int)(p % ho);
+    const size_t img = p / ho;
+    const size_t b = (img * h + 2 * oy) * w + 2 * ox;
+    const size_t q[4] = {b, b + 1, b + w, b + w + 1};
+    float best = ld<T>(x, q[0] * xC + x0 + ch);
+    int arg = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float v = ld<T>(x, q[k] * xC + x0 + ch);
+      if (v > best) { best = v; arg = k; }
+    }
+    const float g = best > 0.f ? ld<T>(dy, (i / c) * yC + y0 + ch) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st<T>(dx, q[k] * dC + d0 + ch, k == arg ? g : 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_scaled_kernel(const float* __restrict__ src, int sC, int s0, float* __restrict__ dst, int n, int c,
+                                                                  int hw, const float* __restrict__ ch_div) {
+  const size_t total = (size_t)n * c * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i % hw;
+    const size_t t = i / hw;
+    const int ch = (int)(t % c);
+    const size_t img = t / c;
+    dst[i] = src[(img * hw + pix) * sC + s0 + ch] / ch_div[ch];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 8192) {
   size_t g = (total + block - 1) / block;
@@ -1286,6 +1340,30 @@ int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int cr
   SRGANFD_LAUNCH(psnr_partial_kernel, dim3(kPsnrBlocks, n), dim3(256), 0, s, a, b, c, h, w, crop_border, y_only, ws);
   const double count = (double)(y_only ? 1 : c) * (h - 2 * crop_border) * (w - 2 * crop_border);
   SRGANFD_LAUNCH(psnr_finish_kernel, dim3(n), dim3(64), 0, s, (const double*)ws, kPsnrBlocks, count, out);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+int l1_grad_views_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, const float* upstream, float scale, hipStream_t s) {
+  if (!a.ptr || !b.ptr || !out.ptr || npix == 0 || c <= 0) return set_err(SRGANFD_EINVAL, "l1_grad_views: bad args");
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(l1_grad_views_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c, upstream, scale),
+             SRGANFD_LAUNCH(l1_grad_views_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c, upstream, scale));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int maxpool2_relu_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, int n, int h, int w, int c, hipStream_t s) {
+  if (!x.ptr || !dy.ptr || !dx.ptr || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0) return set_err(SRGANFD_EINVAL, "maxpool2_relu_bwd: bad args");
+  const size_t total = (size_t)n * (h / 2) * (w / 2) * c;
+  DISPATCH_T(dtype,
+             SRGANFD_LAUNCH(maxpool2_relu_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, dy.ptr, dy.cstride, dy.c0, dx.ptr, dx.cstride, dx.c0, n, h, w, c),
+             SRGANFD_LAUNCH(maxpool2_relu_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, dy.ptr, dy.cstride, dy.c0, dx.ptr, dx.cstride, dx.c0, n, h, w, c));
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int nhwc_to_nchw_scaled_impl(srganfd_view src, int n, int c, int h, int w, float* dst, const float* ch_div, hipStream_t s) {
+  if (!src.ptr || !dst || !ch_div || n <= 0 || c <= 0) return set_err(SRGANFD_EINVAL, "nhwc_to_nchw_scaled: bad args");
+  SRGANFD_LAUNCH(nhwc_to_nchw_scaled_kernel, dim3(grid_for((size_t)n * c * h * w)), dim3(256), 0, s, (const float*)src.ptr, src.cstride, src.c0, dst, n, c, h * w, ch_div);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

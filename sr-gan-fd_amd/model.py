@@ -150,12 +150,19 @@ class ContentLoss(nn.Module):
     reference tree (third-party, network download), so the VGG-19 ``features[0:35]`` topology is
     restated here and its weights come from ``weights_path`` (a torchvision ``vgg19`` state_dict) or,
     when absent, from a seeded random init (benchmarks).  The returned tensor is DETACHED with shape
-    (1, len(nodes)) exactly like the reference's ``torch.Tensor([losses])`` (:552)."""
+    (1, len(nodes)) exactly like the reference's ``torch.Tensor([losses])`` (:552).
 
-    def __init__(self, feature_model_extractor_nodes: list, feature_model_normalize_mean: list,
+    ESRGAN's variant (ESRGAN/model.py:258-292) passes ONE node name as a string and keeps the result in the autograd
+    graph (``F.l1_loss`` of the two feature maps, a scalar): given a ``str`` this class behaves that way, with the frozen
+    extractor's backward pass on the HIP engine (engine_v.py)."""
+
+    def __init__(self, feature_model_extractor_nodes, feature_model_normalize_mean: list,
                  feature_model_normalize_std: list, weights_path: str = "", taps_post_relu: bool = True) -> None:
         super().__init__()
         from .vgg import build_vgg19_features
+        self.single_node = isinstance(feature_model_extractor_nodes, str)
+        if self.single_node:
+            feature_model_extractor_nodes = [feature_model_extractor_nodes]
         self.feature_model_extractor_nodes = list(feature_model_extractor_nodes)
         self.taps_post_relu = taps_post_relu
         self.features = build_vgg19_features(weights_path)
@@ -167,6 +174,9 @@ class ContentLoss(nn.Module):
 
     def forward(self, sr_tensor: Tensor, gt_tensor: Tensor) -> Tensor:
         assert sr_tensor.size() == gt_tensor.size(), "Two tensor must have the same size"
+        if self.single_node:
+            from .engine_v import content_loss_single_apply
+            return content_loss_single_apply(self, sr_tensor, gt_tensor)
         from .engine import content_loss_apply
         return content_loss_apply(self, sr_tensor, gt_tensor)
 

@@ -125,3 +125,59 @@ def test_esrgan_discriminator(golden_dir, dtype):
     e2 = ((xin.grad.double().cpu() - ref).norm() / ref.norm()).item()
     print(f"ESRGAN D {dtype}: input-gradient L2 err {e2:.2e}")
     assert e2 < (3e-2 if f32 else 3e-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_differentiable_single_node_content_loss(dtype):
+    """ESRGAN ContentLoss (one node, kept in the autograd graph: ESRGAN/model.py:258-292): value and d/dSR vs the CPU oracle
+    (seeded VGG-19 weights: the ImageNet file is a network download, parity of VALUES stays unpinned as for BSRGAN's)."""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    cl = M.ContentLoss("features.34", mean, std)
+    cl.compute_dtype = dtype
+    cl.cuda()
+    torch.manual_seed(3)
+    sr, gt = torch.rand(2, 3, 48, 32), torch.rand(2, 3, 48, 32)
+    s = sr.clone().cuda().requires_grad_(True)
+    loss = cl(s, gt.cuda())
+    (2.5 * loss).backward()
+    P = {"features." + k: v.detach().cpu() for k, v in cl.features.state_dict().items()}
+    so = sr.clone().requires_grad_(True)
+    want = O.content_loss_single(so, gt, P, "features.34", mean, std)
+    (2.5 * want).backward()
+    f32 = dtype == torch.float32
+    e_l = abs(loss.item() - want.item()) / abs(want.item())
+    e_g = _rel_l2(s.grad, so.grad)
+    print(f"single-node content loss {dtype}: value {loss.item():.6f} vs {want.item():.6f} (rel {e_l:.2e}), dSR L2 err {e_g:.2e}, max {_rel(s.grad, so.grad):.2e}")
+    assert loss.dim() == 0 and e_l < (1e-4 if f32 else 3e-2)
+    # L2 bound: ~1M ReLU inputs, fp32 conv outputs that differ from the reference's by summation order (~5e-6) -> a handful
+    # of mask flips, each worth sqrt(1/#active) of a layer's gradient (the oracle in fp64 vs fp32 shows none: 6e-7)
+    # bf16: the tap gradient is sign(sr_f - gt_f); wherever |sr_f - gt_f| is below the bf16 error of 16 chained convs the sign
+    # flips outright, so the bf16 gradient is only loosely tied to the fp32 one (the reference's fp16 autocast has the same trait)
+    assert e_g < (1e-2 if f32 else 4e-1)
+    with torch.no_grad():
+        assert abs(cl(sr.cuda(), gt.cuda()).item() - loss.item()) < 1e-6 * abs(loss.item()) + 1e-9
+
+
+def test_maxpool_relu_backward_and_l1_sign_kernels():
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(4)
+    n, c, h, w = 2, 32, 8, 12
+    L, st = A.lib(), A.stream_ptr()
+    z = torch.randn(n, c, h, w, requires_grad=True)
+    y = F.max_pool2d(F.relu(z), 2, 2)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xa = F.relu(z).detach().permute(0, 2, 3, 1).contiguous().cuda()
+    dya = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dxa = torch.empty_like(xa)
+    A.check(L.srganfd_maxpool2_relu_bwd(A.view(xa), A.view(dya), A.view(dxa), A.F32, n, h, w, c, st))
+    a, b = torch.randn(n, h, w, c, device="cuda"), torch.randn(n, h, w, c, device="cuda")
+    b[0, 0, 0, :4] = a[0, 0, 0, :4]                        # exact ties: sign(0) = 0
+    up = torch.tensor([1.5], device="cuda")
+    out = torch.empty_like(a)
+    A.check(L.srganfd_l1_grad_views(A.view(a), A.view(b), A.view(out), A.F32, n * h * w, c, up.data_ptr(), 0.25, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dxa.permute(0, 3, 1, 2).cpu(), z.grad)
+    assert torch.equal(out, 0.375 * torch.sign(a - b))
