@@ -505,3 +505,45 @@ def content_loss_single(sr: Tensor, gt: Tensor, P: Params, node: str, mean: Sequ
                 x = F.max_pool2d(x, 2, 2)
         return x
     return F.l1_loss(run(sr), run(gt))
+
+
+def esrgan_gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: Tensor, gt: Tensor, *, upscale: int = 4,
+                    lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.99), eps: float = 1e-8, pixel_weight: float = 0.01,
+                    content_weight: float = 1.0, adversarial_weight: float = 0.005, content_fn=None) -> Dict[str, float]:
+    """One iteration of ESRGAN/train_esrgan.py:364-431: GENERATOR first (D frozen; relativistic-average adversarial term
+    built from D(gt.detach()) and D(sr), both in training mode so BatchNorm statistics advance), Adam step; then the
+    discriminator: D(gt), D(sr.detach()), loss on gt_output - mean(sr_output) (backward with retain_graph), a THIRD forward
+    D(sr.detach()), loss on sr_output - mean(gt_output) (backward), Adam step."""
+    gn, dn = g_param_names(G), [k for k in D if k.endswith((".weight", ".bias"))]
+    _leafify(G, gn)
+    for k in dn:
+        D[k] = D[k].detach()
+    sr = rrdbnet_forward(lr_img, G, upscale)
+    gt_output = esrgan_discriminator_forward(gt.detach().clone(), D, training=True)
+    sr_output = esrgan_discriminator_forward(sr, D, training=True)
+    pixel = pixel_weight * l1_mean(sr, gt)
+    content = content_weight * (content_fn(sr, gt) if content_fn is not None else torch.zeros(()))
+    bce = F.binary_cross_entropy_with_logits
+    adv = adversarial_weight * (bce(gt_output - sr_output.mean(), torch.zeros_like(gt_output)) * 0.5 +
+                                bce(sr_output - gt_output.mean(), torch.ones_like(sr_output)) * 0.5)
+    grads = torch.autograd.grad(pixel + content + adv, [G[k] for k in gn])
+    with torch.no_grad():
+        adam_step(G, dict(zip(gn, grads)), g_opt, lr, betas, eps)
+    for k in gn:
+        G[k] = G[k].detach()
+    _leafify(D, dn)
+    srd = sr.detach().clone()
+    gt_output = esrgan_discriminator_forward(gt, D, training=True)
+    sr_output = esrgan_discriminator_forward(srd, D, training=True)
+    d_loss_gt = bce(gt_output - sr_output.mean(), torch.ones_like(gt_output)) * 0.5
+    g1 = torch.autograd.grad(d_loss_gt, [D[k] for k in dn], retain_graph=True)
+    sr_output = esrgan_discriminator_forward(srd, D, training=True)
+    d_loss_sr = bce(sr_output - gt_output.mean(), torch.zeros_like(sr_output)) * 0.5
+    g2 = torch.autograd.grad(d_loss_sr, [D[k] for k in dn])
+    with torch.no_grad():
+        adam_step(D, {k: a + b for k, a, b in zip(dn, g1, g2)}, d_opt, lr, betas, eps)
+    for k in dn:
+        D[k] = D[k].detach()
+    return {"d_loss": float(d_loss_gt + d_loss_sr), "pixel_loss": float(pixel), "adversarial_loss": float(adv),
+            "d_gt_probability": float(torch.sigmoid(gt_output.detach().mean())),
+            "d_sr_probability": float(torch.sigmoid(sr_output.detach().mean())), "sr": sr.detach()}

@@ -4,6 +4,10 @@ Reference: Discriminator ESRGAN/model.py:88-141 -- conv3x3(bias) + LeakyReLU, ni
 LeakyReLU(0.2)) stages alternating 4x4 stride 2 / 3x3 stride 1 (3x128x128 -> 512x4x4), flatten, Linear(8192,100),
 LeakyReLU, Linear(100,1).
 
+The relativistic step of ESRGAN/train_esrgan.py:395-418 keeps up to three training forwards alive at once (gt_output and
+sr_output both feed each loss term, ``backward(retain_graph=True)``), each with its own BatchNorm batch statistics, so
+activations live in a ring of RING plan instances per input shape instead of one.
+
 Mapping: the convs are the implicit-GEMM kernel (4x4 stride-2 data gradients as four output-parity classes); BatchNorm +
 LeakyReLU is one fused statistics/apply pass per stage (srganfd_batchnorm_act_fwd / _bwd, channel blocks of 256);
 ``torch.flatten`` of an NCHW tensor followed by Linear(8192,100) IS a 4x4 "valid" convolution of the 4x4x512 map with
@@ -25,6 +29,7 @@ from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape
 
 CONV_IDX = (0, 2, 5, 8, 11, 14, 17, 20, 23, 26)          # positions of the convs inside `features`
 SLOPE = 0.2
+RING = 4                                                   # activation sets per input shape (live forwards of one iteration)
 
 
 class EsrganDiscriminatorEngine:
@@ -82,11 +87,12 @@ class EsrganDiscriminatorEngine:
 
     # ---- per-shape plan ----
     def _plan(self, N, H, W, dt, dtc, device, pk):
-        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr())
+        self._fw_count = getattr(self, "_fw_count", 0) + 1
+        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr(), self._fw_count % RING)
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 4:
+        if len(self.shapes) > 4 * RING:
             self.shapes.clear()
         if H != 128 or W != 128:
             raise A.SrganfdError("Discriminator expects 3x128x128 inputs: its classifier is Linear(512*4*4, 100) (ESRGAN/model.py:129)")

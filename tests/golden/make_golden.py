@@ -391,6 +391,59 @@ def gold_esrgan_discriminator(ME):
     save("esrgan_discriminator.npz", **out)
 
 
+def gold_esrgan_gan_steps(ME):
+    """Two iterations of ESRGAN/train_esrgan.py:340-431 (generator first, relativistic-average losses, discriminator with
+    three training forwards and retain_graph) around the reference's RRDBNet / Discriminator, torch.optim.Adam,
+    AveragedModel; content loss stubbed to zero (no VGG weights); esrgan_config.py:95-111 hyper-parameters."""
+    from torch.optim.swa_utils import AveragedModel
+    out = {}
+    torch.manual_seed(0)
+    d = ME.discriminator()
+    g = ME.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_blocks=2)
+    scaled_init(g, 3.0, 0.5)
+    decay = 0.99998
+    ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - decay) * a + decay * p)
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    d.train()
+    g.train()
+    B = 4
+    out["wsum_g0"], out["wsum_d0"] = sd_checksums(g.state_dict()), sd_checksums(d.state_dict())
+    for it in range(2):
+        lr, gt = torch.rand(B, 3, 32, 32), torch.rand(B, 3, 128, 128)
+        out[f"it{it}_lr"], out[f"it{it}_gt"] = np_(lr), np_(gt)
+        real, fake = torch.full([B, 1], 1.0), torch.full([B, 1], 0.0)
+        for p in d.parameters():
+            p.requires_grad = False
+        g.zero_grad(set_to_none=True)
+        sr = g(lr)
+        gt_output = d(gt.detach().clone())
+        sr_output = d(sr)
+        pixel = 0.01 * l1(sr, gt)
+        content = 1.0 * torch.zeros(())
+        adv = 0.005 * (bce(gt_output - torch.mean(sr_output), fake) * 0.5 + bce(sr_output - torch.mean(gt_output), real) * 0.5)
+        (pixel + content + adv).backward()
+        g_opt.step()
+        ema.update_parameters(g)
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        sr_output = d(sr.detach().clone())
+        d_loss_gt = bce(gt_output - torch.mean(sr_output), real) * 0.5
+        d_loss_gt.backward(retain_graph=True)
+        sr_output = d(sr.detach().clone())
+        d_loss_sr = bce(sr_output - torch.mean(gt_output), fake) * 0.5
+        d_loss_sr.backward()
+        d_opt.step()
+        out[f"it{it}_scalars"] = np.array([(d_loss_gt + d_loss_sr).item(), pixel.item(), adv.item(),
+                                          torch.sigmoid(torch.mean(gt_output.detach())).item(), torch.sigmoid(torch.mean(sr_output.detach())).item()])
+        out[f"it{it}_sr"] = np_(sr)
+        out[f"it{it}_wsum_g"], out[f"it{it}_wsum_d"] = sd_checksums(g.state_dict()), sd_checksums(d.state_dict())
+    save("esrgan_gan_steps.npz", **out)
+
+
 def gold_validation():
     """Validation / data side: _psnr_torch (BSRGAN/image_quality_assessment.py:361-395) and random_crop
     (BSRGAN/imgproc.py:846-886), imported with an empty `cv2` stub module (neither function touches cv2)."""
@@ -438,6 +491,7 @@ def main():
     gold_aesrgan_gan_steps(MA)
     gold_validation()
     gold_esrgan_discriminator(ME)
+    gold_esrgan_gan_steps(ME)
 
 
 if __name__ == "__main__":

@@ -181,3 +181,54 @@ def test_maxpool_relu_backward_and_l1_sign_kernels():
     torch.cuda.synchronize()
     assert torch.equal(dxa.permute(0, 3, 1, 2).cpu(), z.grad)
     assert torch.equal(out, 0.375 * torch.sign(a - b))
+
+
+def test_esrgan_relativistic_iterations_on_dropin_modules(golden_dir):
+    """The reference's own loop body (ESRGAN/train_esrgan.py:364-431: torch.optim.Adam, BCEWithLogitsLoss, L1Loss, autograd
+    with retain_graph and three live discriminator forwards) over the drop-in RRDBNet / Discriminator modules."""
+    from sr_gan_fd_amd import model as M
+    from tests.util import scaled_init
+    g = load_golden(golden_dir, "esrgan_gan_steps.npz")
+    torch.manual_seed(0)
+    d = M.discriminator()
+    gen = M.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_blocks=2)
+    scaled_init(gen, 3.0, 0.5)
+    d.compute_dtype = gen.compute_dtype = torch.float32
+    d.cuda().train()
+    gen.cuda().train()
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    g_opt = torch.optim.Adam(gen.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    for it in range(2):
+        lr, gt = torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()
+        B = gt.shape[0]
+        real, fake = torch.full([B, 1], 1.0, device="cuda"), torch.full([B, 1], 0.0, device="cuda")
+        for p in d.parameters():
+            p.requires_grad = False
+        gen.zero_grad(set_to_none=True)
+        sr = gen(lr)
+        gt_output = d(gt.detach().clone())
+        sr_output = d(sr)
+        pixel = 0.01 * l1(sr, gt)
+        adv = 0.005 * (bce(gt_output - torch.mean(sr_output), fake) * 0.5 + bce(sr_output - torch.mean(gt_output), real) * 0.5)
+        (pixel + adv).backward()
+        g_opt.step()
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        sr_output = d(sr.detach().clone())
+        d_loss_gt = bce(gt_output - torch.mean(sr_output), real) * 0.5
+        d_loss_gt.backward(retain_graph=True)
+        sr_output = d(sr.detach().clone())
+        d_loss_sr = bce(sr_output - torch.mean(gt_output), fake) * 0.5
+        d_loss_sr.backward()
+        d_opt.step()
+        got = [(d_loss_gt + d_loss_sr).item(), pixel.item(), adv.item(), torch.sigmoid(torch.mean(gt_output.detach())).item(),
+               torch.sigmoid(torch.mean(sr_output.detach())).item()]
+        want = g[f"it{it}_scalars"]
+        print(f"ESRGAN relativistic it{it}: got {got} want {list(want)}")
+        # iteration 1 starts from parameters that already took sign-like Adam steps (eps 1e-8): see the oracle test's note
+        assert np.allclose(got, want, rtol=1e-3 if it == 0 else 2e-2, atol=1e-5)
+        assert _rel(sr, g[f"it{it}_sr"]) < (1e-3 if it == 0 else 2e-2)
+    assert int(d.features[3].num_batches_tracked) == 10          # five training forwards per iteration

@@ -310,3 +310,38 @@ def test_esrgan_discriminator(golden_dir):
     dx, = torch.autograd.grad(O.bce_with_logits_mean(lg, 1.0), xin)
     ref = torch.tensor(g["train2_dx"])
     assert ((dx - ref).norm() / ref.norm()).item() < 1e-3        # L2: single LeakyReLU mask ties move isolated patches (see A-ESRGAN note)
+
+
+def test_esrgan_gan_steps(golden_dir):
+    """two iterations of ESRGAN/train_esrgan.py:364-431 (relativistic-average GAN, BatchNorm discriminator)"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "esrgan_gan_steps.npz")
+    torch.manual_seed(0)
+    d = M.discriminator()
+    gen = M.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_blocks=2)
+    scaled_init(gen, 3.0, 0.5)
+    _check_table(table(g, "wsum_g0"), gen.state_dict(), what="G0")
+    _check_table(table(g, "wsum_d0"), d.state_dict(), what="D0")
+    G = sd_to_params(gen.state_dict())
+    D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    g_opt = O.AdamState(G, O.g_param_names(G))
+    d_opt = O.AdamState(D, [k for k in D if k.endswith((".weight", ".bias"))])
+    for it in range(2):
+        out = O.esrgan_gan_step(G, D, g_opt, d_opt, torch.tensor(g[f"it{it}_lr"]), torch.tensor(g[f"it{it}_gt"]))
+        got = [out["d_loss"], out["pixel_loss"], out["adversarial_loss"], out["d_gt_probability"], out["d_sr_probability"]]
+        want = g[f"it{it}_scalars"]
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-6), f"it{it}: {got} vs {want}"
+        _close(out["sr"], g[f"it{it}_sr"], tol=1e-4, what="sr")
+        # esrgan_config's Adam eps is 1e-8: the first steps are lr * g / (|g| + 1e-8), i.e. lr * sign(g) even for gradient
+        # entries that are rounding noise (near-cancelling bias sums), so a few entries per tensor legitimately land on
+        # the other side; the bound allows ~3 % of a tensor's abs-sum.  Scalars and SR above are the tight checks.
+        at = 5e-2
+        bad = []
+        for k, want_c in table(g, f"it{it}_wsum_g").items():
+            if not np.allclose(checksum(G[k]), want_c, rtol=1e-4, atol=at * abs(want_c[1]) + 1e-9):
+                bad.append((k, checksum(G[k]), want_c))
+        assert not bad, bad[:3]
+        for k, want_c in table(g, f"it{it}_wsum_d").items():
+            if not k.endswith("num_batches_tracked"):
+                assert np.allclose(checksum(D[k]), want_c, rtol=1e-4, atol=at * abs(want_c[1]) + 1e-9), f"D {k}: {checksum(D[k])} vs {want_c}"
