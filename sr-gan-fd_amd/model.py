@@ -110,8 +110,15 @@ class BSRGAN(_RRDBGenerator):
 
 
 class RRDBNet(_RRDBGenerator):
+    """ESRGAN/model.py:144-243 (``num_blocks``) and, for the x4 factory it ships, Real_ESRGAN/model.py:179-262
+    (``num_rrdb``; its PixelUnshuffle is the identity at x4 and both upsampling stages always run)."""
+
     def __init__(self, in_channels: int = 3, out_channels: int = 3, channels: int = 64, growth_channels: int = 32,
-                 num_blocks: int = 23, upscale_factor: int = 4) -> None:
+                 num_blocks: int = 23, upscale_factor: int = 4, num_rrdb: int = None) -> None:
+        if num_rrdb is not None:
+            if upscale_factor != 4:
+                raise ValueError("Real-ESRGAN's RRDBNet is mirrored for upscale_factor=4 only (x2 / x1 use PixelUnshuffle)")
+            num_blocks = num_rrdb
         super().__init__(in_channels, out_channels, channels, growth_channels, num_blocks, upscale_factor, always_up1=False)
 
 
