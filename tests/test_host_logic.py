@@ -91,3 +91,76 @@ def test_flat_params_alias_module_parameters():
         assert list(net.state_dict().keys()) == list(sd0.keys())
     finally:
         A.set_dry_run(False)
+
+
+@pytest.mark.parametrize("which", ["unet", "aesrgan", "esrgan"])
+def test_discriminator_plans_dry_run(which):
+    """the three discriminators' forward / backward launch lists pass the C ABI's argument checks (no kernels run)"""
+    from sr_gan_fd_amd import _abi as A, model as M
+    A.set_dry_run(True)
+    try:
+        d = {"unet": lambda: M.discriminator_unet(in_channels=3, out_channels=1, channels=64), "aesrgan": M.uNetDiscriminatorAesrgan,
+             "esrgan": M.discriminator}[which]()
+        size = 128 if which == "esrgan" else 64
+        for dt in (torch.float32, torch.bfloat16):
+            d.compute_dtype = dt
+            d.train()
+            x = torch.rand(2, 3, size, size, requires_grad=True)
+            out = d(x)
+            assert out.shape == ((2, 1) if which == "esrgan" else (2, 1, size, size))
+            out.sum().backward()
+            assert x.grad is not None and x.grad.shape == x.shape
+            for n, p in d.named_parameters():
+                assert p.grad is not None and p.grad.shape == p.shape, n
+            d.zero_grad(set_to_none=True)
+        if which == "esrgan":
+            with pytest.raises(A.SrganfdError):
+                d(torch.rand(1, 3, 64, 64))            # the classifier fixes the input size (ESRGAN/model.py:129)
+    finally:
+        A.set_dry_run(False)
+
+
+def test_content_losses_and_fused_trainers_dry_run():
+    from sr_gan_fd_amd import _abi as A, model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    A.set_dry_run(True)
+    try:
+        cl5 = M.ContentLoss(nodes, mean, std)
+        cl1 = M.ContentLoss("features.34", mean, std)
+        sr = torch.rand(2, 3, 32, 48, requires_grad=True)
+        gt = torch.rand(2, 3, 32, 48)
+        v5 = cl5(sr, gt)
+        assert v5.shape == (1, 5) and not v5.requires_grad           # detached like torch.Tensor([losses]) (model.py:552)
+        v1 = cl1(sr, gt)
+        assert v1.dim() == 0 and v1.requires_grad                    # ESRGAN's stays in the graph
+        v1.backward()
+        assert sr.grad.shape == sr.shape
+        with pytest.raises(A.SrganfdError):
+            cl1(torch.rand(1, 3, 30, 32), torch.rand(1, 3, 30, 32))   # four 2x2 pools
+        g = M.bsrgan_x4(num_rrdb=1)
+        t = GeneratorTrainer(g, lr=1e-4)
+        assert t.step(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)).shape == (1,)
+        for dfac in (lambda: M.discriminator_unet(in_channels=3, out_channels=1, channels=64), M.uNetDiscriminatorAesrgan):
+            tr = GanTrainer(M.bsrgan_x4(num_rrdb=1), dfac(), M.ContentLoss(nodes, mean, std))
+            assert tr.step(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)).shape == (8,)
+            assert tr.content_vals.shape == (1, 5)
+    finally:
+        A.set_dry_run(False)
+
+
+def test_validation_side_argument_checks():
+    from sr_gan_fd_amd import _abi as A
+    A.set_dry_run(True)
+    try:
+        L = A.lib()
+        buf = torch.zeros(64)
+        p = buf.data_ptr()
+        assert L.srganfd_crop_nchw(p, p, 1, 3, 8, 8, 2, 2, 4, 4, None) == 0
+        assert L.srganfd_crop_nchw(p, p, 1, 3, 8, 8, 6, 2, 4, 4, None) != 0          # window leaves the image
+        assert L.srganfd_psnr(p, p, 1, 3, 8, 8, 2, 1, p, p, None) == 0
+        assert L.srganfd_psnr(p, p, 1, 1, 8, 8, 2, 1, p, p, None) != 0              # luma needs RGB
+        assert L.srganfd_psnr(p, p, 1, 3, 8, 8, 4, 0, p, p, None) != 0              # nothing left after the crop
+    finally:
+        A.set_dry_run(False)
