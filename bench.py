@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   region, against the roof its arithmetic intensity puts it under: algorithmic bytes / time vs the
                   8 TB/s HBM peak when FLOP/byte is below the ridge (312), else algorithmic FLOP / time vs the dense
                   bf16 MFMA peak; both fractions are in the object,
+  sr_parity    -- PSNR (Y, 4-pixel border) and max abs error of the bf16 SR against the fp32 CPU oracle on one image,
   cpu_baseline -- the CPU oracle (oracle/srgan_oracle.py, torch-CPU fp32) timed on this host on a
                   bounded sample (batch 1) of the same workload.
 """
@@ -197,10 +198,42 @@ def main():
                 out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get(out["roofline"]["kernel"])
             out["kernel_classes"] = profiling.summary(rec)
         if not args.no_cpu_baseline:
+            out["sr_parity"] = sr_parity(h, args.num_rrdb, dev)
             out["cpu_baseline"] = cpu_baseline(args.workload, h, args.num_rrdb)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def sr_parity(h: int, num_rrdb: int, dev):
+    """The metric's "PSNR vs ref" leg: SR of the HIP path in the benchmark dtype (bf16) against the CPU oracle (fp32) for one
+    image of the workload's size, same weights (seed 0, the x3 / bias 0.5 init recipe of the parity tests: the default
+    init gives a near-constant SR) and same input.  PSNR through the product's own kernel, on Y with a 4-pixel border crop
+    as the reference's validate() does."""
+    import torch
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.image_quality_assessment import PSNR
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(num_rrdb=num_rrdb)
+    with torch.no_grad():
+        for p in g.parameters():
+            if p.dim() == 4:
+                p.mul_(3.0)
+        g.conv4.bias.fill_(0.5)
+    P = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    x = torch.rand(1, 3, h, h)
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        want = O.rrdbnet_forward(x, P, 4)
+    g.compute_dtype = torch.bfloat16
+    g.to(dev).eval()
+    with torch.no_grad():
+        got = g(x.to(dev))
+        psnr = PSNR(4, True)(got, want.to(dev)).item()
+    err = (got.cpu() - want).abs().max().item()
+    log("SR parity: PSNR(Y) %.2f dB, max abs err %.2e" % (psnr, err))
+    return {"psnr_y_db": round(psnr, 2), "max_abs_err": float("%.3g" % err), "what": "bf16 HIP SR vs fp32 CPU oracle, 1 image %d->%d, scaled init" % (h, 4 * h)}
 
 
 def cpu_baseline(workload: str, h: int, num_rrdb: int):
