@@ -15,7 +15,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     -- dominant kernel class (largest total time) from HIP-event brackets around its launches in the timed
                   region, against the roof its arithmetic intensity puts it under: algorithmic bytes / time vs the
                   8 TB/s HBM peak when FLOP/byte is below the ridge (312), else algorithmic FLOP / time vs the dense
-                  bf16 MFMA peak; both fractions are in the object,
+                  bf16 MFMA peak; both fractions are in the object (events bracket every 7th launch of a class: timing every
+                  launch serialised the queue and cost 8 % of the step),
   sr_parity    -- PSNR (Y, 4-pixel border) and max abs error of the bf16 SR against the fp32 CPU oracle on one image,
   cpu_baseline -- the CPU oracle (oracle/srgan_oracle.py, torch-CPU fp32) timed on this host on a
                   bounded sample (batch 1) of the same workload.

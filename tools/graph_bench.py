@@ -17,6 +17,7 @@ def run(b, h, nrrdb, dtype, graphed, steps=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
-for (b, h, dt) in ((4, 32, torch.bfloat16), (4, 32, torch.float32), (1, 64, torch.bfloat16), (8, 64, torch.bfloat16)):
+cfgs = ((32, 128, torch.bfloat16),) if '--big' in sys.argv else ((4, 32, torch.bfloat16), (4, 32, torch.float32), (1, 64, torch.bfloat16), (8, 64, torch.bfloat16))
+for (b, h, dt) in cfgs:
     e, g = run(b, h, 23, dt, False), run(b, h, 23, dt, True)
     print(f"G-only 23 RRDB B={b} {h}->{4*h} {str(dt)[6:]}: eager {e:7.2f} ms/step ({b/e*1e3:7.1f} img/s)   graph replay {g:7.2f} ms/step ({b/g*1e3:7.1f} img/s)")
