@@ -198,7 +198,7 @@ def main():
             if args.workload == "g_only" and B == 32 and h == 128:   # PMC figures were taken on this exact workload
                 out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get(out["roofline"]["kernel"])
             out["kernel_classes"] = profiling.summary(rec)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # host-side legs: rank 0 of the single-GPU run only
             out["sr_parity"] = sr_parity(h, args.num_rrdb, dev)
             out["cpu_baseline"] = cpu_baseline(args.workload, h, args.num_rrdb)
         print(json.dumps(out), flush=True)
