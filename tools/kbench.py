@@ -28,6 +28,10 @@ if __name__ == "__main__":
     N = 32
     if "--dbg" in sys.argv:
         A.lib().srganfd_set_debug(int(sys.argv[sys.argv.index("--dbg") + 1]))
+    if "--chain" in sys.argv:        # one tile per CU: the latency chain of a single workgroup
+        run("N=8 (1 tile/CU) cin=160 cout=32", 8, 128, 128, 160, 32, 192, 0, 192, 160)
+        run("N=16 (2 tiles/CU) cin=160 cout=32", 16, 128, 128, 160, 32, 192, 0, 192, 160)
+        sys.exit(0)
     if "--batch" in sys.argv:
         for n in (4, 8, 16, 32, 64):
             run(f"N={n} fwd cin=160 cout=32 concat buffer", n, 128, 128, 160, 32, 192, 0, 192, 160)
