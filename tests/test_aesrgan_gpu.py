@@ -185,3 +185,26 @@ def test_aesrgan_gan_steps_fused_trainer(golden_dir, dtype):
         for sd, key in ((gen.state_dict(), f"it{it}_wsum_g"), (d.state_dict(), f"it{it}_wsum_d")):
             for k, want_c in table(g, key).items():
                 assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=at * abs(want_c[1]) + 1e-9), f"{key} {k}: {checksum(sd[k])} vs {want_c}"
+
+
+@pytest.mark.parametrize("size", [(120, 120), (72, 104)])
+def test_aesrgan_discriminator_other_input_sizes(size):
+    """aesrgan_config.py:77 trains on 120x120 crops (15x15 at the bottleneck, 17x17 gating map): odd intermediate sizes and a
+    non-square input against the CPU oracle"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    d = M.uNetDiscriminatorAesrgan()
+    d.compute_dtype = torch.float32
+    P = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    d.cuda().train()
+    x = torch.rand(2, 3, *size)
+    xin = x.clone().cuda().requires_grad_(True)
+    out = d(xin)
+    F.binary_cross_entropy_with_logits(out, torch.ones_like(out)).backward()
+    xo = x.clone().requires_grad_(True)
+    want = O.aesrgan_unet_forward(xo, P, training=True)
+    F.binary_cross_entropy_with_logits(want, torch.ones_like(want)).backward()
+    assert out.shape == want.shape == (2, 1, *size)
+    assert _rel(out, want) < 1e-4
+    assert _rel_l2(xin.grad, xo.grad) < 1e-2          # L2: activation-mask ties (see test_aesrgan_discriminator)
