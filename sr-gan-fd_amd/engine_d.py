@@ -381,8 +381,8 @@ class ContentLossEngine:
         dev = sr.device
         pk = self._ensure_packed(dtc, dev)
         N, Cin, H, W = sr.shape
-        if H % 16 or W % 16:
-            raise A.SrganfdError("ContentLoss input height/width must be multiples of 16 (four 2x2 max-pools)")
+        if H < 16 or W < 16:
+            raise A.SrganfdError("ContentLoss input height/width must be at least 16 (four 2x2 max-pools; odd sizes floor like torch)")
         L, st = A.lib(), A.stream_ptr()
         key = (N, H, W, dtc, str(dev), pk["buf"].data_ptr())
         sp = self.shapes.get(key)
