@@ -77,3 +77,51 @@ def test_shard_rejects_uneven_batch():
     from sr_gan_fd_amd import parallel as P
     with pytest.raises(ValueError):
         P.shard(torch.zeros(5, 3), 0, 2)
+
+
+def _trainer_worker(rank, world, port, q):
+    """The fused trainers' data-parallel exchange on two gloo ranks, with the HIP library in dry-run mode (no kernels run: the
+    values are meaningless, what is checked is that both ranks issue the same collectives in the same order on tensors of
+    the same size, once per network per iteration, and that the 1/world scale reaches the optimizer)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from sr_gan_fd_amd import _abi as A, model as M, parallel as P
+    from sr_gan_fd_amd.gan import GanTrainer
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    A.set_dry_run(True)
+    r, lr_, w, pg = P.init_from_env("gloo")
+    calls = []
+    orig = dist.all_reduce
+
+    def spy(t, *a, **k):
+        calls.append(t.numel())
+        return orig(t, *a, **k)
+    dist.all_reduce = spy
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(num_rrdb=1)
+    tr = GeneratorTrainer(g, lr=1e-4, process_group=pg)
+    lr_img, gt = torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)
+    tr.step(lr_img, gt)
+    ok1 = calls == [tr.flat.numel()]
+    calls.clear()
+    gan = GanTrainer(M.bsrgan_x4(num_rrdb=1), M.discriminator_unet(in_channels=3, out_channels=1, channels=64), None, process_group=pg)
+    gan.step(lr_img, gt)
+    ok2 = calls == [gan.de.fp.total, gan.ge.fp.total]            # D after its second backward, then G (gan.py)
+    dist.barrier()
+    q.put((rank, ok1, ok2, calls))
+    dist.destroy_process_group()
+
+
+def test_trainers_exchange_one_flat_gradient_per_network():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2], f"rank {r[0]}: {r}"
