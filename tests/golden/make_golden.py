@@ -408,7 +408,7 @@ def gold_esrgan_gan_steps(ME):
     bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
     d.train()
     g.train()
-    B = 4
+    B = 2
     out["wsum_g0"], out["wsum_d0"] = sd_checksums(g.state_dict()), sd_checksums(d.state_dict())
     for it in range(2):
         lr, gt = torch.rand(B, 3, 32, 32), torch.rand(B, 3, 128, 128)
@@ -439,7 +439,7 @@ def gold_esrgan_gan_steps(ME):
         d_opt.step()
         out[f"it{it}_scalars"] = np.array([(d_loss_gt + d_loss_sr).item(), pixel.item(), adv.item(),
                                           torch.sigmoid(torch.mean(gt_output.detach())).item(), torch.sigmoid(torch.mean(sr_output.detach())).item()])
-        out[f"it{it}_sr"] = np_(sr)
+        out[f"it{it}_sr"] = np_(sr[:, :, ::4, ::4])          # every 4th pixel (fixture size)
         out[f"it{it}_wsum_g"], out[f"it{it}_wsum_d"] = sd_checksums(g.state_dict()), sd_checksums(d.state_dict())
     save("esrgan_gan_steps.npz", **out)
 

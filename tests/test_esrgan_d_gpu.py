@@ -230,5 +230,5 @@ def test_esrgan_relativistic_iterations_on_dropin_modules(golden_dir):
         print(f"ESRGAN relativistic it{it}: got {got} want {list(want)}")
         # iteration 1 starts from parameters that already took sign-like Adam steps (eps 1e-8): see the oracle test's note
         assert np.allclose(got, want, rtol=1e-3 if it == 0 else 2e-2, atol=1e-5)
-        assert _rel(sr, g[f"it{it}_sr"]) < (1e-3 if it == 0 else 2e-2)
+        assert _rel(sr[:, :, ::4, ::4], g[f"it{it}_sr"]) < (1e-3 if it == 0 else 2e-2)
     assert int(d.features[3].num_batches_tracked) == 10          # five training forwards per iteration

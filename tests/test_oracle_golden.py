@@ -332,7 +332,7 @@ def test_esrgan_gan_steps(golden_dir):
         got = [out["d_loss"], out["pixel_loss"], out["adversarial_loss"], out["d_gt_probability"], out["d_sr_probability"]]
         want = g[f"it{it}_scalars"]
         assert np.allclose(got, want, rtol=1e-4, atol=1e-6), f"it{it}: {got} vs {want}"
-        _close(out["sr"], g[f"it{it}_sr"], tol=1e-4, what="sr")
+        _close(out["sr"][:, :, ::4, ::4], g[f"it{it}_sr"], tol=1e-4, what="sr")
         # esrgan_config's Adam eps is 1e-8: the first steps are lr * g / (|g| + 1e-8), i.e. lr * sign(g) even for gradient
         # entries that are rounding noise (near-cancelling bias sums), so a few entries per tensor legitimately land on
         # the other side; the bound allows ~3 % of a tensor's abs-sum.  Scalars and SR above are the tight checks.
