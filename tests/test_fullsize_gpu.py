@@ -1,0 +1,96 @@
+"""Parity through size-independent properties at BASELINE.json's full configuration (configs[1]: 23 RRDB, batch 32,
+128x128 -> 512x512, bf16), where the CPU oracle would need minutes per case: run-to-run determinism of a training
+iteration (the reductions are ordered, no float atomics), data-parallel shard equivalence of the full-batch gradient,
+linearity of the fused convolution, and spot checks of full-size kernel outputs against direct dot products."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import scaled_init
+
+pytestmark = pytest.mark.gpu
+B, H = 32, 128
+
+
+def _gen(seed=0):
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(seed)
+    g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
+    scaled_init(g, 3.0, 0.5)
+    g.compute_dtype = torch.bfloat16
+    return g.cuda().train()
+
+
+def _batch():
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    return torch.rand(B, 3, H, H, device="cuda", generator=gen), torch.rand(B, 3, 4 * H, 4 * H, device="cuda", generator=gen)
+
+
+def test_full_size_iteration_is_bitwise_reproducible():
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    lr, gt = _batch()
+    out = []
+    for _ in range(2):
+        tr = GeneratorTrainer(_gen(), lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999)
+        losses = [tr.step(lr, gt).item() for _ in range(2)]
+        out.append((losses, tr.flat.clone(), tr.opt.ema.clone(), tr.sr.clone()))
+        del tr
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+    assert np.isfinite(out[0][0]).all() and 0.0 < out[0][0][0] < 1.0
+
+
+def test_full_size_shards_equal_full_batch():
+    """(e): mean of the two 16-image shard gradients == the 32-image gradient (bf16 activations: L2 bound)"""
+    from sr_gan_fd_amd.engine import generator_engine
+    g = _gen()
+    lr, gt = _batch()
+
+    def flat_grad(x, y):
+        g.zero_grad(set_to_none=True)
+        F.l1_loss(g(x), y).backward()
+        return torch.cat([p.grad.reshape(-1) for p in g.parameters()]).double()
+    full = flat_grad(lr, gt)
+    halves = 0.5 * (flat_grad(lr[:16], gt[:16]) + flat_grad(lr[16:], gt[16:]))
+    e = ((halves - full).norm() / full.norm()).item()
+    print(f"full-size shard equivalence: relative L2 difference {e:.2e}")
+    assert e < 1e-3           # identical per-image arithmetic; only the fp32 summation grouping differs
+
+
+def test_full_size_conv_linearity_and_spot_values():
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(2)
+    n, h, w, cin, cout = B, H, H, 192, 64
+    wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+    x1 = torch.randn(n, h, w, cin, device="cuda")
+    x2 = torch.randn(n, h, w, cin, device="cuda")
+
+    def conv(x, dt):
+        dtc = ops.DT[dt]
+        xx = x.to(dt)
+        y = torch.empty(n, h, w, cout, device="cuda", dtype=dt)
+        ops.conv2d(ops.conv_args(dtc, A.view(xx), A.view(y), ops.pack_single(wt, dtc), n, h, w, cin, cout))
+        torch.cuda.synchronize()
+        return y.float()
+    # linearity in exact-fp32 mode: conv(x1 + x2) == conv(x1) + conv(x2) up to fp32 summation order
+    lin = conv(x1 + x2, torch.float32) - (conv(x1, torch.float32) + conv(x2, torch.float32))
+    ref_scale = conv(x1, torch.float32).abs().max().item()
+    assert lin.abs().max().item() < 1e-4 * ref_scale
+    # spot values of the bf16 launch against direct dot products of the bf16-rounded operands (fp64 on the host)
+    y = conv(x1, torch.bfloat16)
+    xb, wb = x1.bfloat16().double().cpu(), wt.bfloat16().double().cpu()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(40):
+        i, oy, ox, co = rng.integers(n), rng.integers(h), rng.integers(w), rng.integers(cout)
+        acc = 0.0
+        for ky in range(3):
+            for kx in range(3):
+                yy, xx_ = oy + ky - 1, ox + kx - 1
+                if 0 <= yy < h and 0 <= xx_ < w:
+                    acc += float((xb[i, yy, xx_] * wb[co, :, ky, kx]).sum())
+        worst = max(worst, abs(y[i, oy, ox, co].item() - acc) / ref_scale)
+    print(f"full-size conv spot check: worst error {worst:.2e} of the output scale")
+    assert worst < 4e-3       # the stored result is rounded to bf16 (2^-9 relative)
