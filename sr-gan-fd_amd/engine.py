@@ -96,6 +96,14 @@ class FlatParams:
             return True
         return False
 
+    def new_grad(self, device) -> Tensor:
+        """Flat gradient buffer.  Tensors whose size is not a multiple of 4 leave alignment gaps that no kernel writes: zero
+        them (the optimizer walks the whole buffer), otherwise the gaps of the parameter buffer pick up allocator garbage and
+        two identical runs stop being bitwise equal (found by tests/test_fullsize_gpu.py)."""
+        if self.total == sum(self.numels):
+            return torch.empty(self.total, dtype=torch.float32, device=device)
+        return torch.zeros(self.total, dtype=torch.float32, device=device)
+
     def grad_views(self, flat_grad: Tensor) -> List[Tensor]:
         return [flat_grad[o:o + n].view(s) for o, n, s in zip(self.offsets, self.numels, self.shapes)]
 
@@ -426,7 +434,7 @@ class TrunkEngine:
         L, st = A.lib(), A.stream_ptr()
         N, H, W, dtc = sp.N, sp.H, sp.W, sp.dtc
         dout = dout.contiguous().float()
-        flat_grad = torch.empty(self.fp.total, dtype=torch.float32, device=sp.device)
+        flat_grad = self.fp.new_grad(sp.device)
         if self.full:
             A.check(L.srganfd_clamp_grad_to_nhwc(dout.data_ptr(), A.view(sp.srp), N, self.out_ch, sp.hs, sp.ws, A.view(sp.dsrp), dtc, 32, st), "clamp_grad")
         else:

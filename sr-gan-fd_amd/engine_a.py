@@ -358,7 +358,7 @@ class AesrganDiscriminatorEngine:
         sp.bw = bw
         sp.dx_conv = ops.conv_args(dtc, V(G["dx0"]), V(sp.dxp), Wp("b", "conv0"), N, H, W, nf, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        sp.gtmp = torch.empty(self.fp.total, dtype=torch.float32, device=device)
+        sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
         sp.sn_ws = torch.empty(2048, dtype=torch.float32, device=device)
 
     # ---- execution ----
@@ -416,7 +416,7 @@ class AesrganDiscriminatorEngine:
         A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, 32, None, None, st), "nchw_to_nhwc")
         flat = self.fp.flat
         # the flat gradient also receives BatchNorm's dgamma/dbeta; frozen-parameter passes write them to scratch
-        flat_grad = torch.empty(self.fp.total, dtype=torch.float32, device=sp.device) if need_wgrad else sp.gtmp
+        flat_grad = self.fp.new_grad(sp.device) if need_wgrad else sp.gtmp
         rec = profiling.REC
         for item in sp.bw:
             kind = item[0]

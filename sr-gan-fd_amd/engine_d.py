@@ -234,7 +234,7 @@ class DiscriminatorEngine:
         sp.bw = bw
         sp.dx_conv = ops.conv_args(dtc, V(gD), V(sp.dxp), wptr + O[("b", "conv1")], N, H, W, 64, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        sp.gtmp = torch.empty(self.fp.total, dtype=torch.float32, device=device)
+        sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
         sp.sn_ws = torch.empty(2048, dtype=torch.float32, device=device)
 
     # ---- execution ----
@@ -277,7 +277,7 @@ class DiscriminatorEngine:
         dlogits = dlogits.contiguous().float()
         A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, 32, None, None, st), "nchw_to_nhwc")
         flat = self.fp.flat
-        flat_grad = torch.empty(self.fp.total, dtype=torch.float32, device=sp.device) if need_wgrad else None
+        flat_grad = self.fp.new_grad(sp.device) if need_wgrad else None
         rec = profiling.REC
         for item in sp.bw:
             kind = item[0]

@@ -204,7 +204,7 @@ class EsrganDiscriminatorEngine:
         sp.dxp = torch.empty(N, sp.H, sp.W, 4, dtype=torch.float32, device=device)
         sp.dx_conv = ops.conv_args(dtc, V(dA), V(sp.dxp), wptr + O[("b", 0)], N, sp.H, sp.W, 64, 32, cout_store=3, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        sp.gtmp = torch.empty(self.fp.total, dtype=torch.float32, device=device)
+        sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
 
     # ---- execution ----
     def _conv(self, L, st, a, rec, what):
@@ -260,7 +260,7 @@ class EsrganDiscriminatorEngine:
         dlogits = dlogits.contiguous().float()
         A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, 1, 1, A.view(sp.dl), dtc, 32, None, None, st), "nchw_to_nhwc")
         flat = self.fp.flat
-        flat_grad = torch.empty(self.fp.total, dtype=torch.float32, device=sp.device) if need_wgrad else sp.gtmp
+        flat_grad = self.fp.new_grad(sp.device) if need_wgrad else sp.gtmp
         rec = profiling.REC
         for item in sp.bw:
             kind = item[0]

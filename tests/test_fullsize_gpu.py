@@ -94,3 +94,29 @@ def test_full_size_conv_linearity_and_spot_values():
         worst = max(worst, abs(y[i, oy, ox, co].item() - acc) / ref_scale)
     print(f"full-size conv spot check: worst error {worst:.2e} of the output scale")
     assert worst < 4e-3       # the stored result is rounded to bf16 (2^-9 relative)
+
+
+def test_full_size_gan_iteration_is_bitwise_reproducible():
+    """configs[2]: RRDBNet + U-Net discriminator + VGG-19 content loss, batch 32, 128 -> 512, bf16"""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    lr, gt = _batch()
+    out = []
+    for _ in range(2):
+        g = _gen()
+        torch.manual_seed(1)
+        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        cl = M.ContentLoss(nodes, mean, std)
+        d.compute_dtype = cl.compute_dtype = torch.bfloat16
+        tr = GanTrainer(g, d.cuda().train(), cl.cuda())
+        s = tr.step(lr, gt).clone()
+        out.append((s, tr.g_opt.flat.clone(), tr.d_opt.flat.clone(), tr.content_vals.clone()))
+        del tr, g, d, cl
+        torch.cuda.empty_cache()
+    for name, a, b in zip(("scalars", "G parameters", "D parameters", "content values"), out[0], out[1]):
+        if not torch.equal(a, b):
+            idx = (a != b).nonzero().flatten()
+            raise AssertionError(f"{name}: {idx.numel()} of {a.numel()} elements differ, first at {idx[:5].tolist()}: {a[idx[:5]].tolist()} vs {b[idx[:5]].tolist()}")
+    s = out[0][0].cpu().numpy()
+    assert np.isfinite(s).all() and 0.0 < s[4] < 1.0 and 0.0 < s[5] < 1.0       # D(gt), D(sr) are probabilities
