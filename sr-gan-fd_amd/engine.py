@@ -488,6 +488,12 @@ def _engine(owner: nn.Module, factory):
     eng = _ENGINES.get(owner)
     if eng is None:
         eng = factory()
+        # the registry is keyed weakly by the module; the engine must not keep the module alive in turn, or the entry --
+        # and every activation buffer of the engine -- would never be released (found at 286 GB by test_fullsize_gpu.py)
+        if getattr(eng, "owner", None) is owner:
+            eng.owner = weakref.proxy(owner)
+        if hasattr(eng, "rdbs"):                      # a stand-alone dense block is its own engine's only block
+            eng.rdbs = [weakref.proxy(m) if m is owner else m for m in eng.rdbs]
         _ENGINES[owner] = eng
     return eng
 
