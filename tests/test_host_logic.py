@@ -164,3 +164,36 @@ def test_validation_side_argument_checks():
         assert L.srganfd_psnr(p, p, 1, 3, 8, 8, 4, 0, p, p, None) != 0              # nothing left after the crop
     finally:
         A.set_dry_run(False)
+
+
+def test_modules_deepcopy_and_pickle_like_the_train_scripts_do():
+    """AveragedModel deep-copies the generator (train_bsrgan.py:291) and mlflow.pytorch.log_model pickles both networks
+    (:203-213): copies must carry the same state_dict, own their parameters, and still run"""
+    import copy
+    import pickle
+    from sr_gan_fd_amd import _abi as A, model as M
+    A.set_dry_run(True)
+    try:
+        nodes, mean, std = ["features.2", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        mods = [M.bsrgan_x4(num_rrdb=1), M.rrdbnet_x4(num_blocks=1), M.discriminator_unet(in_channels=3, out_channels=1, channels=64),
+                M.uNetDiscriminatorAesrgan(), M.discriminator(), M.ContentLoss(nodes, mean, std)]
+        for m in mods:
+            if not isinstance(m, M.ContentLoss):
+                m(torch.rand(1, 3, 128, 128) if isinstance(m, M.Discriminator) else torch.rand(1, 3, 64, 64))   # build the engine first
+            for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+                assert type(clone) is type(m)
+                sd, sc = m.state_dict(), clone.state_dict()
+                assert list(sd) == list(sc) and all(torch.equal(sd[k], sc[k]) for k in sd)
+                p0, c0 = next(m.parameters()), next(clone.parameters())
+                assert p0.data_ptr() != c0.data_ptr()
+                with torch.no_grad():
+                    c0.add_(1.0)
+                assert not torch.equal(p0, c0)                       # no aliasing of the flat parameter buffers
+                if isinstance(m, M.ContentLoss):
+                    assert clone(torch.rand(1, 3, 32, 32), torch.rand(1, 3, 32, 32)).shape == (1, 2)
+                elif isinstance(m, M.Discriminator):
+                    assert clone(torch.rand(1, 3, 128, 128)).shape == (1, 1)
+                else:
+                    clone(torch.rand(1, 3, 64, 64))
+    finally:
+        A.set_dry_run(False)
