@@ -66,3 +66,29 @@ def test_checkpoint_roundtrip_and_ragged_inference(tmp_path, golden_dir):
     err = (sr.cpu() - want).abs().max().item()
     print("ragged inference max err", err, "PSNR vs oracle", PSNR(4, True)(sr, want.cuda()).item())
     assert err < 1e-3
+
+
+def test_parameter_changes_behind_the_engine_are_picked_up():
+    """load_state_dict after a forward, in-place edits, and a .cpu()/.cuda() round trip must all reach the packed weights"""
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    a = M.bsrgan_x4(num_rrdb=1)
+    scaled_init(a, 3.0, 0.5)
+    torch.manual_seed(1)
+    b = M.bsrgan_x4(num_rrdb=1)
+    scaled_init(b, 2.0, 0.4)
+    a.compute_dtype = b.compute_dtype = torch.float32
+    a.cuda().eval()
+    b.cuda().eval()
+    x = torch.rand(1, 3, 24, 24, device="cuda")
+    with torch.no_grad():
+        ya, yb = a(x), b(x)
+        assert not torch.equal(ya, yb)
+        a.load_state_dict(b.state_dict())                    # engine of `a` already built and packed
+        assert torch.equal(a(x), yb)
+        a.conv4.bias.add_(0.125)                             # in-place edit
+        y2 = a(x)
+        assert torch.allclose(y2, (yb + 0.125).clamp(0, 1), atol=1e-6) and not torch.equal(y2, yb)
+        a.cpu()
+        a.cuda()                                             # parameters moved: the flat buffer is rebuilt
+        assert torch.equal(a(x), y2)
