@@ -300,3 +300,29 @@ def test_data_parallel_shards_equal_full_batch():
     full = flat_grad(lr, gt)
     halves = 0.5 * (flat_grad(lr[:2], gt[:2]) + flat_grad(lr[2:], gt[2:]))
     assert _rel(halves, full) < 1e-4
+
+
+def test_train_generator_false_freezes_generator_only():
+    """bsrgan_config.train_generator = False (train_bsrgan.py:460): every forward still runs, D steps, G and its EMA do not"""
+    from sr_gan_fd_amd.gan import GanTrainer
+    gen, d = _build_gan(torch.float32)
+    tr = GanTrainer(gen, d, None, train_generator=False)
+    g0, d0 = tr.g_opt.flat.clone(), tr.d_opt.flat.clone()
+    s = tr.step(torch.rand(2, 3, 16, 16, device="cuda"), torch.rand(2, 3, 64, 64, device="cuda")).cpu().numpy()
+    assert np.isfinite(s).all() and s[2] > 0 and s[3] > 0          # pixel and adversarial losses were evaluated
+    assert torch.equal(tr.g_opt.flat, g0) and not torch.equal(tr.d_opt.flat, d0)
+    assert tr.g_opt.t == 0 and tr.d_opt.t == 1
+
+
+def test_stale_activations_are_refused_not_silently_used():
+    """a second training forward of the same network overwrites the saved activations: backward through the first one
+    must fail loudly instead of producing a gradient from the wrong activations"""
+    from sr_gan_fd_amd import _abi as A
+    gen, _ = _build_gan(torch.float32)
+    x1 = torch.rand(1, 3, 16, 16, device="cuda")
+    y1 = gen(x1)
+    y2 = gen(torch.rand(1, 3, 16, 16, device="cuda"))
+    with pytest.raises(A.SrganfdError):
+        y1.sum().backward()
+    y2.sum().backward()                                            # the latest forward is still valid
+    assert all(p.grad is not None for p in gen.parameters())
