@@ -158,3 +158,60 @@ def test_config5_iteration_is_bitwise_reproducible():
     for name, a, b in zip(("scalars", "G parameters", "D parameters", "BatchNorm running_var"), out[0], out[1]):
         assert torch.equal(a, b), name
     assert np.isfinite(out[0][0].cpu().numpy()).all()
+
+
+def test_config5_discriminator_addresses_beyond_2_31_elements():
+    """The 128-channel 768x768 concat of the attention U-Net holds 2.4e9 elements at batch 32 (64-bit per-image bases in the
+    conv / elementwise kernels).  In eval mode (BatchNorm running statistics) images are independent, so the logits of the
+    LAST images of the batch -- the ones behind the 2^31 boundary -- must equal those of the same images pushed through alone."""
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(1)
+    d = M.uNetDiscriminatorAesrgan()
+    d.compute_dtype = torch.bfloat16
+    d.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.rand(B, 3, 768, 768, device="cuda", generator=gen)
+    with torch.no_grad():
+        full = d(x)
+        for k in (0, 27, 31):
+            one = d(x[k:k + 1].contiguous())
+            assert torch.equal(full[k], one[0]), f"image {k}: max diff {(full[k] - one[0]).abs().max().item():.3e}"
+    assert torch.isfinite(full).all()
+
+
+def test_kernels_beyond_2_31_elements():
+    """conv (forward with residual + mask epilogue) and weight gradient on a 32 x 768 x 768 x 128 tensor (2.4e9 elements):
+    the last image's results must equal a launch on that image alone."""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(5)
+    n, h, w, cin, cout = B, 768, 768, 128, 64
+    dtc = A.BF16
+    x = torch.zeros(n, h, w, cin, device="cuda", dtype=torch.bfloat16)
+    assert x.numel() > 2 ** 31
+    k = n - 1
+    x[k] = torch.randn(h, w, cin, device="cuda").bfloat16()
+    r1 = torch.zeros(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    r1[k] = torch.randn(h, w, cout, device="cuda").bfloat16()
+    m = torch.randn(n, h, w, cout, device="cuda").bfloat16()
+    wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+    wp = ops.pack_single(wt, dtc)
+    y = torch.empty(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    ops.conv2d(ops.conv_args(dtc, A.view(x), A.view(y), wp, n, h, w, cin, cout, r1=A.view(r1), r1_scale=0.5, mask=A.view(m), mask_slope=0.2))
+    y1 = torch.empty(1, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    xk, rk, mk = x[k:k + 1].contiguous(), r1[k:k + 1].contiguous(), m[k:k + 1].contiguous()
+    ops.conv2d(ops.conv_args(dtc, A.view(xk), A.view(y1), wp, 1, h, w, cin, cout, r1=A.view(rk), r1_scale=0.5, mask=A.view(mk), mask_slope=0.2))
+    torch.cuda.synchronize()
+    assert torch.equal(y[k], y1[0]) and float(y1.float().abs().sum()) > 0
+    assert float(y[:k].float().abs().sum()) == 0.0                    # zero input, zero residual -> zero output everywhere else
+    # weight gradient: only image k is non-zero on both sides, so the 32-image reduction must equal the single-image one
+    dy = torch.zeros(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    dy[k] = torch.randn(h, w, cout, device="cuda").bfloat16()
+    conv = [dict(cin=cin, cout=cout, dw_off=0, co_dst=cout, ci_dst=cin, db_off=cout * cin * 9)]
+    g_all, g_one = torch.zeros(cout * cin * 9 + cout, device="cuda"), torch.zeros(cout * cin * 9 + cout, device="cuda")
+    for nn_, xx, dd, gg in ((n, x, dy, g_all), (1, xk, dy[k:k + 1].contiguous(), g_one)):
+        plan = ops.WgradPlan(x.device, dtc, nn_, h, w, cin, cout, conv)
+        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
+        plan.run(A.view(xx), A.view(dd), gg, ws)
+    torch.cuda.synchronize()
+    scale = g_one.abs().max().item()
+    assert scale > 0 and (g_all - g_one).abs().max().item() < 1e-5 * scale      # same products, different slab grouping
