@@ -326,3 +326,58 @@ def test_stale_activations_are_refused_not_silently_used():
         y1.sum().backward()
     y2.sum().backward()                                            # the latest forward is still valid
     assert all(p.grad is not None for p in gen.parameters())
+
+
+def test_two_rank_gan_iteration_equals_full_batch_iteration():
+    """SURVEY 8(e) for the whole GAN iteration: two data-parallel ranks (two trainers in two threads of this process, their
+    all-reduce emulated by a barrier + sum) on two 2-image shards == one trainer on the 4-image batch (f32 mode)."""
+    import threading
+    from sr_gan_fd_amd.gan import GanTrainer
+
+    class Exchange:
+        def __init__(self, world):
+            self.world, self.slots, self.bar = world, {}, threading.Barrier(world)
+
+        def allreduce(self, rank, t):
+            self.slots[rank] = t
+            self.bar.wait()
+            torch.cuda.synchronize()
+            total = sum(self.slots[r] for r in range(self.world))
+            self.bar.wait()
+            t.copy_(total)
+            self.bar.wait()
+            return 1.0 / self.world
+
+    torch.manual_seed(3)
+    lr, gt = torch.rand(4, 3, 16, 16).cuda(), torch.rand(4, 3, 64, 64).cuda()
+    gen, d = _build_gan(torch.float32)
+    ref = GanTrainer(gen, d, None)
+    s_ref = ref.step(lr, gt).cpu().numpy().copy()
+    ex = Exchange(2)
+    trainers, scalars, errors = [], [None, None], []
+    for r in range(2):
+        g_r, d_r = _build_gan(torch.float32)
+        t = GanTrainer(g_r, d_r, None)
+        t._allreduce = (lambda grad, r=r: ex.allreduce(r, grad))
+        trainers.append(t)
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                scalars[r] = trainers[r].step(lr[2 * r:2 * r + 2].contiguous(), gt[2 * r:2 * r + 2].contiguous()).cpu().numpy().copy()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+            ex.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    # every rank ends with the same parameters as the single-process step on the concatenated batch
+    for t in trainers:
+        assert _rel(t.g_opt.flat, ref.g_opt.flat) < 1e-4 and _rel(t.d_opt.flat, ref.d_opt.flat) < 1e-4
+    assert torch.equal(trainers[0].g_opt.flat, trainers[1].g_opt.flat) and torch.equal(trainers[0].d_opt.flat, trainers[1].d_opt.flat)
+    # the logged scalars are shard means: their average is the full-batch value
+    assert np.allclose(0.5 * (scalars[0] + scalars[1])[:6], s_ref[:6], rtol=1e-4, atol=1e-6)
