@@ -8,6 +8,7 @@ Tolerances (relative to the tensor's max magnitude):
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from tests.util import checksum, load_golden, scaled_init, table
 
@@ -119,3 +120,28 @@ def test_state_dict_roundtrip_and_deepcopy(golden_dir):
     with torch.no_grad():
         assert torch.equal(fresh(x), sr)
     assert _rel(sr, g["bsrgan_x4_r2_s3/sr"]) < 1e-3
+
+
+def test_bf16_gradient_fidelity_23_blocks():
+    """The benchmark dtype against the exact-fp32 mode through all 23 RRDBs (351 convs forward, the same backward): the bf16
+    flat gradient must point the same way as the f32 one -- cosine similarity, relative norm -- not just be finite."""
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
+    scaled_init(g, 3.0, 0.5)
+    g.cuda().train()
+    lr, gt = torch.rand(4, 3, 48, 48, device="cuda"), torch.rand(4, 3, 192, 192, device="cuda")
+    grads, losses = {}, {}
+    for dt in (torch.float32, torch.bfloat16):
+        g.compute_dtype = dt
+        g.zero_grad(set_to_none=True)
+        loss = F.l1_loss(g(lr), gt)
+        loss.backward()
+        grads[dt] = torch.cat([p.grad.reshape(-1) for p in g.parameters()]).double()
+        losses[dt] = loss.item()
+    a, b = grads[torch.float32], grads[torch.bfloat16]
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    ratio = (b.norm() / a.norm()).item()
+    print(f"23-block gradient: bf16 vs f32 cosine {cos:.4f}, norm ratio {ratio:.4f}, loss {losses[torch.bfloat16]:.6f} vs {losses[torch.float32]:.6f}")
+    assert cos > 0.98 and 0.9 < ratio < 1.1
+    assert abs(losses[torch.bfloat16] - losses[torch.float32]) < 5e-3 * losses[torch.float32]
