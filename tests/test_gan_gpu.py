@@ -381,3 +381,20 @@ def test_two_rank_gan_iteration_equals_full_batch_iteration():
     assert torch.equal(trainers[0].g_opt.flat, trainers[1].g_opt.flat) and torch.equal(trainers[0].d_opt.flat, trainers[1].d_opt.flat)
     # the logged scalars are shard means: their average is the full-batch value
     assert np.allclose(0.5 * (scalars[0] + scalars[1])[:6], s_ref[:6], rtol=1e-4, atol=1e-6)
+
+
+def test_fused_gan_trainer_discriminator_learns():
+    """over a fixed batch the discriminator must pull D(gt) and D(sr) apart (bf16, the benchmark dtype): sign / scale errors in the
+    BCE gradient, the spectral-norm backward or the D Adam step would stall this"""
+    from sr_gan_fd_amd.gan import GanTrainer
+    gen, d = _build_gan(torch.bfloat16)
+    tr = GanTrainer(gen, d, None, d_lr=1e-3)
+    torch.manual_seed(9)
+    lr = torch.rand(2, 3, 16, 16, device="cuda")
+    gt = F.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    hist = np.stack([tr.step(lr, gt).cpu().numpy().copy() for _ in range(25)])
+    d_loss = hist[:, 0] + hist[:, 1]
+    print("d_loss", np.round(d_loss[::6], 4), "D(gt)", np.round(hist[::6, 4], 3), "D(sr)", np.round(hist[::6, 5], 3))
+    assert np.isfinite(hist).all()
+    assert d_loss[-3:].mean() < d_loss[0] - 0.1 and d_loss[-1] < d_loss[12] < d_loss[0]      # steady descent from ~2 ln 2
+    assert hist[-1, 4] > hist[-1, 5]                      # real scored above fake
