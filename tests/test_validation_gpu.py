@@ -92,3 +92,29 @@ def test_parameter_changes_behind_the_engine_are_picked_up():
         a.cpu()
         a.cuda()                                             # parameters moved: the flat buffer is rebuilt
         assert torch.equal(a(x), y2)
+
+
+def test_cuda_prefetcher_feeds_the_hip_path():
+    """dataset.CUDAPrefetcher (interface of BSRGAN/dataset.py:203-243): batches staged on a copy stream are consumed by kernels
+    launched through the C ABI on the current stream; values must be those of the source batches, in order, for two epochs"""
+    from sr_gan_fd_amd.dataset import CUDAPrefetcher
+    from sr_gan_fd_amd.image_quality_assessment import PSNR
+    torch.manual_seed(0)
+    batches = [{"gt": torch.rand(2, 3, 64, 64).pin_memory(), "lr": torch.rand(2, 3, 16, 16).pin_memory(), "name": f"b{i}"} for i in range(4)]
+    pf = CUDAPrefetcher(batches, torch.device("cuda", 0))
+    assert len(pf) == 4
+    psnr = PSNR(0, True)
+    for epoch in range(2):
+        seen = 0
+        batch = pf.next()
+        while batch is not None:
+            src = batches[seen]
+            assert batch["name"] == src["name"] and batch["gt"].is_cuda and batch["lr"].is_cuda
+            # identical images -> the PSNR kernel's error term is the 1e-8 floor: 10*log10(255^2 / 1e-8)
+            val = psnr(batch["gt"], src["gt"].cuda())
+            assert torch.allclose(val, torch.full_like(val, 10 * np.log10(255.0 ** 2 / 1e-8)), atol=1e-6)
+            assert torch.equal(batch["lr"].cpu(), src["lr"])
+            seen += 1
+            batch = pf.next()
+        assert seen == 4
+        pf.reset()
