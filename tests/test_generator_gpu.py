@@ -164,3 +164,38 @@ def test_fused_trainer_actually_learns():
     print("over-fit losses:", [round(v, 4) for v in losses[::10]], round(losses[-1], 4))
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.75 * losses[0] and min(losses[-5:]) < min(losses[:5])
+
+
+def test_reference_amp_wrappers_may_stay():
+    """the scripts' ``amp.autocast()`` + ``GradScaler`` (train_bsrnet.py:250-262) wrap the drop-in module
+    unchanged -- the scaled loss is back-propagated through the HIP path and unscaled by the scaler; the step must equal the
+    plain fp32-loss step."""
+    from torch import amp
+    from sr_gan_fd_amd import model as M
+
+    def build():
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+        scaled_init(g, 3.0, 0.5)
+        g.compute_dtype = torch.float32
+        return g.cuda().train()
+    lr, gt = torch.rand(2, 3, 16, 16, device="cuda"), torch.rand(2, 3, 64, 64, device="cuda")
+    a, b = build(), build()
+    oa = torch.optim.Adam(a.parameters(), 1e-4, (0.9, 0.99), 1e-4)
+    ob = torch.optim.Adam(b.parameters(), 1e-4, (0.9, 0.99), 1e-4)
+    scaler = amp.GradScaler("cuda")
+    for _ in range(2):
+        a.zero_grad(set_to_none=True)
+        with amp.autocast("cuda"):
+            loss_a = F.l1_loss(a(lr), gt)
+        scaler.scale(loss_a).backward()
+        scaler.step(oa)
+        scaler.update()
+        b.zero_grad(set_to_none=True)
+        loss_b = F.l1_loss(b(lr), gt)
+        loss_b.backward()
+        ob.step()
+        assert abs(loss_a.item() - loss_b.item()) < 1e-5
+    fa = torch.cat([p.detach().reshape(-1) for p in a.parameters()])
+    fb = torch.cat([p.detach().reshape(-1) for p in b.parameters()])
+    assert ((fa - fb).abs().max() / fb.abs().max()).item() < 1e-5
