@@ -272,6 +272,14 @@ int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_
  * y_only = BT.601 luma of RGB first (imgproc.py:757-767); out: n doubles (dB); workspace: n * 64 doubles. */
 int srganfd_psnr(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border,
                  int32_t y_only, double* out, double* workspace, void* stream);
+/* SSIM per image (image_quality_assessment.py:420-494, the SSIM module at :497-532): same inputs / crop / luma as
+ * srganfd_psnr; `window` = window_size x window_size fp64 filter in device memory (the reference's outer product of
+ * cv2.getGaussianKernel(11, 1.5)), window_size <= 16, valid padding; moments and map in fp64, out: n floats (the mean of
+ * the map over channels and pixels, cast like the reference's .float()).  workspace: srganfd_ssim_workspace_doubles(). */
+int64_t srganfd_ssim_workspace_doubles(int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only,
+                                       int32_t window_size);
+int srganfd_ssim(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border,
+                 int32_t y_only, const double* window, int32_t window_size, float* out, double* workspace, void* stream);
 
 #ifdef __cplusplus
 }

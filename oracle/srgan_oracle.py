@@ -244,6 +244,49 @@ def psnr_y(raw: Tensor, dst: Tensor, crop_border: int = 0, only_test_y_channel: 
     return 10 * torch.log10(255.0 ** 2 / mse)
 
 
+def gaussian_window(window_size: int = 11, sigma: float = 1.5):
+    """SSIM.__init__ -- BSRGAN/image_quality_assessment.py:520-521: outer product of cv2.getGaussianKernel(ws, sigma) with
+    itself.  OpenCV (a third-party dependency absent from this image; any 4.x) documents that kernel as
+    G_i = alpha * exp(-(i-(ksize-1)/2)^2 / (2 sigma^2)), sum(G) = 1, computed in fp64 -- restated here."""
+    import numpy as np
+    x = np.arange(window_size, dtype=np.float64) - (window_size - 1) / 2.0
+    g = np.exp(-(x ** 2) / (2.0 * sigma ** 2))
+    g = g / g.sum()
+    return np.outer(g, g)
+
+
+def ssim(raw: Tensor, dst: Tensor, crop_border: int = 0, only_test_y_channel: bool = True, window=None) -> Tensor:
+    """_ssim_single_torch + _ssim_torch -- BSRGAN/image_quality_assessment.py:420-494: crop, fp32 luma, fp64 x255, five
+    valid-padding grouped filterings with the 2-D window, SSIM map, mean over (C,H,W), cast to fp32."""
+    import numpy as np
+    window = gaussian_window() if window is None else window
+    ws = window.shape[0]
+    if crop_border > 0:
+        raw = raw[:, :, crop_border:-crop_border, crop_border:-crop_border]
+        dst = dst[:, :, crop_border:-crop_border, crop_border:-crop_border]
+    if only_test_y_channel:
+        wy = torch.tensor([[65.481], [128.553], [24.966]], dtype=raw.dtype)
+
+        def to_y(t: Tensor) -> Tensor:
+            return (torch.matmul(t.permute(0, 2, 3, 1), wy).permute(0, 3, 1, 2) + 16.0) / 255.0
+        raw, dst = to_y(raw), to_y(dst)
+    a = raw.to(torch.float64).numpy() * 255.0
+    b = dst.to(torch.float64).numpy() * 255.0
+    oh, ow = a.shape[2] - ws + 1, a.shape[3] - ws + 1
+
+    def filt(t):
+        acc = np.zeros(t.shape[:2] + (oh, ow), dtype=np.float64)
+        for ky in range(ws):
+            for kx in range(ws):
+                acc += window[ky, kx] * t[:, :, ky:ky + oh, kx:kx + ow]
+        return acc
+    c1, c2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+    ma, mb = filt(a), filt(b)
+    va, vb, cab = filt(a * a) - ma ** 2, filt(b * b) - mb ** 2, filt(a * b) - ma * mb
+    m = ((2 * ma * mb + c1) * (2 * cab + c2)) / ((ma ** 2 + mb ** 2 + c1) * (va + vb + c2))
+    return torch.from_numpy(m.mean(axis=(1, 2, 3))).float()
+
+
 def random_crop(gt: Tensor, lr: Tensor, gt_image_size: int, upscale_factor: int, rng=None) -> Tuple[Tensor, Tensor]:
     """random_crop -- BSRGAN/imgproc.py:846-886: ONE (top, left) for the whole batch from Python's `random` stream
     (randint for the row first, then the column), LR window at the integer-divided position; outputs take lr's dtype."""

@@ -103,6 +103,8 @@ SYMBOLS = {
     "srganfd_nhwc_to_nchw_scaled": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_crop_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "srganfd_psnr": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_ssim_workspace_doubles": (C.c_int64, [C.c_int32] * 7),
+    "srganfd_ssim": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_gate_mul": (C.c_int, [C.c_int32, View, C.c_void_p, View, View, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "srganfd_batchnorm_fwd": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -45,6 +45,9 @@ int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, 
                       int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
+int64_t ssim_workspace_doubles(int n, int c, int h, int w, int crop_border, int y_only, int ws);
+int ssim_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, const double* window, int ws, float* out,
+              double* wsp, hipStream_t s);
 int sigmoid_impl(float* x, size_t n, hipStream_t s);
 int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hipStream_t s);
 int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s);
@@ -161,6 +164,13 @@ int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_
 int srganfd_psnr(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only, double* out,
                  double* workspace, void* stream) {
   return psnr_impl(a, b, n, c, h, w, crop_border, y_only, out, workspace, (hipStream_t)stream);
+}
+int64_t srganfd_ssim_workspace_doubles(int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only, int32_t window_size) {
+  return ssim_workspace_doubles(n, c, h, w, crop_border, y_only, window_size);
+}
+int srganfd_ssim(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only, const double* window,
+                 int32_t window_size, float* out, double* workspace, void* stream) {
+  return ssim_impl(a, b, n, c, h, w, crop_border, y_only, window, window_size, out, workspace, (hipStream_t)stream);
 }
 int srganfd_add_relu(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, void* stream) {
   return add_relu_impl(a, b, out, dtype, (size_t)npix, c, (hipStream_t)stream);

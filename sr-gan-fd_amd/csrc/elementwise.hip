@@ -951,6 +951,82 @@ __global__ void psnr_finish_kernel(const double* __restrict__ partial, int nblk,
   }
 }
 
+// SSIM (image_quality_assessment.py:420-494): border crop, optional BT.601 luma in fp32 (imgproc.py:757-767), x255 in
+// fp64, then the five window-filtered moments (valid padding, any ws x ws window handed over by the caller) and the
+// SSIM map, all in fp64 like the reference; the map is averaged over every channel and pixel of an image.
+// grid (tiles_x * tiles_y, channels, n): a 16x16 output tile per block, its (16+ws-1)^2 inputs staged once in LDS.
+static constexpr int kSsimTile = 16, kSsimMaxWin = 16;
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int c, int h, int w, int cb,
+                                                           int y_only, const double* __restrict__ window, int ws, int tiles_x,
+                                                           double* __restrict__ partial) {
+  constexpr int kIn = kSsimTile + kSsimMaxWin - 1;
+  __shared__ double sa[kIn * kIn], sb[kIn * kIn], sw[kSsimMaxWin * kSsimMaxWin], red[256];
+  const int img = blockIdx.z, ch = blockIdx.y;
+  const int hh = h - 2 * cb, ww = w - 2 * cb;           // cropped image
+  const int oh = hh - ws + 1, ow = ww - ws + 1;          // SSIM map
+  const int ty0 = (blockIdx.x / tiles_x) * kSsimTile, tx0 = (blockIdx.x % tiles_x) * kSsimTile;
+  const size_t plane = (size_t)h * w;
+  const float* pa = a + (size_t)img * c * plane;
+  const float* pb = b + (size_t)img * c * plane;
+  const int in = kSsimTile + ws - 1;
+  for (int i = threadIdx.x; i < ws * ws; i += 256) sw[i] = window[i];
+  for (int i = threadIdx.x; i < in * in; i += 256) {
+    const int iy = i / in, ix = i % in;
+    const int y = ty0 + iy, x = tx0 + ix;
+    double va = 0.0, vb = 0.0;
+    if (y < hh && x < ww) {
+      const size_t o = (size_t)(y + cb) * w + (x + cb);
+      if (y_only) {
+        float ya = pa[o] * 65.481f; ya = fmaf(pa[plane + o], 128.553f, ya); ya = fmaf(pa[2 * plane + o], 24.966f, ya); ya = (ya + 16.0f) / 255.f;
+        float yb = pb[o] * 65.481f; yb = fmaf(pb[plane + o], 128.553f, yb); yb = fmaf(pb[2 * plane + o], 24.966f, yb); yb = (yb + 16.0f) / 255.f;
+        va = (double)ya * 255.0; vb = (double)yb * 255.0;
+      } else {
+        va = (double)pa[ch * plane + o] * 255.0; vb = (double)pb[ch * plane + o] * 255.0;
+      }
+    }
+    sa[iy * in + ix] = va; sb[iy * in + ix] = vb;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / kSsimTile, lx = threadIdx.x % kSsimTile;
+  double val = 0.0;
+  if (ty0 + ly < oh && tx0 + lx < ow) {
+    double ma = 0.0, mb = 0.0, saa = 0.0, sbb = 0.0, sab = 0.0;
+    for (int ky = 0; ky < ws; ++ky)
+      for (int kx = 0; kx < ws; ++kx) {
+        const double g = sw[ky * ws + kx];
+        const double xa = sa[(ly + ky) * in + lx + kx], xb = sb[(ly + ky) * in + lx + kx];
+        ma = fma(g, xa, ma); mb = fma(g, xb, mb);
+        saa = fma(g, xa * xa, saa); sbb = fma(g, xb * xb, sbb); sab = fma(g, xa * xb, sab);
+      }
+    const double c1 = (0.01 * 255.0) * (0.01 * 255.0), c2 = (0.03 * 255.0) * (0.03 * 255.0);
+    const double ma2 = ma * ma, mb2 = mb * mb, mab = ma * mb;
+    const double num = (2.0 * mab + c1) * (2.0 * (sab - mab) + c2);
+    const double den = (ma2 + mb2 + c1) * ((saa - ma2) + (sbb - mb2) + c2);
+    val = num / den;
+  }
+  red[threadIdx.x] = val;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[((size_t)img * gridDim.y + ch) * gridDim.x + blockIdx.x] = red[0];
+}
+// one block per image: fixed-order tree over its (channels * tiles) partials, then the mean (cast to fp32 like .float())
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const double* __restrict__ partial, int per_img, double count, float* __restrict__ out) {
+  __shared__ double red[256];
+  const double* p = partial + (size_t)blockIdx.x * per_img;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < per_img; k += 256) s += p[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] / count);
+}
+
 // ---- differentiable VGG tap (ESRGAN/model.py:281-292): gradient of mean |a - b| w.r.t. a, max-pool backward with the
 // preceding ReLU's derivative folded in, and the relayout that also undoes the 1/std of the input normalisation ----
 template <typename T>
@@ -1340,6 +1416,26 @@ int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int cr
   SRGANFD_LAUNCH(psnr_partial_kernel, dim3(kPsnrBlocks, n), dim3(256), 0, s, a, b, c, h, w, crop_border, y_only, ws);
   const double count = (double)(y_only ? 1 : c) * (h - 2 * crop_border) * (w - 2 * crop_border);
   SRGANFD_LAUNCH(psnr_finish_kernel, dim3(n), dim3(64), 0, s, (const double*)ws, kPsnrBlocks, count, out);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+int64_t ssim_workspace_doubles(int n, int c, int h, int w, int crop_border, int y_only, int ws) {
+  const int oh = h - 2 * crop_border - ws + 1, ow = w - 2 * crop_border - ws + 1;
+  if (n <= 0 || c <= 0 || oh <= 0 || ow <= 0) return 0;
+  const int64_t tiles = (int64_t)((oh + kSsimTile - 1) / kSsimTile) * ((ow + kSsimTile - 1) / kSsimTile);
+  return (int64_t)n * (y_only ? 1 : c) * tiles;
+}
+int ssim_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, const double* window, int ws, float* out,
+              double* wsp, hipStream_t s) {
+  const int oh = h - 2 * crop_border - ws + 1, ow = w - 2 * crop_border - ws + 1;
+  if (!a || !b || !out || !wsp || !window || n <= 0 || c <= 0 || crop_border < 0 || ws < 1 || ws > kSsimMaxWin || oh <= 0 || ow <= 0 ||
+      (y_only && c != 3) || n > 65535 || c > 65535)
+    return set_err(SRGANFD_EINVAL, "ssim: bad args (window 1..%d inside the cropped image; Y channel needs 3-channel RGB input)", kSsimMaxWin);
+  const int tiles_x = (ow + kSsimTile - 1) / kSsimTile, tiles_y = (oh + kSsimTile - 1) / kSsimTile;
+  const int ce = y_only ? 1 : c;
+  SRGANFD_LAUNCH(ssim_partial_kernel, dim3(tiles_x * tiles_y, ce, n), dim3(256), 0, s, a, b, c, h, w, crop_border, y_only, window, ws, tiles_x, wsp);
+  SRGANFD_LAUNCH(ssim_finish_kernel, dim3(n), dim3(256), 0, s, (const double*)wsp, ce * tiles_x * tiles_y, (double)ce * oh * ow, out);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -467,6 +467,20 @@ def gold_validation():
     out["psnr_y_cb4"] = np_(iqa._psnr_torch(a, b, 4, True))
     out["psnr_rgb_cb4"] = np_(iqa._psnr_torch(a, b, 4, False))
     out["psnr_y_cb0"] = np_(iqa.PSNR(0, True)(a, b))
+    # SSIM (image_quality_assessment.py:420-494).  The SSIM module's constructor calls cv2.getGaussianKernel (OpenCV is not
+    # in this image), so the module-level functions it forwards to are called directly with the window OpenCV documents:
+    # G_i ~ exp(-(i-5)^2 / (2*1.5^2)), normalised, outer product (image_quality_assessment.py:520-521).
+    xs = np.arange(11, dtype=np.float64) - 5.0
+    gk = np.exp(-(xs ** 2) / (2.0 * 1.5 ** 2))
+    gk = (gk / gk.sum()).reshape(11, 1)
+    win = np.outer(gk, gk.transpose())
+    out["ssim_window"] = win
+    out["ssim_y_cb4"] = np_(iqa._ssim_single_torch(a, b, 4, True, 11, win))
+    out["ssim_rgb_cb4"] = np_(iqa._ssim_single_torch(a, b, 4, False, 11, win))
+    out["ssim_y_cb0"] = np_(iqa._ssim_single_torch(a, b, 0, True, 11, win))
+    out["ssim_y_rolled"] = np_(iqa._ssim_single_torch(a, torch.roll(b, 3, dims=3), 0, True, 11, win))   # decorrelated pair
+    box = np.full((7, 7), 1.0 / 49.0)
+    out["ssim_box7_rgb_cb2"] = np_(iqa._ssim_single_torch(a, b, 2, False, 7, box))
     gt = torch.rand(2, 3, 48, 64)
     lr = torch.rand(2, 3, 12, 16)
     out["crop_gt"], out["crop_lr"] = np_(gt), np_(lr)
@@ -479,6 +493,8 @@ def gold_validation():
 
 def main():
     torch.set_num_threads(8)
+    if "--only-validation" in sys.argv:
+        return gold_validation()
     MB = load_ref("BSRGAN")
     ME = load_ref("ESRGAN")
     gold_blocks(MB)

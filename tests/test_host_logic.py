@@ -162,6 +162,13 @@ def test_validation_side_argument_checks():
         assert L.srganfd_psnr(p, p, 1, 3, 8, 8, 2, 1, p, p, None) == 0
         assert L.srganfd_psnr(p, p, 1, 1, 8, 8, 2, 1, p, p, None) != 0              # luma needs RGB
         assert L.srganfd_psnr(p, p, 1, 3, 8, 8, 4, 0, p, p, None) != 0              # nothing left after the crop
+        assert L.srganfd_ssim_workspace_doubles(2, 3, 40, 56, 4, 1, 11) == 2 * 1 * 2 * 3   # 22x38 map -> 2x3 tiles of 16x16
+        assert L.srganfd_ssim_workspace_doubles(2, 3, 40, 56, 4, 0, 11) == 2 * 3 * 2 * 3
+        assert L.srganfd_ssim_workspace_doubles(1, 3, 12, 12, 1, 1, 11) == 0               # window larger than the cropped image
+        assert L.srganfd_ssim(p, p, 1, 3, 16, 16, 2, 1, p, 11, p, p, None) == 0
+        assert L.srganfd_ssim(p, p, 1, 3, 12, 12, 1, 1, p, 11, p, p, None) != 0            # window does not fit
+        assert L.srganfd_ssim(p, p, 1, 1, 16, 16, 0, 1, p, 11, p, p, None) != 0            # luma needs RGB
+        assert L.srganfd_ssim(p, p, 1, 3, 32, 32, 0, 0, p, 17, p, p, None) != 0            # window above the kernel's LDS tile
     finally:
         A.set_dry_run(False)
 

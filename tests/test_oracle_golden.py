@@ -251,7 +251,7 @@ def test_aesrgan_gan_steps(golden_dir):
 
 
 def test_validation_side(golden_dir):
-    """_psnr_torch and random_crop restatements vs vectors captured from the reference (cv2 stubbed: neither uses it)"""
+    """_psnr_torch, _ssim_torch and random_crop restatements vs vectors captured from the reference (cv2 stubbed: neither uses it)"""
     import random
     from oracle import srgan_oracle as O
     g = load_golden(golden_dir, "validation.npz")
@@ -259,6 +259,13 @@ def test_validation_side(golden_dir):
     assert np.allclose(O.psnr_y(a, b, 4, True).numpy(), g["psnr_y_cb4"], rtol=0, atol=1e-9)
     assert np.allclose(O.psnr_y(a, b, 4, False).numpy(), g["psnr_rgb_cb4"], rtol=0, atol=1e-9)
     assert np.allclose(O.psnr_y(a, b, 0, True).numpy(), g["psnr_y_cb0"], rtol=0, atol=1e-9)
+    # SSIM (image_quality_assessment.py:420-494): the reference's own functions were driven with the documented OpenCV window
+    assert np.allclose(O.gaussian_window(11, 1.5), g["ssim_window"], rtol=0, atol=1e-16)
+    for cb, y, key in ((4, True, "ssim_y_cb4"), (4, False, "ssim_rgb_cb4"), (0, True, "ssim_y_cb0")):
+        assert np.allclose(O.ssim(a, b, cb, y).numpy(), g[key], rtol=0, atol=1e-7), key
+    assert np.allclose(O.ssim(a, torch.roll(b, 3, dims=3), 0, True).numpy(), g["ssim_y_rolled"], rtol=0, atol=1e-7)
+    assert np.allclose(O.ssim(a, b, 2, False, np.full((7, 7), 1.0 / 49.0)).numpy(), g["ssim_box7_rgb_cb2"], rtol=0, atol=1e-7)
+    assert np.allclose(O.ssim(a, a, 0, True).numpy(), 1.0, rtol=0, atol=1e-7)                       # identical images
     gt, lr = torch.tensor(g["crop_gt"]), torch.tensor(g["crop_lr"])
     for seed in (7, 11):
         random.seed(seed)

@@ -22,6 +22,37 @@ def test_psnr_matches_reference(golden_dir):
         assert got.dtype == np.float64 and np.allclose(got, g[key], rtol=0, atol=1e-4)   # dB; the luma is fp32 in both
 
 
+def test_ssim_matches_reference(golden_dir):
+    """SSIM module vs values captured from the reference's _ssim_single_torch (fp64 maths on both sides; the result is fp32)"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd.image_quality_assessment import SSIM, gaussian_kernel_1d
+    g = load_golden(golden_dir, "validation.npz")
+    a, b = torch.tensor(g["psnr_a"]).cuda(), torch.tensor(g["psnr_b"]).cuda()
+    assert np.allclose(SSIM(0, True).gaussian_kernel_window, g["ssim_window"], rtol=0, atol=1e-16)
+    assert gaussian_kernel_1d(11, 1.5).shape == (11, 1)
+    for cb, y, key in ((4, True, "ssim_y_cb4"), (4, False, "ssim_rgb_cb4"), (0, True, "ssim_y_cb0")):
+        got = SSIM(cb, y)(a, b).cpu().numpy()
+        print(key, got, g[key])
+        assert got.dtype == np.float32 and np.allclose(got, g[key], rtol=0, atol=1e-6), key
+    got = SSIM(0, True)(a, torch.roll(b, 3, dims=3)).cpu().numpy()
+    assert np.allclose(got, g["ssim_y_rolled"], rtol=0, atol=1e-6)
+    box = SSIM(2, False, window_size=7)
+    box.gaussian_kernel_window = np.full((7, 7), 1.0 / 49.0)            # any 2-D window, as _ssim_torch accepts
+    assert np.allclose(box(a, b).cpu().numpy(), g["ssim_box7_rgb_cb2"], rtol=0, atol=1e-6)
+    assert np.allclose(SSIM(0, True)(a, a).cpu().numpy(), 1.0, rtol=0, atol=1e-6)
+    # ragged sizes (map not a multiple of the 16x16 tile, one-pixel map) against the oracle
+    torch.manual_seed(3)
+    for shape, cb in (((2, 3, 11, 11), 0), ((1, 3, 29, 75), 3), ((3, 3, 64, 33), 0)):
+        x = torch.rand(shape)
+        y2 = (x + 0.1 * torch.randn(shape)).clamp(0, 1)
+        for yo in (True, False):
+            want = O.ssim(x, y2, cb, yo).numpy()
+            got = SSIM(cb, yo)(x.cuda(), y2.cuda()).cpu().numpy()
+            assert np.allclose(got, want, rtol=0, atol=1e-6), (shape, cb, yo, got, want)
+    with pytest.raises(Exception):
+        SSIM(0, True)(torch.rand(1, 3, 8, 8).cuda(), torch.rand(1, 3, 8, 8).cuda())     # 11x11 window does not fit
+
+
 def test_random_crop_matches_reference(golden_dir):
     from sr_gan_fd_amd import imgproc
     g = load_golden(golden_dir, "validation.npz")
