@@ -281,6 +281,27 @@ int64_t srganfd_ssim_workspace_doubles(int32_t n, int32_t c, int32_t h, int32_t 
 int srganfd_ssim(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border,
                  int32_t y_only, const double* window, int32_t window_size, float* out, double* workspace, void* stream);
 
+/* ---- Real-ESRGAN on-device degradation (Real_ESRGAN/imgproc.py) ----
+ * filter2d_torch (imgproc.py:1092-1124): NCHW fp32 image (b,c,h,w), reflect padding k/2, cross-correlation of every
+ * channel of image n with kernels[n] (kernel_batch == b) or the one shared kernel (kernel_batch == 1); k odd, <= 51
+ * ("Wrong kernel size." for an even k, like the reference's ValueError). */
+int srganfd_filter2d(const float* image, const float* kernels, int32_t kernel_batch, int32_t b, int32_t c, int32_t h,
+                     int32_t w, int32_t k, float* out, void* stream);
+/* USMSharp.forward (imgproc.py:1529-1540): blur with the shared k x k kernel, residual, |residual|*255 > threshold mask,
+ * blurred mask, blend -- two fused filter passes.  workspace: 2 * b*c*h*w floats. */
+int srganfd_usm_sharp(const float* image, const float* kernel, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k,
+                      float weight, float threshold, float* out, float* workspace, void* stream);
+/* DiffJPEG.forward (imgproc.py:1465-1497): RGB NCHW fp32 in [0,1] -> JPEG round trip (4:2:0, zero-padded to multiples of
+ * 16, cropped back).  quality: b floats in device memory, converted IN PLACE to the compression factor
+ * (imgproc.py:1127-1144, :1476-1480) unless quality_is_factor; differentiable = the cubic rounding of :1183-1195.
+ * tables: srganfd_diff_jpeg_table_floats() floats in device memory, filled on the host by srganfd_diff_jpeg_tables(). */
+int32_t srganfd_diff_jpeg_table_floats(void);
+int srganfd_diff_jpeg_tables(float* host_out);
+int srganfd_diff_jpeg(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, float* quality,
+                      int32_t quality_is_factor, int32_t differentiable, const float* tables, float* out, void* stream);
+/* last line of degradation_process (imgproc.py:2460): dst = clamp(round(src * 255), 0, 255) / 255 (may alias) */
+int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

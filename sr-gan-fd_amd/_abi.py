@@ -103,6 +103,12 @@ SYMBOLS = {
     "srganfd_nhwc_to_nchw_scaled": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_crop_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "srganfd_psnr": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_filter2d": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "srganfd_usm_sharp": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_diff_jpeg_table_floats": (C.c_int32, []),
+    "srganfd_diff_jpeg_tables": (C.c_int, [C.c_void_p]),
+    "srganfd_diff_jpeg": (C.c_int, [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_ssim_workspace_doubles": (C.c_int64, [C.c_int32] * 7),
     "srganfd_ssim": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_gate_mul": (C.c_int, [C.c_int32, View, C.c_void_p, View, View, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),

@@ -45,6 +45,13 @@ int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, 
                       int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
+int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
+                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s);
+void diff_jpeg_tables_host(float* t);
+int jpeg_table_floats();
+int diff_jpeg_impl(const float* src, int b, int c, int h, int w, float* quality, int quality_is_factor, int differentiable, const float* tables,
+                   float* dst, hipStream_t s);
+int quantize_u8_impl(const float* src, float* dst, size_t n, hipStream_t s);
 int64_t ssim_workspace_doubles(int n, int c, int h, int w, int crop_border, int y_only, int ws);
 int ssim_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, const double* window, int ws, float* out,
               double* wsp, hipStream_t s);
@@ -171,6 +178,33 @@ int64_t srganfd_ssim_workspace_doubles(int32_t n, int32_t c, int32_t h, int32_t 
 int srganfd_ssim(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only, const double* window,
                  int32_t window_size, float* out, double* workspace, void* stream) {
   return ssim_impl(a, b, n, c, h, w, crop_border, y_only, window, window_size, out, workspace, (hipStream_t)stream);
+}
+int srganfd_filter2d(const float* image, const float* kernels, int32_t kernel_batch, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k, float* out,
+                     void* stream) {
+  return filter2d_impl(image, kernels, kernel_batch, b, c, h, w, k, 0, nullptr, nullptr, 0.f, 0.f, out, nullptr, (hipStream_t)stream);
+}
+int srganfd_usm_sharp(const float* image, const float* kernel, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k, float weight, float threshold,
+                      float* out, float* workspace, void* stream) {
+  if (!workspace) return set_err(SRGANFD_EINVAL, "usm_sharp: workspace of 2 * b*c*h*w floats needed");
+  const size_t n = (size_t)b * c * h * w;
+  float* residual = workspace;
+  float* mask = workspace + n;
+  int rc = filter2d_impl(image, kernel, 1, b, c, h, w, k, 1, nullptr, nullptr, weight, threshold, residual, mask, (hipStream_t)stream);
+  if (rc != SRGANFD_OK) return rc;
+  return filter2d_impl(mask, kernel, 1, b, c, h, w, k, 2, image, residual, weight, threshold, out, nullptr, (hipStream_t)stream);
+}
+int32_t srganfd_diff_jpeg_table_floats(void) { return jpeg_table_floats(); }
+int srganfd_diff_jpeg_tables(float* host_out) {
+  if (!host_out) return set_err(SRGANFD_EINVAL, "diff_jpeg_tables: null output");
+  diff_jpeg_tables_host(host_out);
+  return SRGANFD_OK;
+}
+int srganfd_diff_jpeg(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, float* quality, int32_t quality_is_factor,
+                      int32_t differentiable, const float* tables, float* out, void* stream) {
+  return diff_jpeg_impl(image, b, c, h, w, quality, quality_is_factor, differentiable, tables, out, (hipStream_t)stream);
+}
+int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream) {
+  return quantize_u8_impl(src, dst, numel > 0 ? (size_t)numel : 0, (hipStream_t)stream);
 }
 int srganfd_add_relu(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, void* stream) {
   return add_relu_impl(a, b, out, dtype, (size_t)npix, c, (hipStream_t)stream);

@@ -1,0 +1,293 @@
+// degrade.hip -- the device-resident stages of Real-ESRGAN's second-order degradation (SURVEY 8f N4;
+// reference: Real_ESRGAN/imgproc.py:1092-1124 filter2d_torch, :1183-1497 DiffJPEG, :1517-1540 USMSharp, :2323-2462
+// degradation_process).  All of them are per-image, HBM-bound fp32 NCHW passes: each kernel reads its input once into
+// LDS tiles, does the whole stage on chip and writes the result once.
+#include <math.h>
+#include "common.hpp"
+
+namespace srganfd {
+
+// ---------------------------------------------------------------------------------------------------------------
+// filter2d_torch (imgproc.py:1092-1124): reflect-pad by k/2, then cross-correlate every channel of image n with kernel
+// n (or the one shared kernel).  A 256-thread block owns a 32-row x 64-column output tile: thread (tx, ty) -> column tx,
+// rows 8*ty .. 8*ty+7, sliding an 8-deep register window down its LDS column so that one LDS read feeds 8 FMAs; the
+// filter taps are wave-uniform (scalar loads).  The USM sharpener's two passes (imgproc.py:1529-1540) are epilogues:
+//   mode 1: residual = x - blur -> out;  mask = (|residual| * 255 > threshold) -> out2
+//   mode 2: soft = blur(mask);  out = soft * clip(x + weight * residual, 0, 1) + (1 - soft) * x
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kF2dRows = 32, kF2dCols = 64, kF2dMaxK = 51;
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return min(max(i, 0), n - 1);   // only positions no output reads get clamped
+}
+
+__global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__ src, const float* __restrict__ kernels, int kernel_batch, int c, int h,
+                                                       int w, int k, int tiles_x, int mode, const float* __restrict__ x_in,
+                                                       const float* __restrict__ res_in, float weight, float threshold, float* __restrict__ out,
+                                                       float* __restrict__ out2) {
+  constexpr int kPitch = kF2dCols + kF2dMaxK - 1;               // 114
+  constexpr int kTileRows = kF2dRows + kF2dMaxK - 1 + 8;        // the unrolled window may address (never use) 8 rows past the halo
+  __shared__ float tile[kTileRows * kPitch];
+  const int plane = blockIdx.y, img = plane / c;
+  const int ty_base = (blockIdx.x / tiles_x) * kF2dRows, tx_base = (blockIdx.x % tiles_x) * kF2dCols;
+  const float* sp = src + (size_t)plane * h * w;
+  const float* kw = kernels + (kernel_batch > 1 ? (size_t)img * k * k : 0);
+  const int r = k / 2, in_rows = kF2dRows + k - 1, in_cols = kF2dCols + k - 1;
+  for (int i = threadIdx.x; i < in_rows * in_cols; i += 256) {
+    const int iy = i / in_cols, ix = i % in_cols;
+    tile[iy * kPitch + ix] = sp[(size_t)reflect_idx(ty_base + iy - r, h) * w + reflect_idx(tx_base + ix - r, w)];
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty0 = (threadIdx.x >> 6) * 8;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  for (int kx = 0; kx < k; ++kx) {
+    const float* col = tile + ty0 * kPitch + tx + kx;
+    float win[8];
+#pragma unroll
+    for (int o = 0; o < 7; ++o) win[o] = col[o * kPitch];
+    for (int ky0 = 0; ky0 < k; ky0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ky = ky0 + j;
+        if (ky < k) {                                          // wave-uniform
+          win[(j + 7) & 7] = col[(ky + 7) * kPitch];
+          const float wv = kw[ky * k + kx];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[o] = fmaf(wv, win[(j + o) & 7], acc[o]);
+        }
+      }
+    }
+  }
+  const int x = tx_base + tx;
+  if (x >= w) return;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const int y = ty_base + ty0 + o;
+    if (y >= h) break;
+    const size_t idx = (size_t)plane * h * w + (size_t)y * w + x;
+    if (mode == 0) {
+      out[idx] = acc[o];
+    } else if (mode == 1) {
+      const float res = sp[(size_t)y * w + x] - acc[o];
+      out[idx] = res;
+      out2[idx] = (fabsf(res) * 255.f > threshold) ? 1.f : 0.f;
+    } else {
+      const float xv = x_in[idx], soft = acc[o];
+      const float sharp = fminf(fmaxf(xv + weight * res_in[idx], 0.f), 1.f);
+      out[idx] = soft * sharp + (1.f - soft) * xv;
+    }
+  }
+}
+
+int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
+                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s) {
+  if (!src || !kernels || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0) return set_err(SRGANFD_EINVAL, "filter2d: null / empty argument");
+  if (k % 2 == 0 || k < 1) return set_err(SRGANFD_EINVAL, "Wrong kernel size.");                     // the reference's ValueError text
+  if (k > kF2dMaxK) return set_err(SRGANFD_EINVAL, "filter2d: kernel size %d above the LDS tile's %d", k, kF2dMaxK);
+  if (k / 2 >= h || k / 2 >= w) return set_err(SRGANFD_EINVAL, "filter2d: reflect padding %d needs an image larger than that (%dx%d)", k / 2, h, w);
+  if (kernel_batch != 1 && kernel_batch != b) return set_err(SRGANFD_EINVAL, "filter2d: %d kernels for %d images", kernel_batch, b);
+  if ((mode == 1 && !out2) || (mode == 2 && (!x_in || !res_in)) || mode < 0 || mode > 2) return set_err(SRGANFD_EINVAL, "filter2d: bad epilogue arguments");
+  if ((long long)b * c > 65535) return set_err(SRGANFD_EINVAL, "filter2d: more than 65535 planes");
+  const int tiles_x = ceil_div(w, kF2dCols), tiles_y = ceil_div(h, kF2dRows);
+  SRGANFD_LAUNCH(filter2d_kernel, dim3(tiles_x * tiles_y, b * c), dim3(256), 0, s, src, kernels, kernel_batch, c, h, w, k, tiles_x, mode, x_in, res_in,
+                 weight, threshold, out, out2);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DiffJPEG (imgproc.py:1198-1497): x255, RGB -> YCbCr, 2x2 chroma average, per 8x8 block DCT -> divide by
+// table * factor -> round (or the cubic "differentiable" rounding, :1183-1195) -> multiply back -> inverse DCT, chroma
+// repeat, YCbCr -> RGB, clamp to [0, 255], /255; the image is zero-padded to multiples of 16 and cropped back
+// (:1482-1495).  One wavefront owns one 16x16 MCU (4 luma blocks + Cb + Cr) from load to store; nothing but the RGB
+// input and output touches HBM.  Lane l owns the 2x2 pixel quad (l/8, l%8) on the way in and out, and coefficient /
+// pixel (l/8, l%8) of each 8x8 block in between.  The 4-D cosine tensors are the reference's fp32 products (:1250-1252,
+// :1366-1368), summed over all 64 terms like its tensordot.
+// tables: [dct 4096 | idct 4096 | dct scale 64 | idct alpha 64 | y_table 64 | c_table 64] floats.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kJpegTableFloats = 4096 * 2 + 64 * 4;
+
+void diff_jpeg_tables_host(float* t) {
+  static const float y_std[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                  14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+  static const float c_small[16] = {17, 18, 24, 47, 18, 21, 26, 66, 24, 26, 56, 99, 47, 66, 99, 99};
+  const double pi = 3.14159265358979323846;
+  float* dct = t;
+  float* idct = t + 4096;
+  float* scale = t + 8192;
+  float* alpha = scale + 64;
+  float* ytab = alpha + 64;
+  float* ctab = ytab + 64;
+  for (int x = 0; x < 8; ++x)
+    for (int y = 0; y < 8; ++y)
+      for (int u = 0; u < 8; ++u)
+        for (int v = 0; v < 8; ++v) {
+          dct[((x * 8 + y) * 8 + u) * 8 + v] = (float)(cos((2 * x + 1) * u * pi / 16) * cos((2 * y + 1) * v * pi / 16));
+          idct[((x * 8 + y) * 8 + u) * 8 + v] = (float)(cos((2 * u + 1) * x * pi / 16) * cos((2 * v + 1) * y * pi / 16));
+        }
+  for (int u = 0; u < 8; ++u)
+    for (int v = 0; v < 8; ++v) {
+      const double au = u == 0 ? 1.0 / sqrt(2.0) : 1.0, av = v == 0 ? 1.0 / sqrt(2.0) : 1.0;
+      scale[u * 8 + v] = (float)(au * av * 0.25);
+      alpha[u * 8 + v] = (float)(au * av);
+      ytab[u * 8 + v] = y_std[v * 8 + u];                                    // the reference transposes the standard table (:43-48)
+      ctab[u * 8 + v] = (u < 4 && v < 4) ? c_small[v * 4 + u] : 99.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void diff_jpeg_kernel(const float* __restrict__ src, int b, int h, int w, int mcus_x, int mcus_y,
+                                                        const float* __restrict__ factor, int differentiable, const float* __restrict__ tables,
+                                                        float* __restrict__ dst) {
+  __shared__ float sp_all[4][384], cf_all[4][384];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long mcu = (long long)blockIdx.x * 4 + wave;
+  const long long total = (long long)b * mcus_x * mcus_y;
+  const bool live = mcu < total;
+  float* sp = sp_all[wave];
+  float* cf = cf_all[wave];
+  const float* dct = tables;
+  const float* idct = tables + 4096;
+  const float* scale = tables + 8192;
+  const float* alpha = scale + 64;
+  const float* ytab = alpha + 64;
+  const float* ctab = ytab + 64;
+  int img = 0, my = 0, mx = 0;
+  if (live) {
+    img = (int)(mcu / ((long long)mcus_x * mcus_y));
+    const int rem = (int)(mcu % ((long long)mcus_x * mcus_y));
+    my = rem / mcus_x;
+    mx = rem % mcus_x;
+  }
+  const size_t plane = (size_t)h * w;
+  const float* ps = src + (size_t)img * 3 * plane;
+  const int qy = lane >> 3, qx = lane & 7;
+  // ---- load the quad, x255, RGB -> YCbCr (tensordot with the transposed matrix + shift, :1201-1212), chroma average (:1219-1226)
+  {
+    float cbs = 0.f, crs = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int ly = qy * 2 + dy, lx = qx * 2 + dx;
+        const int y = my * 16 + ly, x = mx * 16 + lx;
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if (live && y < h && x < w) {
+          const size_t o = (size_t)y * w + x;
+          r = ps[o] * 255.f; g = ps[plane + o] * 255.f; bl = ps[2 * plane + o] * 255.f;
+        }
+        float yy = r * 0.299f; yy = fmaf(g, 0.587f, yy); yy = fmaf(bl, 0.114f, yy);
+        float cb = r * -0.168736f; cb = fmaf(g, -0.331264f, cb); cb = fmaf(bl, 0.5f, cb); cb += 128.f;
+        float cr = r * 0.5f; cr = fmaf(g, -0.418688f, cr); cr = fmaf(bl, -0.081312f, cr); cr += 128.f;
+        sp[ly * 16 + lx] = yy;
+        cbs += cb; crs += cr;
+      }
+    sp[256 + qy * 8 + qx] = cbs * 0.25f;
+    sp[320 + qy * 8 + qx] = crs * 0.25f;
+  }
+  __syncthreads();
+  const float f = live ? factor[img] : 1.f;
+  // ---- forward DCT of the six blocks, quantise, round, de-quantise, x alpha (:1254-1259, :1270-1278, :1183-1195, :1333-1340, :1371)
+  {
+    const int u = lane >> 3, v = lane & 7;
+#pragma unroll 1
+    for (int blk = 0; blk < 6; ++blk) {
+      const float* xb = blk < 4 ? sp + ((blk >> 1) * 8) * 16 + (blk & 1) * 8 : sp + 256 + (blk - 4) * 64;
+      const int pitch = blk < 4 ? 16 : 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 8; ++y) acc = fmaf(xb[x * pitch + y] - 128.f, dct[(x * 8 + y) * 64 + lane], acc);
+      const float coef = scale[lane] * acc;
+      const float tab = (blk < 4 ? ytab[lane] : ctab[lane]) * f;
+      const float q = coef / tab;
+      float rq = rintf(q);                                        // torch.round: half to even
+      if (differentiable) { const float d = q - rq; rq = rq + d * d * d; }
+      cf[blk * 64 + u * 8 + v] = (rq * tab) * alpha[lane];
+    }
+  }
+  __syncthreads();
+  // ---- inverse DCT (:1370-1374): pixel (a, bb) of each block = 0.25 * sum_uv X[u,v] * idct[u,v,a,bb] + 128
+  {
+#pragma unroll 1
+    for (int blk = 0; blk < 6; ++blk) {
+      const float* xb = cf + blk * 64;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc = fmaf(xb[i], idct[i * 64 + lane], acc);
+      const float pv = 0.25f * acc + 128.f;
+      const int a = lane >> 3, bb = lane & 7;
+      if (blk < 4) sp[((blk >> 1) * 8 + a) * 16 + (blk & 1) * 8 + bb] = pv;
+      else sp[256 + (blk - 4) * 64 + a * 8 + bb] = pv;
+    }
+  }
+  __syncthreads();
+  // ---- chroma repeat (:1396-1407), YCbCr -> RGB (:1414-1424), clamp and /255 (:1459-1460), crop (:1495)
+  if (live) {
+    const float cb = sp[256 + qy * 8 + qx] - 128.f, cr = sp[320 + qy * 8 + qx] - 128.f;
+    float* pd = dst + (size_t)img * 3 * plane;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int ly = qy * 2 + dy, lx = qx * 2 + dx;
+        const int y = my * 16 + ly, x = mx * 16 + lx;
+        if (y < h && x < w) {
+          const float yy = sp[ly * 16 + lx];
+          float r = yy * 1.f; r = fmaf(cb, 0.f, r); r = fmaf(cr, 1.402f, r);
+          float g = yy * 1.f; g = fmaf(cb, -0.344136f, g); g = fmaf(cr, -0.714136f, g);
+          float bl = yy * 1.f; bl = fmaf(cb, 1.772f, bl); bl = fmaf(cr, 0.f, bl);
+          const size_t o = (size_t)y * w + x;
+          pd[o] = fminf(255.f, fmaxf(0.f, r)) / 255.f;
+          pd[plane + o] = fminf(255.f, fmaxf(0.f, g)) / 255.f;
+          pd[2 * plane + o] = fminf(255.f, fmaxf(0.f, bl)) / 255.f;
+        }
+      }
+  }
+}
+
+// quality -> factor in place, as DiffJPEG.forward does on the tensor it is given (:1476-1480, :1127-1144)
+__global__ void jpeg_quality_factor_kernel(float* q, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = q[i];
+    const float t = v < 50.f ? 5000.f / v : 200.f - v * 2.f;
+    q[i] = t / 100.f;
+  }
+}
+
+int diff_jpeg_impl(const float* src, int b, int c, int h, int w, float* quality, int quality_is_factor, int differentiable, const float* tables,
+                   float* dst, hipStream_t s) {
+  if (!src || !dst || !quality || !tables || b <= 0 || h <= 0 || w <= 0) return set_err(SRGANFD_EINVAL, "diff_jpeg: null / empty argument");
+  if (c != 3) return set_err(SRGANFD_EINVAL, "diff_jpeg: needs 3-channel RGB input, got %d channels", c);
+  const int mcus_x = ceil_div(w, 16), mcus_y = ceil_div(h, 16);
+  const long long total = (long long)b * mcus_x * mcus_y;
+  if (total > (1ll << 32)) return set_err(SRGANFD_EINVAL, "diff_jpeg: too many blocks");
+  if (!quality_is_factor) SRGANFD_LAUNCH(jpeg_quality_factor_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, s, quality, b);
+  SRGANFD_LAUNCH(diff_jpeg_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, src, b, h, w, mcus_x, mcus_y, (const float*)quality,
+                 differentiable, tables, dst);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+// the last line of degradation_process (imgproc.py:2460): lr = clamp(round(x * 255), 0, 255) / 255
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[i] = fminf(fmaxf(rintf(src[i] * 255.f), 0.f), 255.f) / 255.f;
+}
+int quantize_u8_impl(const float* src, float* dst, size_t n, hipStream_t s) {
+  if (!src || !dst || n == 0) return set_err(SRGANFD_EINVAL, "quantize_u8: null / empty argument");
+  const size_t blocks = (n + 255) / 256;
+  SRGANFD_LAUNCH(quantize_u8_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, src, dst, n);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+int jpeg_table_floats() { return kJpegTableFloats; }
+
+}  // namespace srganfd

@@ -491,10 +491,70 @@ def gold_validation():
     save("validation.npz", **out)
 
 
+def gold_degradation():
+    """Real-ESRGAN's on-device degradation stages: filter2d_torch, USMSharp.forward, DiffJPEG
+    (Real_ESRGAN/imgproc.py:1092-1124, :1517-1540, :1465-1497), imported with empty stubs for cv2, torchvision and
+    scipy's stats (none of the captured functions touches them).  USMSharp.__init__ calls cv2.getGaussianKernel, so the
+    instance is assembled around the kernel OpenCV documents for (51, 0): sigma = 0.3*((51-1)*0.5-1)+0.8 = 8."""
+    for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional",
+                 "torchvision.transforms.functional_tensor"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    sys.modules["torchvision.transforms.functional_tensor"].rgb_to_grayscale = None
+    path = os.path.join(REF, "Real_ESRGAN")
+    sys.path.insert(0, path)
+    try:
+        sys.modules.pop("imgproc", None)
+        ip = importlib.import_module("imgproc")
+    finally:
+        sys.path.remove(path)
+        sys.modules.pop("imgproc", None)
+    out = {}
+    torch.manual_seed(0)
+    img = torch.rand(3, 3, 45, 70)
+    img[1] = torch.nn.functional.interpolate(torch.rand(1, 3, 12, 18), size=(45, 70), mode="bicubic").clamp(0, 1)[0]    # a smooth image too
+    out["image"] = np_(img)
+    k21 = torch.rand(3, 21, 21)
+    k21 = k21 / k21.sum(dim=(1, 2), keepdim=True)
+    out["kernels21"] = np_(k21)
+    with torch.no_grad():
+        out["filter2d_per_image"] = np_(ip.filter2d_torch(img, k21))
+        out["filter2d_shared"] = np_(ip.filter2d_torch(img, k21[:1]))
+        k7 = torch.rand(1, 7, 7)
+        out["kernel7"] = np_(k7)
+        out["filter2d_k7"] = np_(ip.filter2d_torch(img, k7))
+        # USM sharpener on an image large enough for the 25-pixel reflect padding
+        big = torch.nn.functional.interpolate(torch.rand(2, 3, 10, 12), size=(60, 72), mode="bicubic").clamp(0, 1)
+        big = (big + 0.03 * torch.randn_like(big)).clamp(0, 1)
+        out["usm_image"] = np_(big)
+        xs = np.arange(51, dtype=np.float64) - 25.0
+        g = np.exp(-(xs ** 2) / (2.0 * 8.0 ** 2))
+        g = (g / g.sum()).reshape(51, 1)
+        usm = ip.USMSharp.__new__(ip.USMSharp)
+        torch.nn.Module.__init__(usm)
+        usm.radius = 51
+        usm.register_buffer("kernel", torch.FloatTensor(np.dot(g, g.transpose())).unsqueeze_(0))
+        out["usm_kernel"] = np_(usm.kernel)
+        out["usm_w05_t10"] = np_(usm(big, 0.5, 10))
+        out["usm_w15_t3"] = np_(usm(big, 1.5, 3))
+        # DiffJPEG: ragged size (45x70 -> padded to 48x80), per-image quality on both sides of 50, both roundings
+        quality = torch.tensor([30.0, 75.0, 95.0])
+        out["jpeg_quality"] = np_(quality)
+        q = quality.clone()
+        out["jpeg"] = np_(ip.DiffJPEG(False)(img, q))
+        out["jpeg_factor"] = np_(q)                      # the reference converts the tensor it is given in place
+        out["jpeg_diff"] = np_(ip.DiffJPEG(True)(img, quality.clone()))
+        out["jpeg_scalar_q60"] = np_(ip.DiffJPEG(False)(img[:, :, :32, :48], 60))
+    save("degradation.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     if "--only-validation" in sys.argv:
         return gold_validation()
+    if "--only-degradation" in sys.argv:
+        return gold_degradation()
     MB = load_ref("BSRGAN")
     ME = load_ref("ESRGAN")
     gold_blocks(MB)
@@ -508,6 +568,7 @@ def main():
     gold_validation()
     gold_esrgan_discriminator(ME)
     gold_esrgan_gan_steps(ME)
+    gold_degradation()
 
 
 if __name__ == "__main__":
