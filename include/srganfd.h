@@ -299,6 +299,25 @@ int32_t srganfd_diff_jpeg_table_floats(void);
 int srganfd_diff_jpeg_tables(float* host_out);
 int srganfd_diff_jpeg(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, float* quality,
                       int32_t quality_is_factor, int32_t differentiable, const float* tables, float* out, void* stream);
+/* F.interpolate as degradation_process calls it (imgproc.py:2374, :2415-2418, :2440-2442, :2454-2456): mode 0 "area"
+ * (adaptive average pooling), 1 "bilinear", 2 "bicubic" (A = -0.75), align_corners unset.  `planes` = b*c NCHW fp32 planes.
+ * rscale_h/w: 1 / scale_factor when the caller passed scale_factor= (torch maps coordinates with it), 0 = in / out. */
+int srganfd_resize(const float* src, int32_t planes, int32_t h, int32_t w, int32_t out_h, int32_t out_w, int32_t mode,
+                   float rscale_h, float rscale_w, float* dst, void* stream);
+/* random_add_gaussian_noise_torch after its draws (imgproc.py:849-866, :1046-1060): randn_color (b,c,h,w), randn_gray_hw
+ * (h,w) or NULL, sigma[b] (range 255), gray_flag[b] in {0,1}; out = image + mixed noise, then clip / rounds. */
+int srganfd_gaussian_noise(const float* image, const float* randn_color, const float* randn_gray_hw, const float* sigma,
+                           const float* gray_flag, int32_t b, int32_t c, int32_t h, int32_t w, int32_t clip, int32_t rounds,
+                           float* out, void* stream);
+/* random_add_poisson_noise_torch around its draws (imgproc.py:886-919, :1077-1089).  prepare: image rounded to 8 bits
+ * (image_q; gray_q = the same of torchvision's grey image when want_gray) and vals[b] = 2^ceil(log2(#distinct levels));
+ * workspace: b * 512 uint32.  The caller draws poisson(image_q * vals) (and the grey one); apply mixes, scales, adds, clips. */
+int srganfd_poisson_prepare(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, int32_t want_gray,
+                            float* image_q, float* gray_q, float* vals, float* vals_gray, void* workspace, void* stream);
+int srganfd_poisson_apply(const float* image, const float* image_q, const float* gray_q, const float* poisson_color,
+                          const float* poisson_gray, const float* vals, const float* vals_gray, const float* scale,
+                          const float* gray_flag, int32_t b, int32_t c, int32_t h, int32_t w, int32_t clip, int32_t rounds,
+                          float* out, void* stream);
 /* last line of degradation_process (imgproc.py:2460): dst = clamp(round(src * 255), 0, 255) / 255 (may alias) */
 int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream);
 

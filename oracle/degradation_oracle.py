@@ -127,9 +127,137 @@ def diff_jpeg(x: Tensor, factor: Tensor, differentiable: bool = False) -> Tensor
     m2 = torch.from_numpy(np.array([[1., 0., 1.402], [1, -0.344136, -0.714136], [1, 1.772, 0]], dtype=np.float32).T.copy())
     rgb = torch.tensordot(ycc2 + torch.tensor([0, -128., -128.]), m2, dims=1).permute(0, 3, 1, 2)              # :1414-1424
     rgb = torch.clamp(rgb, 0, 255) / 255                                                                       # :1459-1460
-    return rgb[:, :, 0:h, 0:w]
+    return rgb[:, :, 0:h, 0:w].contiguous()   # (the reference returns this permuted view; its CPU filter2d_torch cannot .view() it)
 
 
 def quantize_u8(x: Tensor) -> Tensor:
     """last line of degradation_process -- Real_ESRGAN/imgproc.py:2460"""
     return torch.clamp((x * 255.0).round(), 0, 255) / 255.
+
+
+def interpolate(x: Tensor, size=None, scale_factor=None, mode: str = "bilinear") -> Tensor:
+    """the F_torch.interpolate calls of degradation_process -- Real_ESRGAN/imgproc.py:2374, :2415-2418, :2440-2442, :2454-2456
+    (torch's own CPU kernels are the statement of "area" / "bilinear" / "bicubic" here)"""
+    return F.interpolate(x, size=size, scale_factor=scale_factor, mode=mode)
+
+
+def _finish(out: Tensor, clip: bool, rounds: bool) -> Tensor:
+    if clip and rounds:
+        return torch.clamp((out * 255.0).round(), 0, 255) / 255.
+    if clip:
+        return torch.clamp(out, 0, 1)
+    if rounds:
+        return (out * 255.0).round() / 255.
+    return out
+
+
+def add_gaussian_noise(image: Tensor, sigma, clip: bool = True, rounds: bool = False, gray_noise=0) -> Tensor:
+    """_add_gaussian_noise_torch over _generate_gaussian_noise_torch -- Real_ESRGAN/imgproc.py:970-998, :832-866.  Draws:
+    randn(h, w) first when any image wants grey noise, then randn(b, c, h, w)."""
+    b, _, h, w = image.size()
+    if not isinstance(sigma, (float, int)):
+        sigma = sigma.view(b, 1, 1, 1)
+    if isinstance(gray_noise, (float, int)):
+        cal_gray = gray_noise > 0
+    else:
+        gray_noise = gray_noise.view(b, 1, 1, 1)
+        cal_gray = torch.sum(gray_noise) > 0
+    if cal_gray:
+        noise_gray = (torch.randn(h, w, dtype=image.dtype) * sigma / 255.).view(b, 1, h, w)
+    noise = torch.randn(*image.size(), dtype=image.dtype) * sigma / 255.
+    if cal_gray:
+        noise = noise * (1 - gray_noise) + noise_gray * gray_noise
+    return _finish(image + noise, clip, rounds)
+
+
+def rgb_to_grayscale(img: Tensor) -> Tensor:
+    """torchvision.transforms.functional_tensor.rgb_to_grayscale (third party, absent; any 0.13-0.16): 0.2989 R + 0.587 G +
+    0.114 B, one output channel.  PARITY UNPINNED for the grey Poisson branch that uses it."""
+    r, g, b = img.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).to(img.dtype).unsqueeze(dim=-3)
+
+
+def poisson_vals(image_q: Tensor) -> Tensor:
+    """vals = 2 ** ceil(log2(#unique values)) per image -- Real_ESRGAN/imgproc.py:898-901 / :907-910"""
+    b = image_q.size(0)
+    vals_list = [len(torch.unique(image_q[i])) for i in range(b)]
+    return image_q.new_tensor([2 ** np.ceil(np.log2(v)) for v in vals_list]).view(b, 1, 1, 1)
+
+
+def add_poisson_noise(image: Tensor, scale, clip: bool = True, rounds: bool = False, gray_noise=0) -> Tensor:
+    """_add_poisson_noise_torch over _generate_poisson_noise_torch -- Real_ESRGAN/imgproc.py:1001-1029, :869-919"""
+    b, _, h, w = image.size()
+    if isinstance(gray_noise, (float, int)):
+        cal_gray = gray_noise > 0
+    else:
+        gray_noise = gray_noise.view(b, 1, 1, 1)
+        cal_gray = torch.sum(gray_noise) > 0
+    if cal_gray:
+        img_gray = torch.clamp((rgb_to_grayscale(image) * 255.0).round(), 0, 255) / 255.
+        vals = poisson_vals(img_gray)
+        noise_gray = (torch.poisson(img_gray * vals) / vals - img_gray).expand(b, 3, h, w)
+    image_q = torch.clamp((image * 255.0).round(), 0, 255) / 255.
+    vals = poisson_vals(image_q)
+    noise = torch.poisson(image_q * vals) / vals - image_q
+    if cal_gray:
+        noise = noise * (1 - gray_noise) + noise_gray * gray_noise
+    if not isinstance(scale, (float, int)):
+        scale = scale.view(b, 1, 1, 1)
+    # the rounded copy is local to the generator (:904); the caller adds the noise to the image it was given (:1020)
+    return _finish(image + noise * scale, clip, rounds)
+
+
+def random_add_gaussian_noise(image, sigma_range, gray_prob, clip=True, rounds=False):
+    """random_add_gaussian_noise_torch -- Real_ESRGAN/imgproc.py:1032-1060, draws at :937-941"""
+    b = image.size(0)
+    sigma = torch.rand(b, dtype=image.dtype) * (sigma_range[1] - sigma_range[0]) + sigma_range[0]
+    gray = (torch.rand(b, dtype=image.dtype) < gray_prob).float()
+    return add_gaussian_noise(image, sigma, clip, rounds, gray)
+
+
+def random_add_poisson_noise(image, scale_range, gray_prob, clip=True, rounds=False):
+    """random_add_poisson_noise_torch -- Real_ESRGAN/imgproc.py:1063-1089, draws at :961-965"""
+    b = image.size(0)
+    scale = torch.rand(b, dtype=image.dtype) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    gray = (torch.rand(b, dtype=image.dtype) < gray_prob).float()
+    return add_poisson_noise(image, scale, clip, rounds, gray)
+
+
+def degradation_process(gt, gaussian_kernel1, gaussian_kernel2, sinc_kernel, upscale_factor, P, usm=None):
+    """degradation_process -- Real_ESRGAN/imgproc.py:2323-2462 (jpeg_operation = DiffJPEG(False)); `usm` = (kernel, weight,
+    threshold) or None.  Host draws (np.random / random) in the reference's order."""
+    import random
+    H, W = gt.size()[2:4]
+    gt_usm = usm_sharp(gt, *usm) if usm is not None else gt
+    out = gt_usm
+    if np.random.uniform() <= P["first_blur_probability"]:
+        out = filter2d(gt_usm, gaussian_kernel1)
+
+    def pick_scale(prob, rng):
+        t = random.choices(["up", "down", "keep"], prob)[0]
+        return np.random.uniform(1, rng[1]) if t == "up" else np.random.uniform(rng[0], 1) if t == "down" else 1
+
+    def noise(x, i):
+        if np.random.uniform() < P[f"gaussian_noise_probability{i}"]:
+            return random_add_gaussian_noise(x, P[f"noise_range{i}"], P[f"gray_noise_probability{i}"])
+        return random_add_poisson_noise(x, P[f"poisson_scale_range{i}"], P[f"gray_noise_probability{i}"])
+
+    def jpeg(x, rng):
+        q = x.new_zeros(x.size(0)).uniform_(*rng)
+        return diff_jpeg(torch.clamp(x, 0, 1), quality_to_factor(q))
+    scale = pick_scale(P["resize_probability1"], P["resize_range1"])
+    out = interpolate(out, scale_factor=scale, mode=random.choice(["area", "bilinear", "bicubic"]))
+    out = jpeg(noise(out, 1), P["jpeg_range1"])
+    if np.random.uniform() < P["second_blur_probability"]:
+        out = filter2d(out, gaussian_kernel2)
+    scale = pick_scale(P["resize_probability2"], P["resize_range2"])
+    out = interpolate(out, size=(int(H / upscale_factor * scale), int(W / upscale_factor * scale)), mode=random.choice(["area", "bilinear", "bicubic"]))
+    out = noise(out, 2)
+    if np.random.uniform() < 0.5:
+        out = interpolate(out, size=(H // upscale_factor, W // upscale_factor), mode=random.choice(["area", "bilinear", "bicubic"]))
+        out = jpeg(filter2d(out, sinc_kernel), P["jpeg_range2"])
+    else:
+        out = jpeg(out, P["jpeg_range2"])
+        out = interpolate(out, size=(H // upscale_factor, W // upscale_factor), mode=random.choice(["area", "bilinear", "bicubic"]))
+        out = filter2d(out, sinc_kernel)
+    return gt_usm, gt, quantize_u8(out)

@@ -108,6 +108,10 @@ SYMBOLS = {
     "srganfd_diff_jpeg_table_floats": (C.c_int32, []),
     "srganfd_diff_jpeg_tables": (C.c_int, [C.c_void_p]),
     "srganfd_diff_jpeg": (C.c_int, [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_resize": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_gaussian_noise": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "srganfd_poisson_prepare": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 6),
+    "srganfd_poisson_apply": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "srganfd_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_ssim_workspace_doubles": (C.c_int64, [C.c_int32] * 7),
     "srganfd_ssim": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -52,6 +52,14 @@ int jpeg_table_floats();
 int diff_jpeg_impl(const float* src, int b, int c, int h, int w, float* quality, int quality_is_factor, int differentiable, const float* tables,
                    float* dst, hipStream_t s);
 int quantize_u8_impl(const float* src, float* dst, size_t n, hipStream_t s);
+int resize_impl(const float* src, int planes, int h, int w, int oh, int ow, int mode, float rscale_h, float rscale_w, float* dst, hipStream_t s);
+int gaussian_noise_impl(const float* image, const float* n_color, const float* n_gray, const float* sigma, const float* gray, int b, int c, int h, int w,
+                        int clip, int rounds, float* out, hipStream_t s);
+int poisson_prepare_impl(const float* image, int b, int c, int h, int w, int want_gray, float* img_q, float* gray_q, float* vals, float* vals_gray,
+                         unsigned int* presence, hipStream_t s);
+int poisson_apply_impl(const float* image, const float* img_q, const float* gray_q, const float* pois, const float* pois_gray, const float* vals,
+                       const float* vals_gray, const float* scale, const float* gray, int b, int c, int h, int w, int clip, int rounds, float* out,
+                       hipStream_t s);
 int64_t ssim_workspace_doubles(int n, int c, int h, int w, int crop_border, int y_only, int ws);
 int ssim_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, const double* window, int ws, float* out,
               double* wsp, hipStream_t s);
@@ -202,6 +210,24 @@ int srganfd_diff_jpeg_tables(float* host_out) {
 int srganfd_diff_jpeg(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, float* quality, int32_t quality_is_factor,
                       int32_t differentiable, const float* tables, float* out, void* stream) {
   return diff_jpeg_impl(image, b, c, h, w, quality, quality_is_factor, differentiable, tables, out, (hipStream_t)stream);
+}
+int srganfd_resize(const float* src, int32_t planes, int32_t h, int32_t w, int32_t out_h, int32_t out_w, int32_t mode, float rscale_h, float rscale_w,
+                   float* dst, void* stream) {
+  return resize_impl(src, planes, h, w, out_h, out_w, mode, rscale_h, rscale_w, dst, (hipStream_t)stream);
+}
+int srganfd_gaussian_noise(const float* image, const float* randn_color, const float* randn_gray_hw, const float* sigma, const float* gray_flag, int32_t b,
+                           int32_t c, int32_t h, int32_t w, int32_t clip, int32_t rounds, float* out, void* stream) {
+  return gaussian_noise_impl(image, randn_color, randn_gray_hw, sigma, gray_flag, b, c, h, w, clip, rounds, out, (hipStream_t)stream);
+}
+int srganfd_poisson_prepare(const float* image, int32_t b, int32_t c, int32_t h, int32_t w, int32_t want_gray, float* image_q, float* gray_q, float* vals,
+                            float* vals_gray, void* workspace, void* stream) {
+  return poisson_prepare_impl(image, b, c, h, w, want_gray, image_q, gray_q, vals, vals_gray, (unsigned int*)workspace, (hipStream_t)stream);
+}
+int srganfd_poisson_apply(const float* image, const float* image_q, const float* gray_q, const float* poisson_color, const float* poisson_gray,
+                          const float* vals, const float* vals_gray, const float* scale, const float* gray_flag, int32_t b, int32_t c, int32_t h,
+                          int32_t w, int32_t clip, int32_t rounds, float* out, void* stream) {
+  return poisson_apply_impl(image, image_q, gray_q, poisson_color, poisson_gray, vals, vals_gray, scale, gray_flag, b, c, h, w, clip, rounds, out,
+                            (hipStream_t)stream);
 }
 int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream) {
   return quantize_u8_impl(src, dst, numel > 0 ? (size_t)numel : 0, (hipStream_t)stream);

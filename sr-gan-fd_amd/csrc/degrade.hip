@@ -288,6 +288,212 @@ int quantize_u8_impl(const float* src, float* dst, size_t n, hipStream_t s) {
   return SRGANFD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The three F.interpolate modes degradation_process draws from (imgproc.py:2374, :2415-2418, :2440-2442, :2454-2456;
+// align_corners unset, no antialias): "area" = adaptive average pooling, "bilinear", "bicubic" (A = -0.75, border
+// indices clamped).  Source coordinate = rscale * (dst + 0.5) - 0.5 in fp32, rscale = 1 / scale_factor when the caller
+// passed a scale factor, else in / out.  One thread per output pixel; neighbours share their taps through L1/L2.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+template <int MODE>   // 0 area, 1 bilinear, 2 bicubic
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ src, int planes, int h, int w, int oh, int ow, float rs_h, float rs_w,
+                                                     float* __restrict__ dst) {
+  const size_t total = (size_t)planes * oh * ow;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const size_t t = i / ow;
+    const int oy = (int)(t % oh);
+    const float* sp = src + (t / oh) * (size_t)h * w;
+    float v;
+    if (MODE == 0) {
+      // adaptive_avg_pool2d: window [floor(o*in/out), ceil((o+1)*in/out))
+      const int y0 = (int)(((long long)oy * h) / oh), y1 = (int)((((long long)oy + 1) * h + oh - 1) / oh);
+      const int x0 = (int)(((long long)ox * w) / ow), x1 = (int)((((long long)ox + 1) * w + ow - 1) / ow);
+      float sum = 0.f;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) sum += sp[(size_t)y * w + x];
+      v = sum / (float)((y1 - y0) * (x1 - x0));
+    } else if (MODE == 1) {
+      float sy = rs_h * ((float)oy + 0.5f) - 0.5f, sx = rs_w * ((float)ox + 0.5f) - 0.5f;
+      sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+      const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+      v = hy * (hx * sp[(size_t)y0 * w + x0] + lx * sp[(size_t)y0 * w + x1]) + ly * (hx * sp[(size_t)y1 * w + x0] + lx * sp[(size_t)y1 * w + x1]);
+    } else {
+      const float A = -0.75f;
+      const float sy = rs_h * ((float)oy + 0.5f) - 0.5f, sx = rs_w * ((float)ox + 0.5f) - 0.5f;
+      const float fy = floorf(sy), fx = floorf(sx);
+      const int iy = (int)fy, ix = (int)fx;
+      const float ty = sy - fy, tx = sx - fx;
+      const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+      const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+      v = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int y = min(max(iy - 1 + a, 0), h - 1);
+        float row = 0.f;
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) row += cx[bq] * sp[(size_t)y * w + min(max(ix - 1 + bq, 0), w - 1)];
+        v += cy[a] * row;
+      }
+    }
+    dst[i] = v;
+  }
+}
+
+int resize_impl(const float* src, int planes, int h, int w, int oh, int ow, int mode, float rscale_h, float rscale_w, float* dst, hipStream_t s) {
+  if (!src || !dst || planes <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return set_err(SRGANFD_EINVAL, "resize: null / empty argument");
+  if (mode < 0 || mode > 2) return set_err(SRGANFD_EINVAL, "resize: mode %d (0 area, 1 bilinear, 2 bicubic)", mode);
+  const float rh = rscale_h > 0.f ? rscale_h : (float)h / (float)oh, rw = rscale_w > 0.f ? rscale_w : (float)w / (float)ow;
+  const size_t total = (size_t)planes * oh * ow, blocks = (total + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+  if (mode == 0) SRGANFD_LAUNCH(resize_kernel<0>, grid, dim3(256), 0, s, src, planes, h, w, oh, ow, rh, rw, dst);
+  else if (mode == 1) SRGANFD_LAUNCH(resize_kernel<1>, grid, dim3(256), 0, s, src, planes, h, w, oh, ow, rh, rw, dst);
+  else SRGANFD_LAUNCH(resize_kernel<2>, grid, dim3(256), 0, s, src, planes, h, w, oh, ow, rh, rw, dst);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Noise stages (imgproc.py:832-1089).  The random draws themselves (torch.randn / torch.poisson / torch.rand) stay
+// with the caller's generator -- they are handed in as tensors -- and everything deterministic around them is fused:
+//   gaussian (:849-866, :1046-1060): out = clip?(image + (n_color*(1-g) + n_gray*g) * sigma/255) with per-image sigma
+//     and gray flag g; n_gray is ONE (h, w) field shared by the batch, as the reference draws it (:859-860).
+//   poisson (:886-919, :1077-1089): image rounded to 8 bits; vals = 2^ceil(log2(#distinct levels)) per image (a 256-bin
+//     presence count, the reference's torch.unique loop); the caller draws poisson(image_q * vals); then
+//     out = clip?(image + ((p/vals - image_q)*(1-g) + (pg/vals_g - gray_q)*g) * scale).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finish_noise(float v, int clip, int rounds) {
+  if (clip && rounds) return fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f;
+  if (clip) return fminf(fmaxf(v, 0.f), 1.f);
+  if (rounds) return rintf(v * 255.f) / 255.f;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gaussian_noise_kernel(const float* __restrict__ image, const float* __restrict__ n_color,
+                                                             const float* __restrict__ n_gray, const float* __restrict__ sigma,
+                                                             const float* __restrict__ gray, int c, size_t hw, size_t total, int clip, int rounds,
+                                                             float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i % hw;
+    const int img = (int)(i / (hw * c));
+    const float sg = sigma[img];
+    float noise = n_color[i] * sg / 255.f;
+    if (n_gray) {
+      const float g = gray[img];
+      noise = noise * (1.f - g) + (n_gray[pix] * sg / 255.f) * g;
+    }
+    out[i] = finish_noise(image[i] + noise, clip, rounds);
+  }
+}
+
+// per image: 8-bit quantised copy (colour, and optionally the grey image of torchvision's rgb_to_grayscale) + the number
+// of distinct levels -> vals.  grid (blocks, b); bins are OR-ed into a 256-entry presence table per image.
+__global__ __launch_bounds__(256) void poisson_prepare_kernel(const float* __restrict__ image, int c, size_t hw, int want_gray, float* __restrict__ img_q,
+                                                              float* __restrict__ gray_q, unsigned int* __restrict__ presence) {
+  __shared__ unsigned int seen[2][256];
+  seen[0][threadIdx.x] = 0; seen[1][threadIdx.x] = 0;
+  __syncthreads();
+  const int img = blockIdx.y;
+  const float* p = image + (size_t)img * c * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (size_t)gridDim.x * 256) {
+    for (int k = 0; k < c; ++k) {
+      const float q = fminf(fmaxf(rintf(p[k * hw + i] * 255.f), 0.f), 255.f);
+      img_q[(size_t)img * c * hw + k * hw + i] = q / 255.f;
+      seen[0][(int)q] = 1;
+    }
+    if (want_gray) {
+      const float gr = 0.2989f * p[i] + 0.587f * p[hw + i] + 0.114f * p[2 * hw + i];
+      const float q = fminf(fmaxf(rintf(gr * 255.f), 0.f), 255.f);
+      gray_q[(size_t)img * hw + i] = q / 255.f;
+      seen[1][(int)q] = 1;
+    }
+  }
+  __syncthreads();
+  if (seen[0][threadIdx.x]) presence[(size_t)img * 512 + threadIdx.x] = 1;
+  if (want_gray && seen[1][threadIdx.x]) presence[(size_t)img * 512 + 256 + threadIdx.x] = 1;
+}
+__global__ __launch_bounds__(256) void poisson_vals_kernel(const unsigned int* __restrict__ presence, float* __restrict__ vals, float* __restrict__ vals_gray) {
+  __shared__ int cnt[2][256];
+  const int img = blockIdx.x;
+  cnt[0][threadIdx.x] = presence[(size_t)img * 512 + threadIdx.x] ? 1 : 0;
+  cnt[1][threadIdx.x] = presence[(size_t)img * 512 + 256 + threadIdx.x] ? 1 : 0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { cnt[0][threadIdx.x] += cnt[0][threadIdx.x + st]; cnt[1][threadIdx.x] += cnt[1][threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // 2 ** ceil(log2(n)) for 1 <= n <= 256, in integers
+    for (int which = 0; which < 2; ++which) {
+      const int n = cnt[which][0];
+      int p2 = 1;
+      while (p2 < n) p2 <<= 1;
+      float* dstv = which ? vals_gray : vals;
+      if (dstv) dstv[img] = (float)p2;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void poisson_apply_kernel(const float* __restrict__ image, const float* __restrict__ img_q, const float* __restrict__ gray_q,
+                                                            const float* __restrict__ pois, const float* __restrict__ pois_gray,
+                                                            const float* __restrict__ vals, const float* __restrict__ vals_gray,
+                                                            const float* __restrict__ scale, const float* __restrict__ gray, int c, size_t hw,
+                                                            size_t total, int clip, int rounds, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i % hw;
+    const int img = (int)(i / (hw * c));
+    float noise = pois[i] / vals[img] - img_q[i];
+    if (pois_gray) {
+      const float g = gray[img];
+      const size_t gi = (size_t)img * hw + pix;
+      noise = noise * (1.f - g) + (pois_gray[gi] / vals_gray[img] - gray_q[gi]) * g;
+    }
+    out[i] = finish_noise(image[i] + noise * scale[img], clip, rounds);
+  }
+}
+
+static inline dim3 ew_grid(size_t total) {
+  const size_t blocks = (total + 255) / 256;
+  return dim3((unsigned)(blocks < 32768 ? blocks : 32768));
+}
+int gaussian_noise_impl(const float* image, const float* n_color, const float* n_gray, const float* sigma, const float* gray, int b, int c, int h, int w,
+                        int clip, int rounds, float* out, hipStream_t s) {
+  if (!image || !n_color || !sigma || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0 || (n_gray && !gray))
+    return set_err(SRGANFD_EINVAL, "gaussian_noise: null / empty argument (a gray field needs the per-image gray flags)");
+  const size_t hw = (size_t)h * w, total = hw * c * b;
+  SRGANFD_LAUNCH(gaussian_noise_kernel, ew_grid(total), dim3(256), 0, s, image, n_color, n_gray, sigma, gray, c, hw, total, clip, rounds, out);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int poisson_prepare_impl(const float* image, int b, int c, int h, int w, int want_gray, float* img_q, float* gray_q, float* vals, float* vals_gray,
+                         unsigned int* presence, hipStream_t s) {
+  if (!image || !img_q || !vals || !presence || b <= 0 || c <= 0 || h <= 0 || w <= 0 || b > 65535)
+    return set_err(SRGANFD_EINVAL, "poisson_prepare: null / empty argument");
+  if (want_gray && (c != 3 || !gray_q || !vals_gray)) return set_err(SRGANFD_EINVAL, "poisson_prepare: gray noise needs 3-channel RGB and its outputs");
+  const size_t hw = (size_t)h * w;
+  SRGANFD_HIP_CHECK(hipMemsetAsync(presence, 0, (size_t)b * 512 * sizeof(unsigned int), s));
+  const size_t blocks = (hw + 255) / 256;
+  SRGANFD_LAUNCH(poisson_prepare_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256), b), dim3(256), 0, s, image, c, hw, want_gray, img_q, gray_q, presence);
+  SRGANFD_LAUNCH(poisson_vals_kernel, dim3(b), dim3(256), 0, s, (const unsigned int*)presence, vals, want_gray ? vals_gray : nullptr);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int poisson_apply_impl(const float* image, const float* img_q, const float* gray_q, const float* pois, const float* pois_gray, const float* vals,
+                       const float* vals_gray, const float* scale, const float* gray, int b, int c, int h, int w, int clip, int rounds, float* out,
+                       hipStream_t s) {
+  if (!image || !img_q || !pois || !vals || !scale || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0)
+    return set_err(SRGANFD_EINVAL, "poisson_apply: null / empty argument");
+  if (pois_gray && (!gray_q || !vals_gray || !gray)) return set_err(SRGANFD_EINVAL, "poisson_apply: gray noise needs gray_q, vals_gray and the gray flags");
+  const size_t hw = (size_t)h * w, total = hw * c * b;
+  SRGANFD_LAUNCH(poisson_apply_kernel, ew_grid(total), dim3(256), 0, s, image, img_q, gray_q, pois, pois_gray, vals, vals_gray, scale, gray, c, hw, total, clip,
+                 rounds, out);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
 int jpeg_table_floats() { return kJpegTableFloats; }
 
 }  // namespace srganfd

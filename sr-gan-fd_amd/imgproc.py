@@ -1,6 +1,6 @@
 """Device-side mirror of the data-side helpers the train loops call on GPU tensors (reference: BSRGAN/imgproc.py for
 ``random_crop``; Real_ESRGAN/imgproc.py for the on-device degradation stages -- SURVEY 8f N4: ``filter2d_torch``,
-``USMSharp``, ``DiffJPEG``).  The CPU-side pieces of that file (kernel synthesis with numpy / scipy, cv2 image I/O)
+``USMSharp``, ``DiffJPEG``, the noise stages, ``degradation_process``).  The CPU-side pieces of that file (kernel synthesis with numpy / scipy, cv2 image I/O)
 stay the reference's own."""
 from __future__ import annotations
 
@@ -122,3 +122,216 @@ class DiffJPEG(nn.Module):
         A.check(A.lib().srganfd_diff_jpeg(xx.data_ptr(), b, c, h, w, fac.data_ptr(), is_factor, 1 if self.differentiable else 0,
                                           tables.data_ptr(), out.data_ptr(), A.stream_ptr()), "diff_jpeg")
         return out
+
+
+_RESIZE_MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
+
+# Where the random draws of the noise / JPEG-quality stages are made.  None: on the image's device (the reference's
+# behaviour on a GPU).  "cpu": drawn from torch's CPU generator and copied over -- a run seeded with torch.manual_seed then
+# consumes exactly the stream the reference consumes when it runs on the CPU (parity tests, device-independent replays).
+DRAW_DEVICE = None
+
+
+def _draw(fn, *shape, device):
+    return fn(*shape, dtype=torch.float32, device=DRAW_DEVICE or device).to(device)
+
+
+def _poisson(rate: Tensor) -> Tensor:
+    return torch.poisson(rate.to(DRAW_DEVICE)).to(rate.device) if DRAW_DEVICE else torch.poisson(rate)
+
+
+def interpolate(x: Tensor, size=None, scale_factor=None, mode: str = "bilinear") -> Tensor:
+    """``torch.nn.functional.interpolate`` as degradation_process calls it (Real_ESRGAN/imgproc.py:2374, :2415-2418,
+    :2440-2442, :2454-2456): modes "area" / "bilinear" / "bicubic", align_corners unset; ``scale_factor=`` sizes the output
+    as floor(in * scale) and maps coordinates with 1 / scale_factor, ``size=`` with in / out -- torch's rules."""
+    _need_gpu(x, "interpolate")
+    if mode not in _RESIZE_MODES:
+        raise ValueError(f"interpolate: mode {mode!r} is not one of {sorted(_RESIZE_MODES)}")
+    if (size is None) == (scale_factor is None):
+        raise ValueError("only one of size or scale_factor should be defined")
+    xx = x.detach().contiguous().float()
+    b, c, h, w = xx.shape
+    if size is not None:
+        oh, ow = (size, size) if isinstance(size, int) else size
+        rs_h = rs_w = 0.0
+    else:
+        sf = (scale_factor, scale_factor) if isinstance(scale_factor, (int, float)) else tuple(scale_factor)
+        oh, ow = int(np.floor(float(h * sf[0]))), int(np.floor(float(w * sf[1])))
+        rs_h, rs_w = float(np.float32(1.0 / sf[0])), float(np.float32(1.0 / sf[1]))
+    out = torch.empty(b, c, int(oh), int(ow), dtype=torch.float32, device=xx.device)
+    A.check(A.lib().srganfd_resize(xx.data_ptr(), b * c, h, w, int(oh), int(ow), _RESIZE_MODES[mode], rs_h, rs_w, out.data_ptr(), A.stream_ptr()), "resize")
+    return out
+
+
+def _per_image(v, b: int, device) -> Tensor:
+    if isinstance(v, (float, int)):
+        return torch.full((b,), float(v), dtype=torch.float32, device=device)
+    return v.detach().to(device=device, dtype=torch.float32).reshape(b).contiguous()
+
+
+def _add_gaussian_noise_torch(image: Tensor, sigma=10.0, clip: bool = True, rounds: bool = False, gray_noise=0) -> Tensor:
+    """imgproc._add_gaussian_noise_torch (Real_ESRGAN/imgproc.py:970-998 over :832-866): the draws come from torch's
+    generator on the image's device in the reference's order (the shared (h, w) grey field first, if any image asks for
+    grey noise, then the colour field); scaling, grey / colour mixing, the add and the clip are one HIP pass."""
+    _need_gpu(image, "_add_gaussian_noise_torch")
+    x = image.detach().contiguous().float()
+    b, c, h, w = x.shape
+    sg = _per_image(sigma, b, x.device)
+    if isinstance(gray_noise, (float, int)):
+        cal_gray, gray = gray_noise > 0, _per_image(gray_noise, b, x.device)
+    else:
+        gray = _per_image(gray_noise, b, x.device)
+        cal_gray = bool(torch.sum(gray) > 0)
+    n_gray = _draw(torch.randn, h, w, device=x.device) if cal_gray else None
+    n_color = _draw(torch.randn, b, c, h, w, device=x.device)
+    return gaussian_noise_apply(x, n_color, n_gray, sg, gray, clip, rounds)
+
+
+def gaussian_noise_apply(image: Tensor, randn_color: Tensor, randn_gray_hw, sigma: Tensor, gray_flag: Tensor, clip: bool, rounds: bool) -> Tensor:
+    """the deterministic part of the Gaussian-noise stage on given draws (srganfd_gaussian_noise)"""
+    b, c, h, w = image.shape
+    out = torch.empty_like(image)
+    A.check(A.lib().srganfd_gaussian_noise(image.data_ptr(), randn_color.data_ptr(), randn_gray_hw.data_ptr() if randn_gray_hw is not None else None,
+                                           sigma.data_ptr(), gray_flag.data_ptr(), b, c, h, w, int(clip), int(rounds), out.data_ptr(), A.stream_ptr()),
+            "gaussian_noise")
+    return out
+
+
+def random_add_gaussian_noise_torch(image: Tensor, sigma_range: tuple = (0, 1.0), gray_prob: int = 0, clip: bool = True, rounds: bool = False) -> Tensor:
+    """imgproc.random_add_gaussian_noise_torch (Real_ESRGAN/imgproc.py:1032-1060 over :922-943): per-image sigma and grey
+    flag drawn with torch.rand in the reference's order, then ``_add_gaussian_noise_torch``."""
+    b = image.size(0)
+    sigma = _draw(torch.rand, b, device=image.device) * (sigma_range[1] - sigma_range[0]) + sigma_range[0]
+    gray_noise = (_draw(torch.rand, b, device=image.device) < gray_prob).float()
+    return _add_gaussian_noise_torch(image, sigma, clip, rounds, gray_noise)
+
+
+def poisson_noise_prepare(image: Tensor, want_gray: bool):
+    """8-bit rounded image (and grey image), and vals = 2^ceil(log2(#distinct levels)) per image (imgproc.py:892-910)"""
+    b, c, h, w = image.shape
+    img_q = torch.empty_like(image)
+    gray_q = torch.empty(b, 1, h, w, dtype=torch.float32, device=image.device) if want_gray else None
+    vals = torch.empty(b, dtype=torch.float32, device=image.device)
+    vals_gray = torch.empty(b, dtype=torch.float32, device=image.device) if want_gray else None
+    ws = torch.empty(b * 512, dtype=torch.int32, device=image.device)
+    A.check(A.lib().srganfd_poisson_prepare(image.data_ptr(), b, c, h, w, int(want_gray), img_q.data_ptr(), gray_q.data_ptr() if want_gray else None,
+                                            vals.data_ptr(), vals_gray.data_ptr() if want_gray else None, ws.data_ptr(), A.stream_ptr()), "poisson_prepare")
+    return img_q, gray_q, vals, vals_gray
+
+
+def poisson_noise_apply(image, img_q, gray_q, pois, pois_gray, vals, vals_gray, scale, gray_flag, clip: bool, rounds: bool) -> Tensor:
+    """the deterministic part of the Poisson-noise stage on given draws (srganfd_poisson_apply)"""
+    b, c, h, w = image.shape
+    out = torch.empty_like(image)
+    P = lambda t: t.data_ptr() if t is not None else None
+    A.check(A.lib().srganfd_poisson_apply(image.data_ptr(), img_q.data_ptr(), P(gray_q), pois.data_ptr(), P(pois_gray), vals.data_ptr(), P(vals_gray),
+                                          scale.data_ptr(), P(gray_flag), b, c, h, w, int(clip), int(rounds), out.data_ptr(), A.stream_ptr()), "poisson_apply")
+    return out
+
+
+def _add_poisson_noise_torch(image: Tensor, scale=1.0, clip: bool = True, rounds: bool = False, gray_noise=0) -> Tensor:
+    """imgproc._add_poisson_noise_torch (Real_ESRGAN/imgproc.py:1001-1029 over :869-919): torch.poisson draws (grey first, as
+    in the reference) on rates prepared by one HIP pass, everything after the draws in another."""
+    _need_gpu(image, "_add_poisson_noise_torch")
+    x = image.detach().contiguous().float()
+    b, c, h, w = x.shape
+    if isinstance(gray_noise, (float, int)):
+        cal_gray, gray = gray_noise > 0, _per_image(gray_noise, b, x.device)
+    else:
+        gray = _per_image(gray_noise, b, x.device)
+        cal_gray = bool(torch.sum(gray) > 0)
+    img_q, gray_q, vals, vals_gray = poisson_noise_prepare(x, cal_gray)
+    pois_gray = _poisson(gray_q * vals_gray.view(b, 1, 1, 1)) if cal_gray else None
+    pois = _poisson(img_q * vals.view(b, 1, 1, 1))
+    return poisson_noise_apply(x, img_q, gray_q, pois, pois_gray, vals, vals_gray, _per_image(scale, b, x.device), gray if cal_gray else None, clip, rounds)
+
+
+def random_add_poisson_noise_torch(image: Tensor, scale_range: tuple = (0, 1.0), gray_prob: int = 0, clip: bool = True, rounds: bool = False) -> Tensor:
+    """imgproc.random_add_poisson_noise_torch (Real_ESRGAN/imgproc.py:1063-1089 over :946-967)"""
+    b = image.size(0)
+    scale = _draw(torch.rand, b, device=image.device) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    gray_noise = (_draw(torch.rand, b, device=image.device) < gray_prob).float()
+    return _add_poisson_noise_torch(image, scale, clip, rounds, gray_noise)
+
+
+def quantize_u8(x: Tensor) -> Tensor:
+    """clamp(round(x * 255), 0, 255) / 255 -- the last line of degradation_process (Real_ESRGAN/imgproc.py:2460)"""
+    _need_gpu(x, "quantize_u8")
+    xx = x.detach().contiguous().float()
+    out = torch.empty_like(xx)
+    A.check(A.lib().srganfd_quantize_u8(xx.data_ptr(), out.data_ptr(), xx.numel(), A.stream_ptr()), "quantize_u8")
+    return out
+
+
+def _jpeg_quality(out: Tensor, jpeg_range) -> Tensor:
+    """quality = out.new_zeros(b).uniform_(*range) (imgproc.py:2393-2394)"""
+    return torch.zeros(out.size(0), dtype=torch.float32, device=DRAW_DEVICE or out.device).uniform_(*jpeg_range).to(out.device)
+
+
+def degradation_process(gt: Tensor, gaussian_kernel1: Tensor, gaussian_kernel2: Tensor, sinc_kernel: Tensor, upscale_factor: int,
+                        degradation_process_parameters_dict: dict, jpeg_operation: nn.Module = None, usm_sharpener: nn.Module = None):
+    """imgproc.degradation_process (Real_ESRGAN/imgproc.py:2323-2462): the second-order degradation of a GT batch on the
+    GPU -- [sharpen] blur, random resize, Gaussian-or-Poisson noise, JPEG; blur, resize, noise; then resize + sinc filter
+    and JPEG in a random order; 8-bit quantisation.  Host-side draws (numpy / ``random``) are made in the reference's
+    order, so a seeded run takes the same branches; every stage is a HIP kernel of this library.  Returns
+    ``(gt_usm, gt, lr)``.  Differences from the reference, both where it cannot run as written: the sharpener is called
+    as ``usm_sharpener(gt, 0.5, 10)`` (the reference passes no weight / threshold to a forward that requires them;
+    0.5 / 10 are its numpy twin's defaults, :1500), and a skipped first blur passes the image on (the reference would hit
+    an unbound ``out``; its configs use probability 1.0)."""
+    P = degradation_process_parameters_dict
+    image_height, image_width = gt.size()[2:4]
+    gt_usm = gt
+    if usm_sharpener is not None:
+        gt_usm = usm_sharpener(gt, 0.5, 10)
+    out = gt_usm
+    # first degradation: blur, resize, noise, JPEG
+    if np.random.uniform() <= P["first_blur_probability"]:
+        out = filter2d_torch(gt_usm, gaussian_kernel1)
+    updown_type = random.choices(["up", "down", "keep"], P["resize_probability1"])[0]
+    if updown_type == "up":
+        scale = np.random.uniform(1, P["resize_range1"][1])
+    elif updown_type == "down":
+        scale = np.random.uniform(P["resize_range1"][0], 1)
+    else:
+        scale = 1
+    mode = random.choice(["area", "bilinear", "bicubic"])
+    out = interpolate(out, scale_factor=scale, mode=mode)
+    if np.random.uniform() < P["gaussian_noise_probability1"]:
+        out = random_add_gaussian_noise_torch(image=out, sigma_range=P["noise_range1"], clip=True, rounds=False, gray_prob=P["gray_noise_probability1"])
+    else:
+        out = random_add_poisson_noise_torch(image=out, scale_range=P["poisson_scale_range1"], gray_prob=P["gray_noise_probability1"], clip=True,
+                                             rounds=False)
+    quality = _jpeg_quality(out, P["jpeg_range1"])
+    out = jpeg_operation(torch.clamp(out, 0, 1), quality)
+    # second degradation: blur, resize, noise
+    if np.random.uniform() < P["second_blur_probability"]:
+        out = filter2d_torch(out, gaussian_kernel2)
+    updown_type = random.choices(["up", "down", "keep"], P["resize_probability2"])[0]
+    if updown_type == "up":
+        scale = np.random.uniform(1, P["resize_range2"][1])
+    elif updown_type == "down":
+        scale = np.random.uniform(P["resize_range2"][0], 1)
+    else:
+        scale = 1
+    mode = random.choice(["area", "bilinear", "bicubic"])
+    out = interpolate(out, size=(int(image_height / upscale_factor * scale), int(image_width / upscale_factor * scale)), mode=mode)
+    if np.random.uniform() < P["gaussian_noise_probability2"]:
+        out = random_add_gaussian_noise_torch(image=out, sigma_range=P["noise_range2"], clip=True, rounds=False, gray_prob=P["gray_noise_probability2"])
+    else:
+        out = random_add_poisson_noise_torch(image=out, scale_range=P["poisson_scale_range2"], gray_prob=P["gray_noise_probability2"], clip=True,
+                                             rounds=False)
+    final_size = (image_height // upscale_factor, image_width // upscale_factor)
+    if np.random.uniform() < 0.5:
+        # resize back -> sinc filter -> JPEG
+        out = interpolate(out, size=final_size, mode=random.choice(["area", "bilinear", "bicubic"]))
+        out = filter2d_torch(out, sinc_kernel)
+        quality = _jpeg_quality(out, P["jpeg_range2"])
+        out = jpeg_operation(torch.clamp(out, 0, 1), quality)
+    else:
+        # JPEG -> resize back -> sinc filter
+        quality = _jpeg_quality(out, P["jpeg_range2"])
+        out = jpeg_operation(torch.clamp(out, 0, 1), quality)
+        out = interpolate(out, size=final_size, mode=random.choice(["area", "bilinear", "bicubic"]))
+        out = filter2d_torch(out, sinc_kernel)
+    lr = quantize_u8(out)
+    return gt_usm, gt, lr

@@ -546,6 +546,66 @@ def gold_degradation():
         out["jpeg_factor"] = np_(q)                      # the reference converts the tensor it is given in place
         out["jpeg_diff"] = np_(ip.DiffJPEG(True)(img, quality.clone()))
         out["jpeg_scalar_q60"] = np_(ip.DiffJPEG(False)(img[:, :, :32, :48], 60))
+        # noise stages: the reference's own functions under torch.manual_seed (CPU generator); the tests replay the draws
+        sigma = torch.tensor([5.0, 20.0, 12.0])
+        gray = torch.tensor([0.0, 1.0, 0.0])
+        torch.manual_seed(123)
+        out["gauss_gray"] = np_(ip._add_gaussian_noise_torch(img, sigma, True, False, gray))
+        torch.manual_seed(124)
+        out["gauss_color_rounds"] = np_(ip._add_gaussian_noise_torch(img, sigma, True, True, torch.zeros(3)))
+        torch.manual_seed(125)
+        out["gauss_random"] = np_(ip.random_add_gaussian_noise_torch(img, sigma_range=[1, 30], gray_prob=0.4, clip=True, rounds=False))
+        img8 = torch.clamp((img * 255.0).round(), 0, 255) / 255.             # 8-bit image: the Poisson rates are then exact on any device
+        img8[2] = (img8[2] * 255 // 8 * 8) / 255.                            # fewer distinct levels -> a different vals for this image
+        out["poisson_image"] = np_(img8)
+        torch.manual_seed(126)
+        out["poisson_color"] = np_(ip._add_poisson_noise_torch(img8, torch.tensor([0.5, 2.0, 1.0]), True, False, 0))
+        torch.manual_seed(127)
+        out["poisson_random"] = np_(ip.random_add_poisson_noise_torch(img8, scale_range=[0.05, 3], gray_prob=0.0, clip=True, rounds=False))
+        # the whole second-order pipeline on CPU, seeds chosen so that both noise stages are Gaussian (a Poisson stage's draw
+        # count depends on the rates, so a 1e-7 difference upstream would desynchronise the generator) and both final orders occur.
+        # usm_sharpener=None: the reference calls usm_sharpener(gt) without the weight / threshold its forward requires.
+        P = dict(first_blur_probability=1.0, resize_probability1=[0.2, 0.7, 0.1], resize_range1=[0.15, 1.5], gray_noise_probability1=0.4,
+                 gaussian_noise_probability1=0.5, noise_range1=[1, 30], poisson_scale_range1=[0.05, 3], jpeg_range1=[30, 95],
+                 second_blur_probability=0.8, resize_probability2=[0.3, 0.4, 0.3], resize_range2=[0.3, 1.2], gray_noise_probability2=0.4,
+                 gaussian_noise_probability2=0.5, noise_range2=[1, 25], poisson_scale_range2=[0.05, 2.5], jpeg_range2=[30, 95])
+        import random
+        gt = torch.nn.functional.interpolate(torch.rand(2, 3, 16, 16), size=(128, 128), mode="bicubic").clamp(0, 1)
+        gt = (gt + 0.02 * torch.randn_like(gt)).clamp(0, 1)
+        gk1 = torch.rand(2, 21, 21) ** 4
+        gk1 = gk1 / gk1.sum(dim=(1, 2), keepdim=True)
+        gk2 = torch.rand(2, 21, 21) ** 4
+        gk2 = gk2 / gk2.sum(dim=(1, 2), keepdim=True)
+        sk = torch.zeros(2, 21, 21)
+        sk[:, 10, 10] = 1.2
+        sk[:, 9:12, 9:12] -= 0.2 / 9
+        out["pipe_gt"], out["pipe_k1"], out["pipe_k2"], out["pipe_sinc"] = np_(gt), np_(gk1), np_(gk2), np_(sk)
+        orig_g, orig_p = ip.random_add_gaussian_noise_torch, ip.random_add_poisson_noise_torch
+        jpeg_ref = ip.DiffJPEG(False)
+
+        class ContiguousJPEG(torch.nn.Module):
+            """the reference's DiffJPEG returns a permuted view; on the CPU its filter2d_torch then fails in .view(), so the
+            operator handed to degradation_process makes the same values contiguous"""
+            def forward(self, x, quality):
+                return jpeg_ref(x, quality).contiguous()
+        seeds = []
+        for seed in range(400):
+            trace = []
+            ip.random_add_gaussian_noise_torch = lambda *a, **k: (trace.append("g"), orig_g(*a, **k))[1]
+            ip.random_add_poisson_noise_torch = lambda *a, **k: (trace.append("p"), orig_p(*a, **k))[1]
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+            try:
+                _, _, lr = ip.degradation_process(gt, gk1, gk2, sk, 4, P, ContiguousJPEG(), None)
+            except TypeError:
+                continue                                  # grey Poisson noise needs torchvision's rgb_to_grayscale (absent)
+            if trace != ["g", "g"]:
+                continue
+            seeds.append(seed)
+            out[f"pipe_lr_seed{seed}"] = np_(lr)
+            if len(seeds) == 4:
+                break
+        ip.random_add_gaussian_noise_torch, ip.random_add_poisson_noise_torch = orig_g, orig_p
+        out["pipe_seeds"] = np.array(seeds)
     save("degradation.npz", **out)
 
 

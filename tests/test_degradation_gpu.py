@@ -107,3 +107,103 @@ def test_diff_jpeg_other_sizes_vs_oracle():
     # a flat grey image survives exactly: only the DC terms are non-zero and they quantise back to themselves within a step
     grey = torch.full((1, 3, 32, 32), 0.5).cuda()
     assert float((jp(grey, 90) - grey).abs().max()) < 2e-2
+
+
+def test_interpolate_vs_torch_cpu():
+    """the three modes degradation_process draws from, by scale factor (coordinates mapped with 1/scale_factor) and by size"""
+    from oracle import degradation_oracle as D
+    from sr_gan_fd_amd import imgproc
+    torch.manual_seed(2)
+    x = torch.rand(2, 3, 45, 70)
+    for mode in ("area", "bilinear", "bicubic"):
+        for kw in (dict(scale_factor=0.37), dict(scale_factor=1.43), dict(scale_factor=1), dict(scale_factor=0.15), dict(size=(11, 17)), dict(size=(45, 70)),
+                   dict(size=(90, 141)), dict(size=(1, 1))):
+            want = D.interpolate(x, mode=mode, **kw)
+            got = imgproc.interpolate(x.cuda(), mode=mode, **kw)
+            assert tuple(got.shape) == tuple(want.shape), (mode, kw, got.shape, want.shape)
+            _cmp(got, want.numpy(), 2e-6, f"{mode} {kw}")
+    with pytest.raises(ValueError):
+        imgproc.interpolate(x.cuda(), scale_factor=2, mode="nearest")
+
+
+def test_gaussian_noise_matches_reference(golden_dir):
+    """the reference's outputs under torch.manual_seed; the draws are replayed from the CPU generator (DRAW_DEVICE)"""
+    from sr_gan_fd_amd import imgproc
+    g = load_golden(golden_dir, "degradation.npz")
+    img = torch.tensor(g["image"]).cuda()
+    sigma, gray = torch.tensor([5.0, 20.0, 12.0]).cuda(), torch.tensor([0.0, 1.0, 0.0]).cuda()
+    imgproc.DRAW_DEVICE = "cpu"
+    try:
+        torch.manual_seed(123)
+        _cmp(imgproc._add_gaussian_noise_torch(img, sigma, True, False, gray), g["gauss_gray"], 1e-6, "gaussian, grey noise on image 1")
+        torch.manual_seed(124)
+        # rounds=True snaps to the 8-bit grid: a sum within float rounding of a half level may land on the neighbouring level
+        _cmp(imgproc._add_gaussian_noise_torch(img, sigma, True, True, torch.zeros(3).cuda()), g["gauss_color_rounds"], 1e-6, "gaussian colour, rounds",
+             max_bad_frac=1e-4)
+        torch.manual_seed(125)
+        _cmp(imgproc.random_add_gaussian_noise_torch(img, sigma_range=[1, 30], gray_prob=0.4, clip=True, rounds=False), g["gauss_random"], 1e-6,
+             "random_add_gaussian_noise_torch")
+    finally:
+        imgproc.DRAW_DEVICE = None
+    out = imgproc.random_add_gaussian_noise_torch(img, sigma_range=[10, 10], gray_prob=0.0)         # device generator: statistics only
+    d = (out - img)[(img > 0.2) & (img < 0.8)]
+    assert abs(float(d.std()) - 10 / 255) < 2e-3 and abs(float(d.mean())) < 1e-3
+
+
+def test_poisson_noise_matches_reference(golden_dir):
+    from oracle import degradation_oracle as D
+    from sr_gan_fd_amd import imgproc
+    g = load_golden(golden_dir, "degradation.npz")
+    img8 = torch.tensor(g["poisson_image"])
+    iq, gq, vals, vg = imgproc.poisson_noise_prepare(img8.cuda(), True)
+    assert torch.equal(iq.cpu(), img8) and torch.equal(vals.cpu(), D.poisson_vals(img8).flatten())
+    grey8 = torch.clamp((D.rgb_to_grayscale(img8) * 255.0).round(), 0, 255) / 255.
+    assert float((gq.cpu() - grey8).abs().max()) <= 1 / 255 + 1e-6 and float(((gq.cpu() - grey8).abs() > 1e-6).float().mean()) < 1e-3
+    assert torch.equal(vg.cpu(), D.poisson_vals(gq.cpu()).flatten())
+    imgproc.DRAW_DEVICE = "cpu"
+    try:
+        torch.manual_seed(126)
+        _cmp(imgproc._add_poisson_noise_torch(img8.cuda(), torch.tensor([0.5, 2.0, 1.0]).cuda(), True, False, 0), g["poisson_color"], 1e-6, "poisson colour")
+        torch.manual_seed(127)
+        _cmp(imgproc.random_add_poisson_noise_torch(img8.cuda(), scale_range=[0.05, 3], gray_prob=0.0, clip=True, rounds=False), g["poisson_random"], 1e-6,
+             "random_add_poisson_noise_torch")
+        # grey branch (torchvision's rgb_to_grayscale is not in the reference tree: oracle only)
+        torch.manual_seed(128)
+        want = D.add_poisson_noise(img8, torch.tensor([1.0, 1.0, 1.0]), True, False, torch.tensor([1.0, 0.0, 1.0]))
+        torch.manual_seed(128)
+        got = imgproc._add_poisson_noise_torch(img8.cuda(), torch.tensor([1.0, 1.0, 1.0]).cuda(), True, False, torch.tensor([1.0, 0.0, 1.0]).cuda())
+        _cmp(got, want.numpy(), 1e-6, "poisson with grey noise on images 0 and 2", max_bad_frac=2e-2)
+    finally:
+        imgproc.DRAW_DEVICE = None
+
+
+def test_degradation_process_matches_reference(golden_dir):
+    """The whole second-order pipeline against LR batches the reference produced on the CPU (seeds whose noise stages are
+    both Gaussian, see make_golden.py), host draws and torch draws replayed from the same seeds.  The LR output is 8-bit
+    quantised after two JPEG round trips, so a 1e-6 difference upstream can move a DCT coefficient or a final pixel across a
+    rounding boundary: the gate is mean absolute error below a tenth of a grey level and 98 % of the pixels identical."""
+    import random
+    from sr_gan_fd_amd import imgproc
+    from tests.test_oracle_golden import PIPE_PARAMS
+    g = load_golden(golden_dir, "degradation.npz")
+    T = lambda k: torch.tensor(g[k]).cuda()
+    jpeg = imgproc.DiffJPEG().cuda()
+    imgproc.DRAW_DEVICE = "cpu"
+    try:
+        for seed in g["pipe_seeds"]:
+            seed = int(seed)
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+            gt_usm, gt, lr = imgproc.degradation_process(T("pipe_gt"), T("pipe_k1"), T("pipe_k2"), T("pipe_sinc"), 4, PIPE_PARAMS, jpeg, None)
+            want = g[f"pipe_lr_seed{seed}"]
+            err = np.abs(lr.cpu().numpy() - want) * 255
+            print(f"seed {seed}: mean |err| {err.mean():.4f} levels, identical {float((err < 0.5).mean()):.4f}, max {err.max():.1f}")
+            assert tuple(lr.shape) == want.shape and gt_usm is gt
+            assert err.mean() < 0.1 and (err < 0.5).mean() > 0.98
+    finally:
+        imgproc.DRAW_DEVICE = None
+    # with the sharpener and the device generator: shapes, range, 8-bit grid
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    gt_usm, gt, lr = imgproc.degradation_process(T("pipe_gt"), T("pipe_k1"), T("pipe_k2"), T("pipe_sinc"), 4, PIPE_PARAMS, jpeg, imgproc.USMSharp().cuda())
+    assert tuple(lr.shape) == (2, 3, 32, 32) and tuple(gt_usm.shape) == tuple(gt.shape) and not torch.equal(gt_usm, gt)
+    lv = lr * 255
+    assert float(lr.min()) >= 0 and float(lr.max()) <= 1 and float((lv - lv.round()).abs().max()) < 1e-4

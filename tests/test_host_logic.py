@@ -169,6 +169,28 @@ def test_validation_side_argument_checks():
         assert L.srganfd_ssim(p, p, 1, 3, 12, 12, 1, 1, p, 11, p, p, None) != 0            # window does not fit
         assert L.srganfd_ssim(p, p, 1, 1, 16, 16, 0, 1, p, 11, p, p, None) != 0            # luma needs RGB
         assert L.srganfd_ssim(p, p, 1, 3, 32, 32, 0, 0, p, 17, p, p, None) != 0            # window above the kernel's LDS tile
+        # on-device degradation stages (Real_ESRGAN/imgproc.py)
+        assert L.srganfd_filter2d(p, p, 1, 2, 3, 32, 32, 21, p, None) == 0
+        assert L.srganfd_filter2d(p, p, 2, 2, 3, 32, 32, 21, p, None) == 0
+        assert L.srganfd_filter2d(p, p, 1, 2, 3, 32, 32, 4, p, None) != 0 and b"Wrong kernel size." in L.srganfd_last_error()
+        assert L.srganfd_filter2d(p, p, 3, 2, 3, 32, 32, 21, p, None) != 0                   # 3 kernels for 2 images
+        assert L.srganfd_filter2d(p, p, 1, 2, 3, 10, 32, 21, p, None) != 0                   # reflect padding 10 needs > 10 rows
+        assert L.srganfd_filter2d(p, p, 1, 2, 3, 64, 64, 53, p, None) != 0                   # above the LDS tile
+        assert L.srganfd_usm_sharp(p, p, 1, 3, 64, 64, 51, 0.5, 10.0, p, p, None) == 0
+        assert L.srganfd_usm_sharp(p, p, 1, 3, 64, 64, 51, 0.5, 10.0, p, None, None) != 0    # workspace required
+        assert L.srganfd_diff_jpeg_table_floats() == 2 * 4096 + 4 * 64
+        assert L.srganfd_diff_jpeg(p, 2, 3, 17, 33, p, 0, 0, p, p, None) == 0
+        assert L.srganfd_diff_jpeg(p, 2, 1, 16, 16, p, 0, 0, p, p, None) != 0                # RGB only
+        assert L.srganfd_resize(p, 6, 32, 32, 8, 8, 0, 0.0, 0.0, p, None) == 0
+        assert L.srganfd_resize(p, 6, 32, 32, 8, 8, 3, 0.0, 0.0, p, None) != 0               # unknown mode
+        assert L.srganfd_resize(p, 6, 32, 32, 0, 8, 1, 0.0, 0.0, p, None) != 0
+        assert L.srganfd_gaussian_noise(p, p, None, p, None, 2, 3, 8, 8, 1, 0, p, None) == 0
+        assert L.srganfd_gaussian_noise(p, p, p, p, None, 2, 3, 8, 8, 1, 0, p, None) != 0    # grey field without the grey flags
+        assert L.srganfd_poisson_prepare(p, 2, 3, 8, 8, 0, p, None, p, None, p, None) == 0
+        assert L.srganfd_poisson_prepare(p, 2, 1, 8, 8, 1, p, p, p, p, p, None) != 0         # grey needs RGB
+        assert L.srganfd_poisson_apply(p, p, None, p, None, p, None, p, None, 2, 3, 8, 8, 1, 0, p, None) == 0
+        assert L.srganfd_poisson_apply(p, p, None, p, p, p, None, p, None, 2, 3, 8, 8, 1, 0, p, None) != 0
+        assert L.srganfd_quantize_u8(p, p, 64, None) == 0 and L.srganfd_quantize_u8(p, p, 0, None) != 0
     finally:
         A.set_dry_run(False)
 

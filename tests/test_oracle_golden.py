@@ -273,6 +273,46 @@ def test_validation_side(golden_dir):
         assert np.array_equal(pg.numpy(), g[f"crop{seed}_gt"]) and np.array_equal(pl.numpy(), g[f"crop{seed}_lr"])
 
 
+PIPE_PARAMS = dict(first_blur_probability=1.0, resize_probability1=[0.2, 0.7, 0.1], resize_range1=[0.15, 1.5], gray_noise_probability1=0.4,
+                   gaussian_noise_probability1=0.5, noise_range1=[1, 30], poisson_scale_range1=[0.05, 3], jpeg_range1=[30, 95],
+                   second_blur_probability=0.8, resize_probability2=[0.3, 0.4, 0.3], resize_range2=[0.3, 1.2], gray_noise_probability2=0.4,
+                   gaussian_noise_probability2=0.5, noise_range2=[1, 25], poisson_scale_range2=[0.05, 2.5], jpeg_range2=[30, 95])
+
+
+def test_degradation_oracle(golden_dir):
+    """Real_ESRGAN/imgproc.py restatements (filter2d_torch, USMSharp, DiffJPEG, the noise stages, degradation_process) vs
+    outputs of the reference's own functions: same torch CPU ops and the same generator stream, so bit-exact."""
+    import random
+    from oracle import degradation_oracle as D
+    g = load_golden(golden_dir, "degradation.npz")
+    T = lambda k: torch.tensor(g[k])
+    same = lambda a, k: np.array_equal(a.numpy(), g[k])
+    img = T("image")
+    assert same(D.filter2d(img, T("kernels21")), "filter2d_per_image") and same(D.filter2d(img, T("kernels21")[:1]), "filter2d_shared")
+    assert same(D.filter2d(img, T("kernel7")), "filter2d_k7")
+    assert same(D.usm_kernel(50, 0), "usm_kernel")
+    assert same(D.usm_sharp(T("usm_image"), D.usm_kernel(), 0.5, 10), "usm_w05_t10") and same(D.usm_sharp(T("usm_image"), D.usm_kernel(), 1.5, 3), "usm_w15_t3")
+    f = D.quality_to_factor(T("jpeg_quality"))
+    assert same(f, "jpeg_factor") and same(D.diff_jpeg(img, f), "jpeg") and same(D.diff_jpeg(img, f, True), "jpeg_diff")
+    assert same(D.diff_jpeg(img[:, :, :32, :48], torch.full((3,), 0.8)), "jpeg_scalar_q60")
+    sigma, gray = torch.tensor([5.0, 20.0, 12.0]), torch.tensor([0.0, 1.0, 0.0])
+    torch.manual_seed(123)
+    assert same(D.add_gaussian_noise(img, sigma, True, False, gray), "gauss_gray")
+    torch.manual_seed(124)
+    assert same(D.add_gaussian_noise(img, sigma, True, True, torch.zeros(3)), "gauss_color_rounds")
+    torch.manual_seed(125)
+    assert same(D.random_add_gaussian_noise(img, [1, 30], 0.4), "gauss_random")
+    torch.manual_seed(126)
+    assert same(D.add_poisson_noise(T("poisson_image"), torch.tensor([0.5, 2.0, 1.0]), True, False, 0), "poisson_color")
+    torch.manual_seed(127)
+    assert same(D.random_add_poisson_noise(T("poisson_image"), [0.05, 3], 0.0), "poisson_random")
+    for seed in g["pipe_seeds"]:
+        seed = int(seed)
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        _, _, lr = D.degradation_process(T("pipe_gt"), T("pipe_k1"), T("pipe_k2"), T("pipe_sinc"), 4, PIPE_PARAMS)
+        assert same(lr, f"pipe_lr_seed{seed}"), seed
+
+
 def _esrgan_d():
     from sr_gan_fd_amd import model as M
     torch.manual_seed(0)
