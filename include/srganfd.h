@@ -287,10 +287,15 @@ int srganfd_ssim(const float* a, const float* b, int32_t n, int32_t c, int32_t h
  * ("Wrong kernel size." for an even k, like the reference's ValueError). */
 int srganfd_filter2d(const float* image, const float* kernels, int32_t kernel_batch, int32_t b, int32_t c, int32_t h,
                      int32_t w, int32_t k, float* out, void* stream);
+/* the same filter when kernels[n] is an outer product: taps = per image (or shared) [k vertical taps | k horizontal taps];
+ * a horizontal pass through LDS then the vertical one, 2k instead of k*k multiply-adds per pixel. */
+int srganfd_filter2d_separable(const float* image, const float* taps, int32_t kernel_batch, int32_t b, int32_t c, int32_t h,
+                               int32_t w, int32_t k, float* out, void* stream);
 /* USMSharp.forward (imgproc.py:1529-1540): blur with the shared k x k kernel, residual, |residual|*255 > threshold mask,
- * blurred mask, blend -- two fused filter passes.  workspace: 2 * b*c*h*w floats. */
-int srganfd_usm_sharp(const float* image, const float* kernel, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k,
-                      float weight, float threshold, float* out, float* workspace, void* stream);
+ * blurred mask, blend -- two fused filter passes.  separable != 0: `kernel` holds 2k taps as for
+ * srganfd_filter2d_separable (USMSharp's kernel is the outer product of a 1-D Gaussian).  workspace: 2 * b*c*h*w floats. */
+int srganfd_usm_sharp(const float* image, const float* kernel, int32_t separable, int32_t b, int32_t c, int32_t h, int32_t w,
+                      int32_t k, float weight, float threshold, float* out, float* workspace, void* stream);
 /* DiffJPEG.forward (imgproc.py:1465-1497): RGB NCHW fp32 in [0,1] -> JPEG round trip (4:2:0, zero-padded to multiples of
  * 16, cropped back).  quality: b floats in device memory, converted IN PLACE to the compression factor
  * (imgproc.py:1127-1144, :1476-1480) unless quality_is_factor; differentiable = the cubic rounding of :1183-1195.

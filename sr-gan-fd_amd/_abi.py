@@ -104,7 +104,8 @@ SYMBOLS = {
     "srganfd_crop_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "srganfd_psnr": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_filter2d": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
-    "srganfd_usm_sharp": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_filter2d_separable": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "srganfd_usm_sharp": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_diff_jpeg_table_floats": (C.c_int32, []),
     "srganfd_diff_jpeg_tables": (C.c_int, [C.c_void_p]),
     "srganfd_diff_jpeg": (C.c_int, [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -46,7 +46,7 @@ int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, 
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
 int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
-                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s);
+                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s, bool separable = false);
 void diff_jpeg_tables_host(float* t);
 int jpeg_table_floats();
 int diff_jpeg_impl(const float* src, int b, int c, int h, int w, float* quality, int quality_is_factor, int differentiable, const float* tables,
@@ -191,15 +191,19 @@ int srganfd_filter2d(const float* image, const float* kernels, int32_t kernel_ba
                      void* stream) {
   return filter2d_impl(image, kernels, kernel_batch, b, c, h, w, k, 0, nullptr, nullptr, 0.f, 0.f, out, nullptr, (hipStream_t)stream);
 }
-int srganfd_usm_sharp(const float* image, const float* kernel, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k, float weight, float threshold,
-                      float* out, float* workspace, void* stream) {
+int srganfd_usm_sharp(const float* image, const float* kernel, int32_t separable, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k, float weight,
+                      float threshold, float* out, float* workspace, void* stream) {
   if (!workspace) return set_err(SRGANFD_EINVAL, "usm_sharp: workspace of 2 * b*c*h*w floats needed");
   const size_t n = (size_t)b * c * h * w;
   float* residual = workspace;
   float* mask = workspace + n;
-  int rc = filter2d_impl(image, kernel, 1, b, c, h, w, k, 1, nullptr, nullptr, weight, threshold, residual, mask, (hipStream_t)stream);
+  int rc = filter2d_impl(image, kernel, 1, b, c, h, w, k, 1, nullptr, nullptr, weight, threshold, residual, mask, (hipStream_t)stream, separable != 0);
   if (rc != SRGANFD_OK) return rc;
-  return filter2d_impl(mask, kernel, 1, b, c, h, w, k, 2, image, residual, weight, threshold, out, nullptr, (hipStream_t)stream);
+  return filter2d_impl(mask, kernel, 1, b, c, h, w, k, 2, image, residual, weight, threshold, out, nullptr, (hipStream_t)stream, separable != 0);
+}
+int srganfd_filter2d_separable(const float* image, const float* taps, int32_t kernel_batch, int32_t b, int32_t c, int32_t h, int32_t w, int32_t k,
+                               float* out, void* stream) {
+  return filter2d_impl(image, taps, kernel_batch, b, c, h, w, k, 0, nullptr, nullptr, 0.f, 0.f, out, nullptr, (hipStream_t)stream, true);
 }
 int32_t srganfd_diff_jpeg_table_floats(void) { return jpeg_table_floats(); }
 int srganfd_diff_jpeg_tables(float* host_out) {

@@ -23,17 +23,23 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return min(max(i, 0), n - 1);   // only positions no output reads get clamped
 }
 
+// SEP: the k x k filter is the outer product kcol (vertical taps) x krow (horizontal taps), handed over as kernels[0..k) and
+// kernels[k..2k): a horizontal pass into a second LDS image, then the same sliding-window pass vertically -- 2k instead of
+// k*k multiply-adds per pixel (the 51x51 Gaussian of the USM sharpener: 25x fewer).
+template <bool SEP>
 __global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__ src, const float* __restrict__ kernels, int kernel_batch, int c, int h,
                                                        int w, int k, int tiles_x, int mode, const float* __restrict__ x_in,
                                                        const float* __restrict__ res_in, float weight, float threshold, float* __restrict__ out,
                                                        float* __restrict__ out2) {
   constexpr int kPitch = kF2dCols + kF2dMaxK - 1;               // 114
-  constexpr int kTileRows = kF2dRows + kF2dMaxK - 1 + 8;        // the unrolled window may address (never use) 8 rows past the halo
+  constexpr int kTileRows = kF2dRows + kF2dMaxK - 1 + (SEP ? 0 : 8);   // the unrolled window may address (never use) 8 rows past the halo
+  constexpr int kHRows = SEP ? kF2dRows + kF2dMaxK - 1 + 8 : 1;
   __shared__ float tile[kTileRows * kPitch];
+  __shared__ float hbuf[kHRows * kF2dCols];
   const int plane = blockIdx.y, img = plane / c;
   const int ty_base = (blockIdx.x / tiles_x) * kF2dRows, tx_base = (blockIdx.x % tiles_x) * kF2dCols;
   const float* sp = src + (size_t)plane * h * w;
-  const float* kw = kernels + (kernel_batch > 1 ? (size_t)img * k * k : 0);
+  const float* kw = kernels + (kernel_batch > 1 ? (size_t)img * (SEP ? 2 * k : k * k) : 0);
   const int r = k / 2, in_rows = kF2dRows + k - 1, in_cols = kF2dCols + k - 1;
   for (int i = threadIdx.x; i < in_rows * in_cols; i += 256) {
     const int iy = i / in_cols, ix = i % in_cols;
@@ -44,18 +50,31 @@ __global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__
   float acc[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-  for (int kx = 0; kx < k; ++kx) {
-    const float* col = tile + ty0 * kPitch + tx + kx;
+  if (SEP) {
+    const float* krow = kw + k;
+    for (int row = threadIdx.x >> 6; row < in_rows; row += 4) {
+      const float* tr = tile + row * kPitch + tx;
+      float a = 0.f;
+      for (int kx = 0; kx < k; ++kx) a = fmaf(krow[kx], tr[kx], a);
+      hbuf[row * kF2dCols + tx] = a;
+    }
+    __syncthreads();
+  }
+  const int n_kx = SEP ? 1 : k;
+  const int pitch = SEP ? kF2dCols : kPitch;
+  const int tap_stride = SEP ? 1 : k;
+  for (int kx = 0; kx < n_kx; ++kx) {
+    const float* col = (SEP ? hbuf : tile) + ty0 * pitch + tx + kx;
     float win[8];
 #pragma unroll
-    for (int o = 0; o < 7; ++o) win[o] = col[o * kPitch];
+    for (int o = 0; o < 7; ++o) win[o] = col[o * pitch];
     for (int ky0 = 0; ky0 < k; ky0 += 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ky = ky0 + j;
         if (ky < k) {                                          // wave-uniform
-          win[(j + 7) & 7] = col[(ky + 7) * kPitch];
-          const float wv = kw[ky * k + kx];
+          win[(j + 7) & 7] = col[(ky + 7) * pitch];
+          const float wv = kw[ky * tap_stride + kx];
 #pragma unroll
           for (int o = 0; o < 8; ++o) acc[o] = fmaf(wv, win[(j + o) & 7], acc[o]);
         }
@@ -84,7 +103,7 @@ __global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__
 }
 
 int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
-                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s) {
+                  const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s, bool separable = false) {
   if (!src || !kernels || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0) return set_err(SRGANFD_EINVAL, "filter2d: null / empty argument");
   if (k % 2 == 0 || k < 1) return set_err(SRGANFD_EINVAL, "Wrong kernel size.");                     // the reference's ValueError text
   if (k > kF2dMaxK) return set_err(SRGANFD_EINVAL, "filter2d: kernel size %d above the LDS tile's %d", k, kF2dMaxK);
@@ -93,8 +112,12 @@ int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int 
   if ((mode == 1 && !out2) || (mode == 2 && (!x_in || !res_in)) || mode < 0 || mode > 2) return set_err(SRGANFD_EINVAL, "filter2d: bad epilogue arguments");
   if ((long long)b * c > 65535) return set_err(SRGANFD_EINVAL, "filter2d: more than 65535 planes");
   const int tiles_x = ceil_div(w, kF2dCols), tiles_y = ceil_div(h, kF2dRows);
-  SRGANFD_LAUNCH(filter2d_kernel, dim3(tiles_x * tiles_y, b * c), dim3(256), 0, s, src, kernels, kernel_batch, c, h, w, k, tiles_x, mode, x_in, res_in,
-                 weight, threshold, out, out2);
+  if (separable)
+    SRGANFD_LAUNCH(filter2d_kernel<true>, dim3(tiles_x * tiles_y, b * c), dim3(256), 0, s, src, kernels, kernel_batch, c, h, w, k, tiles_x, mode, x_in, res_in,
+                   weight, threshold, out, out2);
+  else
+    SRGANFD_LAUNCH(filter2d_kernel<false>, dim3(tiles_x * tiles_y, b * c), dim3(256), 0, s, src, kernels, kernel_batch, c, h, w, k, tiles_x, mode, x_in, res_in,
+                   weight, threshold, out, out2);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

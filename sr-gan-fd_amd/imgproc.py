@@ -80,15 +80,33 @@ class USMSharp(nn.Module):
         kernel = torch.FloatTensor(np.dot(kernel, kernel.transpose())).unsqueeze_(0)
         self.register_buffer("kernel", kernel)
 
+    def _taps(self, device) -> Tuple[Tensor, int]:
+        """(filter operand, separable flag).  The constructor's kernel is an outer product, so the two passes run as a
+        horizontal + a vertical 1-D filter (2k instead of k*k multiply-adds per pixel); a ``kernel`` buffer that was replaced
+        by something of higher rank is detected (checked once per buffer version) and run as the full 2-D filter."""
+        key = (self.kernel.data_ptr(), self.kernel._version, str(device))
+        if getattr(self, "_taps_key", None) != key:
+            k2 = self.kernel.detach().double().cpu().reshape(self.radius, self.radius)
+            mid = self.radius // 2
+            sep = None
+            if float(k2[mid, mid]) != 0.0:
+                col, row = k2[:, mid] / k2[mid, mid], k2[mid, :]
+                if float((torch.outer(col, row) - k2).abs().max()) <= 1e-6 * float(k2.abs().max()):    # fp32 rounding of the stored outer product is ~2e-7
+                    sep = torch.cat([col, row]).float()
+            self._taps_cache = ((sep, 1) if sep is not None else (self.kernel.detach().float().contiguous(), 0))
+            self._taps_cache = (self._taps_cache[0].to(device), self._taps_cache[1])
+            self._taps_key = key
+        return self._taps_cache
+
     def forward(self, x: Tensor, weight: float, threshold: int) -> Tensor:
         _need_gpu(x, "USMSharp")
         xx = x.detach().contiguous().float()
         b, c, h, w = xx.shape
-        kk = self.kernel.to(device=xx.device, dtype=torch.float32).contiguous()
+        kk, separable = self._taps(xx.device)
         out = torch.empty_like(xx)
         ws = torch.empty(2 * xx.numel(), dtype=torch.float32, device=xx.device)
-        A.check(A.lib().srganfd_usm_sharp(xx.data_ptr(), kk.data_ptr(), b, c, h, w, self.radius, float(weight), float(threshold), out.data_ptr(),
-                                          ws.data_ptr(), A.stream_ptr()), "usm_sharp")
+        A.check(A.lib().srganfd_usm_sharp(xx.data_ptr(), kk.data_ptr(), separable, b, c, h, w, self.radius, float(weight), float(threshold),
+                                          out.data_ptr(), ws.data_ptr(), A.stream_ptr()), "usm_sharp")
         return out
 
 

@@ -69,6 +69,24 @@ def test_usm_sharp_matches_reference(golden_dir):
     _cmp(usm(big, 0.5, 10), g["usm_w05_t10"], 1e-5, "usm w=0.5 t=10 (tight, few pixels)", max_bad_frac=0.02)
     flat = torch.full((1, 3, 64, 64), 0.25).cuda()
     assert torch.allclose(usm(flat, 0.5, 10), flat, atol=1e-6)              # nothing to sharpen
+    assert usm._taps(big.device)[1] == 1                                    # the Gaussian ran as two 1-D passes
+    # a kernel buffer that is not an outer product runs as the full 2-D filter (same entry point, separable = 0)
+    from oracle import degradation_oracle as D
+    torch.manual_seed(4)
+    odd = torch.rand(1, 51, 51)
+    odd = odd / odd.sum()
+    usm.kernel.copy_(odd.cuda())
+    assert usm._taps(big.device)[1] == 0
+    _cmp(usm(big, 0.7, 5), D.usm_sharp(torch.tensor(g["usm_image"]), odd, 0.7, 5).numpy(), 1e-4, "usm with a rank-51 kernel")
+    # the separable entry point by itself, per-image taps
+    from sr_gan_fd_amd import _abi as A
+    img = torch.rand(2, 3, 50, 90)
+    taps = torch.rand(2, 2, 9)
+    k2 = torch.einsum("bi,bj->bij", taps[:, 0], taps[:, 1])
+    got = torch.empty_like(img).cuda()
+    xi, tp = img.cuda(), taps.cuda().contiguous()
+    A.check(A.lib().srganfd_filter2d_separable(xi.data_ptr(), tp.data_ptr(), 2, 2, 3, 50, 90, 9, got.data_ptr(), A.stream_ptr()), "filter2d_separable")
+    _cmp(got, D.filter2d(img, k2).numpy(), 2e-5, "separable per-image 9x9 (taps sum to ~20)")
 
 
 def _jpeg_check(got, want, what):

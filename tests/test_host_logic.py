@@ -176,8 +176,9 @@ def test_validation_side_argument_checks():
         assert L.srganfd_filter2d(p, p, 3, 2, 3, 32, 32, 21, p, None) != 0                   # 3 kernels for 2 images
         assert L.srganfd_filter2d(p, p, 1, 2, 3, 10, 32, 21, p, None) != 0                   # reflect padding 10 needs > 10 rows
         assert L.srganfd_filter2d(p, p, 1, 2, 3, 64, 64, 53, p, None) != 0                   # above the LDS tile
-        assert L.srganfd_usm_sharp(p, p, 1, 3, 64, 64, 51, 0.5, 10.0, p, p, None) == 0
-        assert L.srganfd_usm_sharp(p, p, 1, 3, 64, 64, 51, 0.5, 10.0, p, None, None) != 0    # workspace required
+        assert L.srganfd_filter2d_separable(p, p, 1, 2, 3, 64, 64, 51, p, None) == 0
+        assert L.srganfd_usm_sharp(p, p, 0, 1, 3, 64, 64, 51, 0.5, 10.0, p, p, None) == 0 and L.srganfd_usm_sharp(p, p, 1, 1, 3, 64, 64, 51, 0.5, 10.0, p, p, None) == 0
+        assert L.srganfd_usm_sharp(p, p, 0, 1, 3, 64, 64, 51, 0.5, 10.0, p, None, None) != 0    # workspace required
         assert L.srganfd_diff_jpeg_table_floats() == 2 * 4096 + 4 * 64
         assert L.srganfd_diff_jpeg(p, 2, 3, 17, 33, p, 0, 0, p, p, None) == 0
         assert L.srganfd_diff_jpeg(p, 2, 1, 16, 16, p, 0, 0, p, p, None) != 0                # RGB only
