@@ -49,6 +49,14 @@ PMC_TRAFFIC_BYTES = {
     "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": (2 * 2.538e6 + 1.622e6) * 64,
     "wgrad_kernel<bf16,KS=3,S=1>+reduce": (2 * (4.339e6 + 2.959e5) + 5.907e5 + 1.112e5) * 64,
 }
+# MFMA-pipe utilisation from a third rocprofv3 pass (profiles/r01_pmc_mfma_busy.txt):
+#     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); the counter is 32 cycles per v_mfma_f32_32x32x16_bf16.
+PMC_MFMA_UTIL = {
+    "g_only": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.237, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.373,
+               "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.388},
+    "gan": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.236, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.396,
+            "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.417},
+}
 NODES = ["features.2", "features.7", "features.16", "features.25", "features.34"]   # bsrgan_config.py:130-132
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
@@ -199,6 +207,8 @@ def main():
             out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS, PEAK_HBM_GBPS)
             if args.workload == "g_only" and B == 32 and h == 128:   # PMC figures were taken on this exact workload
                 out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get(out["roofline"]["kernel"])
+            if B == 32 and h == 128 and args.workload in PMC_MFMA_UTIL:
+                out["roofline"]["mfma_busy_pmc"] = PMC_MFMA_UTIL[args.workload].get(out["roofline"]["kernel"])
             out["kernel_classes"] = profiling.summary(rec)
         if not args.no_cpu_baseline and world == 1:      # host-side legs: rank 0 of the single-GPU run only
             out["sr_parity"] = sr_parity(h, args.num_rrdb, dev)

@@ -28,6 +28,7 @@ __all__ = [
     "discriminator_unet", "bsrgan_x2", "bsrgan_x4", "content_loss",
     "rrdbnet_x1", "rrdbnet_x2", "rrdbnet_x4", "rrdbnet_x8",
     "UNetDiscriminatorAesrgan", "uNetDiscriminatorAesrgan",
+    "Discriminator", "discriminator",
 ]
 
 
