@@ -232,13 +232,13 @@ class TrunkEngine:
             return torch.empty(*shape, dtype=dtype, device=device)
 
         if train:
-            sp.cat = [new(N, H, W, Ccat) for _ in range(R + 1)]
-            catb = lambda i: sp.cat[i]
+            cat = sp.cat = [new(N, H, W, Ccat) for _ in range(R + 1)]
+            catb = lambda i: cat[i]            # (captures the list, not `sp`: a closure stored on sp that refers to sp is a cycle)
         else:
             # inference: block 0's buffer is kept (conv2 adds out1, model.py:369-370); the rest rotate.
             # block i reads buffer i, writes i+1, and (last block of an RRDB) re-reads i-2: 4 buffers suffice.
-            sp.cat = [new(N, H, W, Ccat) for _ in range(min(R + 1, 5))]
-            catb = lambda i: sp.cat[0] if i == 0 else sp.cat[1 + (i - 1) % 4]
+            cat = sp.cat = [new(N, H, W, Ccat) for _ in range(min(R + 1, 5))]
+            catb = lambda i: cat[0] if i == 0 else cat[1 + (i - 1) % 4]
         sp.catb = catb
         V = A.view
 

@@ -17,6 +17,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
+import weakref
+
 import torch
 from torch import Tensor, nn
 
@@ -138,7 +140,8 @@ class AesrganDiscriminatorEngine:
         V = A.view
         L = A.lib()
         fptr, wptr, O = self.fp.flat.data_ptr(), pk["buf"].data_ptr(), pk["offs"]
-        P = lambda name: fptr + 4 * self._poff(name)
+        me = weakref.proxy(self)                    # closures stored on the plan must not hold the engine (reference cycle)
+        P = lambda name: fptr + 4 * me._poff(name)
         Wp = lambda *key: wptr + O[key]
         nf = self.nf
 

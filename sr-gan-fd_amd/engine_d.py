@@ -148,8 +148,11 @@ class DiscriminatorEngine:
             cv(V(sp.c2), V(sp.c3), wptr + O[("f", "conv3")], N, H, W, 64, 64, **lre),
         ]
         sp.fw = fw
-        sp.conv4 = lambda logits: ops.conv_args(dtc, V(sp.c3), A.View(logits.data_ptr(), self.out_ch, 0), wptr + O[("f", "conv4")], N, H, W, 64, 32,
-                                                 cout_store=self.out_ch, bias=fptr + 4 * self._poff("conv4.bias"), y_f32=True)
+        # locals only: a closure stored on sp that captured `sp` or `self` would be a reference cycle, and the plan's activation
+        # buffers would then outlive the module until a cyclic collection (found as an OOM between full-size tests)
+        c3_v, out_ch, w4, b4 = V(sp.c3), self.out_ch, wptr + O[("f", "conv4")], fptr + 4 * self._poff("conv4.bias")
+        sp.conv4 = lambda logits: ops.conv_args(dtc, c3_v, A.View(logits.data_ptr(), out_ch, 0), w4, N, H, W, 64, 32,
+                                                 cout_store=out_ch, bias=b4, y_f32=True)
         self._plan_backward(sp, pk)
         self.shapes[key] = sp
         return sp

@@ -128,8 +128,9 @@ class EsrganDiscriminatorEngine:
                           pad=0, bias=fptr + 4 * self._poff("classifier.0.bias"), act=A.ACT_LRELU, slope=SLOPE)
         fw.append(("conv", a))
         sp.fw = fw
-        sp.fc2 = lambda logits: ops.conv_args(dtc, V(sp.f1), A.View(logits.data_ptr(), 1, 0), wptr + O[("f", "fc2")], N, 1, 1, self.hid_pad, 32,
-                                               cout_store=1, ksize=1, pad=0, bias=fptr + 4 * self._poff("classifier.2.bias"), y_f32=True)
+        f1_v, hid, w2, b2 = V(sp.f1), self.hid_pad, wptr + O[("f", "fc2")], fptr + 4 * self._poff("classifier.2.bias")   # no `sp` / `self` in the closure
+        sp.fc2 = lambda logits: ops.conv_args(dtc, f1_v, A.View(logits.data_ptr(), 1, 0), w2, N, 1, 1, hid, 32,
+                                               cout_store=1, ksize=1, pad=0, bias=b2, y_f32=True)
         sp.bn_ws = torch.empty(2048 * 256 + 3 * 256, dtype=torch.float32, device=device)
         self._plan_backward(sp, pk)
         self.shapes[key] = sp

@@ -227,3 +227,48 @@ def test_modules_deepcopy_and_pickle_like_the_train_scripts_do():
                     clone(torch.rand(1, 3, 64, 64))
     finally:
         A.set_dry_run(False)
+
+
+def test_engines_release_their_buffers_by_reference_counting():
+    """A plan closure that captures its engine or its own plan object is a reference cycle: the activation buffers (hundreds of
+    GB at the benchmark sizes) then outlive the module until a cyclic collection that HIP allocations never trigger -- an
+    out-of-memory error between two full-size tests.  After dropping the modules, the cyclic collector must find no tensor
+    and no engine."""
+    import gc
+    from sr_gan_fd_amd import _abi as A, model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    A.set_dry_run(True)
+    gc.collect()
+    gc.disable()
+    try:
+        for dfac in (lambda: M.discriminator_unet(in_channels=3, out_channels=1, channels=64), M.uNetDiscriminatorAesrgan, M.discriminator):
+            g, d, cl, cl1 = M.bsrgan_x4(num_rrdb=1), dfac(), M.ContentLoss(nodes, mean, std), M.ContentLoss("features.34", mean, std)
+            if dfac is M.discriminator:
+                x = torch.rand(2, 3, 128, 128, requires_grad=True)
+                d(x).sum().backward()
+                sr = torch.rand(2, 3, 32, 32, requires_grad=True)
+                cl1(sr, torch.rand(2, 3, 32, 32)).backward()
+                y = g(torch.rand(2, 3, 16, 16))
+                y.sum().backward()
+                del x, sr, y
+            else:
+                tr = GanTrainer(g, d, cl)
+                tr.step(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64))
+                del tr
+            del g, d, cl, cl1
+            gc.set_debug(gc.DEBUG_SAVEALL)
+            gc.collect()
+            leaked = []
+            for o in gc.garbage:
+                name = type(o).__name__            # (type(), not isinstance(): dead weakref proxies sit in the garbage list too)
+                if type(o) is torch.Tensor or "Engine" in name or name in ("_Shape", "FlatParams"):
+                    leaked.append(name)
+            gc.garbage.clear()
+            gc.set_debug(0)
+            assert not leaked, f"kept alive only by reference cycles: {sorted(set(leaked))} ({len(leaked)} objects)"
+    finally:
+        gc.set_debug(0)
+        gc.garbage.clear()
+        gc.enable()
+        A.set_dry_run(False)
