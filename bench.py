@@ -33,8 +33,10 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0      # HBM3E peak (same guide)
 # algorithmic FLOP per image, SURVEY.md 8(d): 1 MAC = 2 FLOP, backward = 2x forward
-FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9}
-BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192}     # the input size those figures are quoted at
+# esrgan_gan (ESRGAN/train_esrgan.py:364-431 at 32 -> 128, the discriminator's fixed input size): generator fwd+bwd
+# 1762.3/16 GFLOP, five discriminator forwards + three backwards of ~1.0 GFLOP each, VGG-19[:35] fwd on SR and GT + bwd on SR
+FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9, "esrgan_gan": 1762.3e9 / 16 + 11 * 1.0e9 + 4 * 5.1e9}
+BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32}     # the input size those figures are quoted at
 
 
 # Memory-side bytes per launch of the dominant kernels from separate `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum`
@@ -95,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan", "aesrgan_gan"])
+    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan", "aesrgan_gan", "esrgan_gan"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--lr-size", type=int, default=0, help="LR image side (default 128; 192 for aesrgan_gan)")
     ap.add_argument("--num-rrdb", type=int, default=23)
@@ -142,7 +144,11 @@ def main():
     g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)
     g.compute_dtype = torch.bfloat16
     g.to(dev)
-    if args.workload == "g_only":
+    if args.workload == "esrgan_gan":
+        if world > 1 or h != 32:
+            raise SystemExit("esrgan_gan: single GPU, 32 -> 128 only (the discriminator's classifier fixes the 128x128 input, ESRGAN/model.py:118-122)")
+        step_fn = esrgan_loop(M, g, dev)
+    elif args.workload == "g_only":
         # BSRGAN/bsrnet_config.py:86-96 hyper-parameters
         trainer = GeneratorTrainer(g, lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999, process_group=pg)
         step_fn = trainer.step
@@ -197,6 +203,8 @@ def main():
         "config": {"workload": {"g_only": "BSRGAN RRDBNet x4 generator-only (L1), %d RRDB, batch %d/GPU, %d->%d",
                                 "gan": "BSRGAN full GAN step (RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "aesrgan_gan": "A-ESRGAN full GAN step (RRDBNet %d RRDB + attention U-Net D + VGG19 content), batch %d/GPU, %d->%d",
+                                "esrgan_gan": "ESRGAN relativistic GAN step, the script's own loop over the drop-in modules (RRDBNet %d RRDB + BatchNorm D "
+                                              "+ differentiable VGG19 content), batch %d/GPU, %d->%d",
                                 }[args.workload] % (args.num_rrdb, B, h, 4 * h),
                    "global_batch": B * world, "num_rrdb": args.num_rrdb, "parallelism": "dp%d" % world,
                    "flop_per_image": flop_img},
@@ -216,6 +224,45 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def esrgan_loop(M, g, dev):
+    """ESRGAN/train_esrgan.py:364-431 as the script writes it -- torch.optim.Adam, BCEWithLogitsLoss / L1Loss, autograd with
+    retain_graph and three live discriminator forwards -- over the drop-in modules (esrgan_config.py:75-92 hyper-parameters)."""
+    import torch
+    d = M.discriminator()
+    cl = M.ContentLoss("features.34", MEAN, STD)          # a str node selects ESRGAN's differentiable single-tap loss
+    d.compute_dtype = cl.compute_dtype = torch.bfloat16
+    d.to(dev).train()
+    cl.to(dev)
+    g.train()
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+
+    def step(lr, gt):
+        B = gt.shape[0]
+        real, fake = torch.full([B, 1], 1.0, device=dev), torch.full([B, 1], 0.0, device=dev)
+        for p in d.parameters():
+            p.requires_grad = False
+        g.zero_grad(set_to_none=True)
+        sr = g(lr)
+        gt_output = d(gt.detach().clone())
+        sr_output = d(sr)
+        loss = 0.01 * l1(sr, gt) + 1.0 * cl(sr, gt) + 0.005 * (bce(gt_output - torch.mean(sr_output), fake) * 0.5 +
+                                                              bce(sr_output - torch.mean(gt_output), real) * 0.5)
+        loss.backward()
+        g_opt.step()
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        sr_output = d(sr.detach().clone())
+        (bce(gt_output - torch.mean(sr_output), real) * 0.5).backward(retain_graph=True)
+        sr_output = d(sr.detach().clone())
+        (bce(sr_output - torch.mean(gt_output), fake) * 0.5).backward()
+        d_opt.step()
+    return step
 
 
 def sr_parity(h: int, num_rrdb: int, dev):
@@ -265,6 +312,22 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
     n_it = 9
     d_forward, hp = None, dict(g_lr=8e-5, d_lr=2e-4, pixel_weight=20.0, adversarial_weight=0.5)
+    if workload == "esrgan_gan":
+        n_it, bsz = 4, 4
+        lr_img, gt = torch.rand(bsz, 3, h, h), torch.rand(bsz, 3, 4 * h, 4 * h)
+        d = M.discriminator()
+        D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+        d_opt = O.AdamState(D, [k for k in D if k.endswith((".weight", ".bias"))])
+        cl = M.ContentLoss("features.34", MEAN, STD)
+        VP = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
+        times = []
+        for it in range(n_it):
+            t0 = time.perf_counter()
+            O.esrgan_gan_step(G, D, opt, d_opt, lr_img, gt, content_fn=lambda sr, gt_: O.content_loss_single(sr, gt_, VP, "features.34", MEAN, STD))
+            times.append(time.perf_counter() - t0)
+            log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
+        return {"value": round(bsz / min(times[1:]), 4), "unit": "img/s", "cores": cores, "kind": "port",
+                "sample": "batch %d, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (bsz, h, 4 * h, n_it - 1)}
     if workload != "g_only":
         n_it = 4 if workload == "gan" else 3
         if workload == "aesrgan_gan":
