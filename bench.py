@@ -35,8 +35,9 @@ PEAK_HBM_GBPS = 8000.0      # HBM3E peak (same guide)
 # algorithmic FLOP per image, SURVEY.md 8(d): 1 MAC = 2 FLOP, backward = 2x forward
 # esrgan_gan (ESRGAN/train_esrgan.py:364-431 at 32 -> 128, the discriminator's fixed input size): generator fwd+bwd
 # 1762.3/16 GFLOP, five discriminator forwards + three backwards of ~1.0 GFLOP each, VGG-19[:35] fwd on SR and GT + bwd on SR
-FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9, "esrgan_gan": 1762.3e9 / 16 + 11 * 1.0e9 + 4 * 5.1e9}
-BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32}     # the input size those figures are quoted at
+FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9, "esrgan_gan": 1762.3e9 / 16 + 11 * 1.0e9 + 4 * 5.1e9,
+                "realesrgan_gan": 3828.9e9 / 4}      # the BSRGAN GAN networks at 64 -> 256 (realesrgan_config.py:116); degradation FLOPs not counted
+BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32, "realesrgan_gan": 64}     # the input size those figures are quoted at
 
 
 # Memory-side bytes per launch of the dominant kernels from separate `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum`
@@ -59,6 +60,11 @@ PMC_MFMA_UTIL = {
     "gan": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.236, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.396,
             "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.417},
 }
+REALESRGAN_DEGRADATION = dict(      # realesrgan_config.py:67-90
+    first_blur_probability=1.0, resize_probability1=[0.2, 0.7, 0.1], resize_range1=[0.15, 1.5], gray_noise_probability1=0.4,
+    gaussian_noise_probability1=0.5, noise_range1=[1, 30], poisson_scale_range1=[0.05, 3], jpeg_range1=[30, 95],
+    second_blur_probability=0.8, resize_probability2=[0.3, 0.4, 0.3], resize_range2=[0.3, 1.2], gray_noise_probability2=0.4,
+    gaussian_noise_probability2=0.5, noise_range2=[1, 25], poisson_scale_range2=[0.05, 2.5], jpeg_range2=[30, 95])
 NODES = ["features.2", "features.7", "features.16", "features.25", "features.34"]   # bsrgan_config.py:130-132
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
@@ -97,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan", "aesrgan_gan", "esrgan_gan"])
+    ap.add_argument("--workload", default="g_only", choices=["g_only", "gan", "aesrgan_gan", "esrgan_gan", "realesrgan_gan"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--lr-size", type=int, default=0, help="LR image side (default 128; 192 for aesrgan_gan)")
     ap.add_argument("--num-rrdb", type=int, default=23)
@@ -162,8 +168,26 @@ def main():
         cl.to(dev)
         # bsrgan_config.py:137-151 defaults / aesrgan_config.py:137-155
         kw = dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1) if aes else {}
+        if args.workload == "realesrgan_gan":
+            # Real_ESRGAN/train_realesrgan.py:383-476 per batch: on-device second-order degradation of the GT batch, then the
+            # generator-first GAN iteration (realesrgan_config.py:67-90, 138-151)
+            from sr_gan_fd_amd import imgproc
+            kw = dict(g_lr=1e-4, d_lr=1e-4, betas=(0.9, 0.99), pixel_weight=1.0, content_weight=[0.1, 0.1, 1.0, 1.0, 1.0], adversarial_weight=0.1,
+                      generator_first=True)
+            jpeg, usm = imgproc.DiffJPEG().to(dev), imgproc.USMSharp().to(dev)
+            kgen = torch.Generator(device=dev).manual_seed(7)
+            k21 = torch.rand(B, 21, 21, device=dev, generator=kgen) ** 4
+            k21 = k21 / k21.sum(dim=(1, 2), keepdim=True)
+            import random as _random
+            import numpy as _np
+            _random.seed(rank)
+            _np.random.seed(rank)
         trainer = GanTrainer(g, d, cl, process_group=pg, **kw)
         step_fn = trainer.step
+        if args.workload == "realesrgan_gan":
+            def step_fn(_lr_unused, gt_batch):
+                gt_usm, gt_, lr_ = imgproc.degradation_process(gt_batch, k21, k21, k21, 4, REALESRGAN_DEGRADATION, jpeg, usm)
+                return trainer.step(lr_, gt_, gt_usm)
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -203,6 +227,8 @@ def main():
         "config": {"workload": {"g_only": "BSRGAN RRDBNet x4 generator-only (L1), %d RRDB, batch %d/GPU, %d->%d",
                                 "gan": "BSRGAN full GAN step (RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "aesrgan_gan": "A-ESRGAN full GAN step (RRDBNet %d RRDB + attention U-Net D + VGG19 content), batch %d/GPU, %d->%d",
+                                "realesrgan_gan": "Real-ESRGAN iteration: on-device second-order degradation of the GT batch + generator-first GAN step "
+                                                  "(RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "esrgan_gan": "ESRGAN relativistic GAN step, the script's own loop over the drop-in modules (RRDBNet %d RRDB + BatchNorm D "
                                               "+ differentiable VGG19 content), batch %d/GPU, %d->%d",
                                 }[args.workload] % (args.num_rrdb, B, h, 4 * h),
@@ -312,6 +338,29 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
     n_it = 9
     d_forward, hp = None, dict(g_lr=8e-5, d_lr=2e-4, pixel_weight=20.0, adversarial_weight=0.5)
+    if workload == "realesrgan_gan":
+        import random as _random
+        import numpy as _np
+        from oracle import degradation_oracle as DO
+        _random.seed(0)
+        _np.random.seed(0)
+        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+        d_opt = O.AdamState(D, O.d_param_names(D))
+        cl = M.ContentLoss(NODES, MEAN, STD)
+        VP = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
+        gt = torch.rand(1, 3, 4 * h, 4 * h)
+        k21 = torch.rand(1, 21, 21) ** 4
+        k21 = k21 / k21.sum()
+        times, n_it = [], 5
+        for it in range(n_it):
+            t0 = time.perf_counter()
+            gt_usm, gt_, lr_ = DO.degradation_process(gt, k21, k21, k21, 4, REALESRGAN_DEGRADATION, usm=(DO.usm_kernel(), 0.5, 10))
+            O.realesrgan_gan_step(G, D, opt, d_opt, lr_, gt_, gt_usm, content_fn=lambda sr, gt__: O.content_loss(sr, gt__, VP, NODES, MEAN, STD))
+            times.append(time.perf_counter() - t0)
+            log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
+        return {"value": round(1.0 / min(times[1:]), 4), "unit": "img/s", "cores": cores, "kind": "port",
+                "sample": "batch 1, degradation + GAN step, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (h, 4 * h, n_it - 1)}
     if workload == "esrgan_gan":
         n_it, bsz = 4, 4
         lr_img, gt = torch.rand(bsz, 3, h, h), torch.rand(bsz, 3, 4 * h, 4 * h)

@@ -194,6 +194,9 @@ int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t
 int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out,
                        int32_t accumulate, float* sigmoid_mean_out /* or NULL */, float* grad /* or NULL */,
                        float grad_scale, float* workspace, void* stream);
+/* *out = sigmoid(mean(logits)): the D(x) probability as ESRGAN / Real-ESRGAN log it (train_esrgan.py:430-431,
+ * train_realesrgan.py:475-476; BSRGAN logs mean(sigmoid), srganfd_bce_logits' sigmoid_mean_out). */
+int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, float* workspace, void* stream);
 
 /* ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132).
  * One power iteration in place on u, v when training; sigma = u^T W v; workspace >= rows+cols floats. */

@@ -420,6 +420,44 @@ def gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: T
     }
 
 
+def realesrgan_gan_step(G: Params, D: Params, g_opt: AdamState, d_opt: AdamState, lr_img: Tensor, gt: Tensor, gt_usm: Tensor, *,
+                        upscale: int = 4, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.99), eps: float = 1e-4,
+                        pixel_weight: float = 1.0, content_weight=(0.1, 0.1, 1.0, 1.0, 1.0), adversarial_weight: float = 0.1,
+                        content_fn=None) -> Dict[str, float]:
+    """One iteration of Real_ESRGAN/train_realesrgan.py:407-476 (realesrgan_config.py:138-151): GENERATOR first -- pixel and
+    (detached, logged-only) content loss against the USM-sharpened GT, adversarial BCE vs ones through the frozen D -- Adam
+    step; then D(gt) and D(sr.detach()) forward+backward (gradients accumulate), Adam step.  Probabilities are
+    sigmoid(mean(logits)) (:475-476)."""
+    gn, dn = g_param_names(G), d_param_names(D)
+    _leafify(G, gn)
+    for k in dn:
+        D[k] = D[k].detach()
+    sr = rrdbnet_forward(lr_img, G, upscale)
+    pixel = pixel_weight * l1_mean(sr, gt_usm)
+    content = content_fn(sr.detach(), gt_usm) if content_fn is not None else torch.zeros(1, 5)
+    content = (torch.tensor(content_weight) * content).sum()
+    adv = adversarial_weight * bce_with_logits_mean(discriminator_unet_forward(sr, D, training=True), 1.0)
+    grads = torch.autograd.grad(pixel + content + adv, [G[k] for k in gn])
+    with torch.no_grad():
+        adam_step(G, dict(zip(gn, grads)), g_opt, lr, betas, eps)
+    for k in gn:
+        G[k] = G[k].detach()
+    _leafify(D, dn)
+    gt_out = discriminator_unet_forward(gt, D, training=True)
+    d_loss_gt = bce_with_logits_mean(gt_out, 1.0)
+    g1 = torch.autograd.grad(d_loss_gt, [D[k] for k in dn])
+    sr_out = discriminator_unet_forward(sr.detach().clone(), D, training=True)
+    d_loss_sr = bce_with_logits_mean(sr_out, 0.0)
+    g2 = torch.autograd.grad(d_loss_sr, [D[k] for k in dn])
+    with torch.no_grad():
+        adam_step(D, {k: a + b for k, a, b in zip(dn, g1, g2)}, d_opt, lr, betas, eps)
+    for k in dn:
+        D[k] = D[k].detach()
+    return {"d_loss": float(d_loss_gt + d_loss_sr), "pixel_loss": float(pixel), "content_loss": float(content), "adversarial_loss": float(adv),
+            "d_gt_probability": float(torch.sigmoid(gt_out.detach().mean())), "d_sr_probability": float(torch.sigmoid(sr_out.detach().mean())),
+            "sr": sr.detach()}
+
+
 # ----------------------------------------------------------------------------------------------
 # A-ESRGAN attention U-Net discriminator (BASELINE config 5)
 # ----------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@ int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int
 int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int h, int w, int c, hipStream_t s);
 int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s);
 int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s);
+int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStream_t s);
 int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s);
 int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
                     float grad_scale, float* ws, hipStream_t s);
@@ -132,6 +133,9 @@ int srganfd_l1_loss(const float* a, const float* b, int64_t numel, float weight,
 int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t npix, int32_t c, int32_t relu_first, float weight, float* out,
                           int32_t accumulate, float* workspace, void* stream) {
   return l1_views_impl(a, b, dtype, (size_t)npix, c, relu_first, weight, out, accumulate, workspace, (hipStream_t)stream);
+}
+int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, float* workspace, void* stream) {
+  return sigmoid_of_mean_impl(logits, numel > 0 ? (size_t)numel : 0, out, workspace, (hipStream_t)stream);
 }
 int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out, int32_t accumulate,
                        float* sigmoid_mean_out, float* grad, float grad_scale, float* workspace, void* stream) {

@@ -460,6 +460,22 @@ __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict
   const float r = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + r * scale;
 }
+// sigmoid(mean(logits)): the D(x) probability as ESRGAN / Real-ESRGAN log it (train_esrgan.py:430-431, train_realesrgan.py:475-476;
+// BSRGAN / A-ESRGAN log mean(sigmoid(logits)) instead -- bce_partial_kernel's second output)
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void finish_sigmoid_mean_kernel(const float* __restrict__ partial, int nblk, float inv_n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) *out = 1.f / (1.f + expf(-r * inv_n));
+}
 
 // ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132) ----
 // W is (rows=Cout, cols=Cin*k*k) row-major fp32.
@@ -1238,6 +1254,14 @@ int bce_logits_impl(const float* x, size_t n, float target, float weight, float*
   SRGANFD_LAUNCH(bce_partial_kernel, dim3(g), dim3(256), 0, s, x, n, target, grad_scale / (float)n, grad, ws, ws + kRedBlocks);
   SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, loss_out, accumulate);
   if (sig_mean_out) SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + kRedBlocks), (int)g, 1.f / (float)n, sig_mean_out, 0);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStream_t s) {
+  if (!x || !out || !ws || n == 0) return set_err(SRGANFD_EINVAL, "sigmoid_of_mean: bad args");
+  const unsigned g = grid_for(n, 256, kRedBlocks);
+  SRGANFD_LAUNCH(sum_partial_kernel, dim3(g), dim3(256), 0, s, x, n, ws);
+  SRGANFD_LAUNCH(finish_sigmoid_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, 1.f / (float)n, out);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -1,4 +1,5 @@
-"""Fused GAN training iteration -- the reference's BSRGAN/train_bsrgan.py:387-483 on the HIP engines.
+"""Fused GAN training iteration -- the reference's BSRGAN/train_bsrgan.py:387-483 on the HIP engines
+(``generator_first=True``: Real_ESRGAN/train_realesrgan.py:407-476, see ``GanTrainer._step_generator_first``).
 
 Order kept exactly: D(gt) forward+backward, G forward, D(sr.detach())
 forward+backward (gradients accumulate), D Adam step, freeze D, pixel (L1) + content (VGG-19, detached:
@@ -26,7 +27,8 @@ from .trainer import FlatAdamEMA
 class GanTrainer:
     def __init__(self, g_model, d_model, content_criterion=None, *, g_lr: float = 8e-5, d_lr: float = 2e-4, betas=(0.9, 0.999),
                  eps: float = 1e-4, weight_decay: float = 0.0, ema_decay: float = 0.999, pixel_weight: float = 20.0,
-                 content_weight: float = 1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None):
+                 content_weight=1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None,
+                 generator_first: bool = False):
         # defaults = BSRGAN/bsrgan_config.py:137-159
         self.g, self.d, self.content = g_model, d_model, content_criterion
         # either discriminator of the reference: DiscriminatorUNet (BSRGAN / Real-ESRGAN) or the A-ESRGAN attention U-Net
@@ -39,6 +41,7 @@ class GanTrainer:
         self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None)
         self.pw, self.cw, self.aw = pixel_weight, content_weight, adversarial_weight
         self.train_generator = train_generator
+        self.generator_first = generator_first
         self.pg = process_group
         # [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt) prob, D(sr) prob]
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)
@@ -62,9 +65,57 @@ class GanTrainer:
                                            (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight,
                                            self.ws.data_ptr(), A.stream_ptr()), "bce_logits")
 
-    def step(self, lr_img: Tensor, gt: Tensor) -> Tensor:
+    def _content(self, sr: Tensor, gt: Tensor) -> None:
+        if self.content is not None:
+            cw = self.cw if isinstance(self.cw, (int, float)) else torch.tensor(list(self.cw), dtype=torch.float32, device=self.dev)
+            self.content_vals = self.content(sr, gt) * cw      # per-node weights broadcast over the (1, nodes) tensor
+
+    def _step_generator_first(self, lr_img: Tensor, gt: Tensor, gt_usm: Optional[Tensor]) -> Tensor:
+        """Real_ESRGAN/train_realesrgan.py:407-476: the GENERATOR step first -- pixel and (detached) content loss against the
+        USM-sharpened GT, adversarial BCE vs ones through the frozen current D, G Adam step + EMA -- then the discriminator on the
+        plain GT and on the detached SR (two backward passes accumulate), D Adam step.  Slots 4 / 5 hold sigmoid(mean(logits))
+        as that script logs them (:475-476)."""
+        L, st = A.lib(), A.stream_ptr()
+        ge, de = self.ge, self.de
+        gt = gt.contiguous().float()
+        gtu = gt if gt_usm is None else gt_usm.contiguous().float()
+        sr = ge.forward(lr_img, True)
+        g_sp, g_tok = ge._last, ge.token
+        dsr = self._buf("dsr", sr)
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gtu.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+                                  self.ws.data_ptr(), st), "l1_loss")
+        self._content(sr, gtu)
+        adv_out = de.forward(sr, True)
+        dl = self._buf("dl", adv_out)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
+        if self.train_generator:
+            _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
+            A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
+            gg, _ = ge.backward(g_sp, g_tok, dsr, False)
+            self.g_opt.step(gg, self._allreduce(gg))
+            ge.fp._seen = None
+        s = self.scalars.data_ptr()
+        gt_out = de.forward(gt, True)
+        self._bce(gt_out, 1.0, 1.0, 0, None, dl)
+        A.check(L.srganfd_sigmoid_of_mean(gt_out.data_ptr(), gt_out.numel(), s + 16, self.ws.data_ptr(), st), "sigmoid_of_mean")
+        gd1, _ = de.backward(de._last, de.token, dl, True, False)
+        sr_out = de.forward(sr, True)
+        self._bce(sr_out, 0.0, 1.0, 1, None, dl)
+        A.check(L.srganfd_sigmoid_of_mean(sr_out.data_ptr(), sr_out.numel(), s + 20, self.ws.data_ptr(), st), "sigmoid_of_mean")
+        gd2, _ = de.backward(de._last, de.token, dl, True, False)
+        A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
+        self.d_opt.step(gd2, self._allreduce(gd2))
+        self.sr = sr
+        return self.scalars
+
+    def step(self, lr_img: Tensor, gt: Tensor, gt_usm: Optional[Tensor] = None) -> Tensor:
         """One iteration; returns the device tensor [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt), D(sr), 0, 0]
-        (no host synchronisation inside; content-loss values are in ``self.content_vals``)."""
+        (no host synchronisation inside; content-loss values are in ``self.content_vals``).  ``gt_usm`` (generator-first
+        mode): the sharpened GT the generator's pixel / content losses compare against; the discriminator sees ``gt``."""
+        if self.generator_first:
+            return self._step_generator_first(lr_img, gt, gt_usm)
+        if gt_usm is not None:
+            raise A.SrganfdError("GanTrainer.step: gt_usm belongs to the generator-first (Real-ESRGAN) iteration")
         L, st = A.lib(), A.stream_ptr()
         ge, de = self.ge, self.de
         gt = gt.contiguous().float()
@@ -84,8 +135,7 @@ class GanTrainer:
         dsr = self._buf("dsr", sr)
         A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
                                   self.ws.data_ptr(), st), "l1_loss")
-        if self.content is not None:
-            self.content_vals = self.content(sr, gt) * self.cw
+        self._content(sr, gt)
         adv_out = de.forward(sr, True)                      # updated D, SN state advances again (train_bsrgan.py:452)
         self._bce(adv_out, 1.0, self.aw, 3, None, dl)
         if self.train_generator:

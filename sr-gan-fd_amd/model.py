@@ -35,7 +35,7 @@ __all__ = [
 class _ResidualDenseBlock(nn.Module):
     """Parameter container of BSRGAN/model.py:31-62; standalone forward = a 1-block trunk on the GPU."""
 
-    def __init__(self, channels: int, growth_channels: int) -> None:
+    def __init__(self, channels: int, growth_channels: int, self_init: bool = False) -> None:
         super().__init__()
         self.conv1 = nn.Conv2d(channels + growth_channels * 0, growth_channels, (3, 3), (1, 1), (1, 1))
         self.conv2 = nn.Conv2d(channels + growth_channels * 1, growth_channels, (3, 3), (1, 1), (1, 1))
@@ -44,6 +44,13 @@ class _ResidualDenseBlock(nn.Module):
         self.conv5 = nn.Conv2d(channels + growth_channels * 4, channels, (3, 3), (1, 1), (1, 1))
         self.leaky_relu = nn.LeakyReLU(0.2, True)
         self.identity = nn.Identity()
+        if self_init:     # Real_ESRGAN/model.py:135-150: its dense block initialises itself (the generator then re-draws everything)
+            for module in self.modules():
+                if isinstance(module, nn.Conv2d):
+                    nn.init.kaiming_normal_(module.weight)
+                    module.weight.data *= 0.1
+                    if module.bias is not None:
+                        nn.init.constant_(module.bias, 0)
         self.compute_dtype = torch.bfloat16
 
     def forward(self, x: Tensor) -> Tensor:
@@ -54,11 +61,11 @@ class _ResidualDenseBlock(nn.Module):
 class _ResidualResidualDenseBlock(nn.Module):
     """Parameter container of BSRGAN/model.py:65-88."""
 
-    def __init__(self, channels: int, growth_channels: int) -> None:
+    def __init__(self, channels: int, growth_channels: int, self_init: bool = False) -> None:
         super().__init__()
-        self.rdb1 = _ResidualDenseBlock(channels, growth_channels)
-        self.rdb2 = _ResidualDenseBlock(channels, growth_channels)
-        self.rdb3 = _ResidualDenseBlock(channels, growth_channels)
+        self.rdb1 = _ResidualDenseBlock(channels, growth_channels, self_init)
+        self.rdb2 = _ResidualDenseBlock(channels, growth_channels, self_init)
+        self.rdb3 = _ResidualDenseBlock(channels, growth_channels, self_init)
         self.compute_dtype = torch.bfloat16
 
     def forward(self, x: Tensor) -> Tensor:
@@ -70,11 +77,11 @@ class _RRDBGenerator(nn.Module):
     """Shared body of BSRGAN (BSRGAN/model.py:311-384) and RRDBNet (ESRGAN/model.py:144-243)."""
 
     def __init__(self, in_channels: int, out_channels: int, channels: int, growth_channels: int,
-                 num_blocks: int, upscale_factor: int, always_up1: bool) -> None:
+                 num_blocks: int, upscale_factor: int, always_up1: bool, rdb_self_init: bool = False) -> None:
         super().__init__()
         self.upscale_factor = upscale_factor
         self.conv1 = nn.Conv2d(in_channels, channels, (3, 3), (1, 1), (1, 1))
-        self.trunk = nn.Sequential(*[_ResidualResidualDenseBlock(channels, growth_channels) for _ in range(num_blocks)])
+        self.trunk = nn.Sequential(*[_ResidualResidualDenseBlock(channels, growth_channels, rdb_self_init) for _ in range(num_blocks)])
         self.conv2 = nn.Conv2d(channels, channels, (3, 3), (1, 1), (1, 1))
         n_up = {1: 0, 2: 1, 4: 2, 8: 3}[upscale_factor]
         if always_up1:               # BSRGAN builds upsampling1 unconditionally (model.py:337-340)
@@ -120,7 +127,10 @@ class RRDBNet(_RRDBGenerator):
             if upscale_factor != 4:
                 raise ValueError("Real-ESRGAN's RRDBNet is mirrored for upscale_factor=4 only (x2 / x1 use PixelUnshuffle)")
             num_blocks = num_rrdb
-        super().__init__(in_channels, out_channels, channels, growth_channels, num_blocks, upscale_factor, always_up1=False)
+        # Real-ESRGAN's dense blocks draw their own initialisation first: same random stream, so a seeded construction
+        # gives the reference's initial weights
+        super().__init__(in_channels, out_channels, channels, growth_channels, num_blocks, upscale_factor, always_up1=False,
+                         rdb_self_init=num_rrdb is not None)
 
 
 class DiscriminatorUNet(nn.Module):

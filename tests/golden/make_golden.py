@@ -254,6 +254,68 @@ def _gan_iterations(d, g, fname, *, g_lr, d_lr, pixel_w, adv_w, d_probe):
     save(fname, **out)
 
 
+def gold_realesrgan_gan_steps(MR):
+    """Two iterations of Real_ESRGAN/train_realesrgan.py:407-466 around Real_ESRGAN/model.py's own modules: GENERATOR first
+    (pixel + content on the USM-sharpened GT, adversarial through the frozen D), then the discriminator on the plain GT and the
+    detached SR; realesrgan_config.py:138-151 hyper-parameters; content loss stubbed to zeros (no VGG weights)."""
+    from torch.optim.swa_utils import AveragedModel
+    torch.manual_seed(0)
+    d = MR.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    g = MR.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+    scaled_init(g, 3.0, 0.5)
+    out = {}
+    decay = 0.999
+    ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - decay) * a + decay * p)
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+    g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    pw, cw, aw = torch.Tensor([1.0]), torch.Tensor([0.1, 0.1, 1.0, 1.0, 1.0]), torch.Tensor([0.1])
+    d.train()
+    g.train()
+    B, h = 2, 16
+    out["wsum_g0"] = sd_checksums(g.state_dict())
+    out["wsum_d0"] = sd_checksums(d.state_dict())
+    for it in range(2):
+        lr = torch.rand(B, 3, h, h)
+        gt = torch.rand(B, 3, 4 * h, 4 * h)
+        gt_usm = (gt + 0.1 * (gt - torch.nn.functional.avg_pool2d(gt, 3, 1, 1))).clamp(0, 1)       # any sharpened copy
+        out[f"it{it}_lr"], out[f"it{it}_gt"], out[f"it{it}_gt_usm"] = np_(lr), np_(gt), np_(gt_usm)
+        real = torch.full([B, 1, 4 * h, 4 * h], 1.0)
+        fake = torch.full([B, 1, 4 * h, 4 * h], 0.0)
+        for p in d.parameters():
+            p.requires_grad = False
+        g.zero_grad(set_to_none=True)
+        sr = g(lr)
+        pixel = l1(sr, gt_usm)
+        feature = torch.zeros(1, 5)
+        adv = bce(d(sr), real)
+        pixel = torch.sum(torch.mul(pw, pixel))
+        content = torch.sum(torch.mul(cw, feature))
+        adv = torch.sum(torch.mul(aw, adv))
+        (pixel + content + adv).backward()
+        g_opt.step()
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        gt_output = d(gt)
+        d_loss_gt = bce(gt_output, real)
+        d_loss_gt.backward()
+        sr_output = d(sr.detach().clone())
+        d_loss_sr = bce(sr_output, fake)
+        d_loss_sr.backward()
+        d_opt.step()
+        ema.update_parameters(g)
+        out[f"it{it}_scalars"] = np.array([(d_loss_sr + d_loss_gt).item(), pixel.item(), content.item(), adv.item(),
+                                          torch.sigmoid_(torch.mean(gt_output.detach())).item(), torch.sigmoid_(torch.mean(sr_output.detach())).item()])
+        out[f"it{it}_sr"] = np_(sr)
+        out[f"it{it}_wsum_g"] = sd_checksums(g.state_dict())
+        out[f"it{it}_wsum_d"] = sd_checksums(d.state_dict())
+        out[f"it{it}_wsum_ema"] = sd_checksums(ema.state_dict())
+        out[f"it{it}_g_conv4_bias"] = np_(g.conv4.bias)
+        out[f"it{it}_d_probe"] = np_(dict(d.named_parameters())["conv4.weight"])
+    save("realesrgan_gan_steps.npz", **out)
+
+
 def gold_gan_steps(MB):
     torch.manual_seed(0)
     d = MB.discriminator_unet(in_channels=3, out_channels=1, channels=64)
@@ -615,6 +677,8 @@ def main():
         return gold_validation()
     if "--only-degradation" in sys.argv:
         return gold_degradation()
+    if "--only-realesrgan" in sys.argv:
+        return gold_realesrgan_gan_steps(load_ref("Real_ESRGAN"))
     MB = load_ref("BSRGAN")
     ME = load_ref("ESRGAN")
     gold_blocks(MB)
@@ -629,6 +693,7 @@ def main():
     gold_esrgan_discriminator(ME)
     gold_esrgan_gan_steps(ME)
     gold_degradation()
+    gold_realesrgan_gan_steps(load_ref("Real_ESRGAN"))
 
 
 if __name__ == "__main__":
