@@ -4,4 +4,5 @@
 set -e
 out=$1; conv=$2; shift 2
 src=$(dirname "$0")/../sr-gan-fd_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$src" "$@" -o "$out" "$src/abi.hip" "$conv" "$src/elementwise.hip" "$src/pack.hip" "$src/wgrad.hip"
+others=$(ls "$src"/*.hip | grep -v conv_igemm.hip)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$src" "$@" -o "$out" "$conv" $others
