@@ -326,6 +326,11 @@ int srganfd_poisson_apply(const float* image, const float* image_q, const float*
                           const float* poisson_gray, const float* vals, const float* vals_gray, const float* scale,
                           const float* gray_flag, int32_t b, int32_t c, int32_t h, int32_t w, int32_t clip, int32_t rounds,
                           float* out, void* stream);
+/* random_crop_torch / random_rotate_torch / random_*_flip_torch (imgproc.py:2081-2320) on one NCHW fp32 tensor: crop the
+ * window (top, left, ph x pw) of every plane, then op 0 nothing, 1 / 2 / 3 = 90 / 180 / 270 degrees counter-clockwise
+ * (square windows), 4 horizontal flip, 5 vertical flip.  dst: planes x ph x pw. */
+int srganfd_crop_rot_flip(const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t top, int32_t left,
+                          int32_t ph, int32_t pw, int32_t op, void* stream);
 /* last line of degradation_process (imgproc.py:2460): dst = clamp(round(src * 255), 0, 255) / 255 (may alias) */
 int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream);
 

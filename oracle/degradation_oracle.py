@@ -261,3 +261,24 @@ def degradation_process(gt, gaussian_kernel1, gaussian_kernel2, sinc_kernel, ups
         out = interpolate(out, size=(H // upscale_factor, W // upscale_factor), mode=random.choice(["area", "bilinear", "bicubic"]))
         out = filter2d(out, sinc_kernel)
     return gt_usm, gt, quantize_u8(out)
+
+
+def random_crop_lists(gts, lrs, gt_patch_size: int, upscale_factor: int):
+    """random_crop_torch on tensor lists -- Real_ESRGAN/imgproc.py:2081-2155: LR window drawn with random.randint (row, column)"""
+    import random
+    lh, lw = lrs[0].size()[-2:]
+    lps = gt_patch_size // upscale_factor
+    top, left = random.randint(0, lh - lps), random.randint(0, lw - lps)
+    gtop, gleft = int(top * upscale_factor), int(left * upscale_factor)
+    return [v[:, :, gtop:gtop + gt_patch_size, gleft:gleft + gt_patch_size] for v in gts], [v[:, :, top:top + lps, left:left + lps] for v in lrs]
+
+
+def rotate_flip(t: Tensor, op: int) -> Tensor:
+    """random_rotate_torch / random_*_flip_torch on square even-sized tensors -- Real_ESRGAN/imgproc.py:2158-2320.  The reference
+    calls torchvision (third party, absent): F.rotate(img, angle, center=[w // 2, h // 2]) rotates counter-clockwise about what is
+    the exact image centre in torchvision's half-pixel convention, i.e. torch.rot90 for multiples of 90 degrees; hflip / vflip
+    reverse the last / second-to-last axis.  PARITY UNPINNED (restated from torchvision's documentation).
+    op 1 / 2 / 3 = 90 / 180 / 270 degrees, 4 = hflip, 5 = vflip."""
+    if op in (1, 2, 3):
+        return torch.rot90(t, op, dims=(-2, -1))
+    return torch.flip(t, dims=(-1,)) if op == 4 else torch.flip(t, dims=(-2,)) if op == 5 else t

@@ -114,6 +114,7 @@ SYMBOLS = {
     "srganfd_gaussian_noise": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "srganfd_poisson_prepare": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 6),
     "srganfd_poisson_apply": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "srganfd_crop_rot_flip": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "srganfd_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_ssim_workspace_doubles": (C.c_int64, [C.c_int32] * 7),
     "srganfd_ssim": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -53,6 +53,7 @@ int jpeg_table_floats();
 int diff_jpeg_impl(const float* src, int b, int c, int h, int w, float* quality, int quality_is_factor, int differentiable, const float* tables,
                    float* dst, hipStream_t s);
 int quantize_u8_impl(const float* src, float* dst, size_t n, hipStream_t s);
+int crop_rot_flip_impl(const float* src, float* dst, int planes, int h, int w, int top, int left, int ph, int pw, int op, hipStream_t s);
 int resize_impl(const float* src, int planes, int h, int w, int oh, int ow, int mode, float rscale_h, float rscale_w, float* dst, hipStream_t s);
 int gaussian_noise_impl(const float* image, const float* n_color, const float* n_gray, const float* sigma, const float* gray, int b, int c, int h, int w,
                         int clip, int rounds, float* out, hipStream_t s);
@@ -236,6 +237,10 @@ int srganfd_poisson_apply(const float* image, const float* image_q, const float*
                           int32_t w, int32_t clip, int32_t rounds, float* out, void* stream) {
   return poisson_apply_impl(image, image_q, gray_q, poisson_color, poisson_gray, vals, vals_gray, scale, gray_flag, b, c, h, w, clip, rounds, out,
                             (hipStream_t)stream);
+}
+int srganfd_crop_rot_flip(const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t top, int32_t left, int32_t ph, int32_t pw,
+                          int32_t op, void* stream) {
+  return crop_rot_flip_impl(src, dst, planes, h, w, top, left, ph, pw, op, (hipStream_t)stream);
 }
 int srganfd_quantize_u8(const float* src, float* dst, int64_t numel, void* stream) {
   return quantize_u8_impl(src, dst, numel > 0 ? (size_t)numel : 0, (hipStream_t)stream);

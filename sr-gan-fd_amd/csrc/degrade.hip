@@ -517,6 +517,39 @@ int poisson_apply_impl(const float* image, const float* img_q, const float* gray
   return SRGANFD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batch augmentation of the Real-ESRGAN loop (train_realesrgan.py:400-404 -> imgproc.py:2081-2320): one common crop window,
+// one quarter-turn, one flip for every image of the GT / GT-USM / LR lists.  op: 0 copy (crop only), 1..3 = 90 / 180 / 270
+// degrees counter-clockwise (torchvision's rotate about the image centre is an exact permutation for these on square planes),
+// 4 horizontal flip, 5 vertical flip; the source window (top, left, ph x pw) is cropped first.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_rot_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int top,
+                                                            int left, int ph, int pw, int op) {
+  const size_t total = (size_t)planes * ph * pw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % pw);
+    const size_t t = i / pw;
+    const int y = (int)(t % ph);
+    const size_t pl = t / ph;
+    int sy = y, sx = x;                                  // position inside the cropped window that lands on (y, x)
+    if (op == 1) { sy = x; sx = pw - 1 - y; }            // rot90 ccw: out[y][x] = in[x][W-1-y]
+    else if (op == 2) { sy = ph - 1 - y; sx = pw - 1 - x; }
+    else if (op == 3) { sy = ph - 1 - x; sx = y; }       // rot270 ccw (= 90 cw): out[y][x] = in[H-1-x][y]
+    else if (op == 4) { sx = pw - 1 - x; }
+    else if (op == 5) { sy = ph - 1 - y; }
+    dst[i] = src[(pl * h + top + sy) * w + left + sx];
+  }
+}
+int crop_rot_flip_impl(const float* src, float* dst, int planes, int h, int w, int top, int left, int ph, int pw, int op, hipStream_t s) {
+  if (!src || !dst || planes <= 0 || top < 0 || left < 0 || ph <= 0 || pw <= 0 || top + ph > h || left + pw > w)
+    return set_err(SRGANFD_EINVAL, "crop_rot_flip: window %dx%d at (%d,%d) outside %dx%d", ph, pw, top, left, h, w);
+  if (op < 0 || op > 5) return set_err(SRGANFD_EINVAL, "crop_rot_flip: op %d", op);
+  if ((op == 1 || op == 3) && ph != pw) return set_err(SRGANFD_EINVAL, "crop_rot_flip: quarter turns need a square window (%dx%d)", ph, pw);
+  SRGANFD_LAUNCH(crop_rot_flip_kernel, ew_grid((size_t)planes * ph * pw), dim3(256), 0, s, src, dst, planes, h, w, top, left, ph, pw, op);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
 int jpeg_table_floats() { return kJpegTableFloats; }
 
 }  // namespace srganfd

@@ -353,3 +353,74 @@ def degradation_process(gt: Tensor, gaussian_kernel1: Tensor, gaussian_kernel2: 
         out = filter2d_torch(out, sinc_kernel)
     lr = quantize_u8(out)
     return gt_usm, gt, lr
+
+
+# ---- batch augmentation of the Real-ESRGAN loop (train_realesrgan.py:400-404) ------------------------------------------------
+def _as_list(v):
+    return (v, True) if isinstance(v, list) else ([v], False)
+
+
+def _crop_rot_flip(t: Tensor, top: int, left: int, ph: int, pw: int, op: int) -> Tensor:
+    _need_gpu(t, "augmentation")
+    x = t.detach().contiguous().float()
+    b, c, h, w = x.shape
+    out = torch.empty(b, c, ph, pw, dtype=torch.float32, device=x.device)
+    A.check(A.lib().srganfd_crop_rot_flip(x.data_ptr(), out.data_ptr(), b * c, h, w, top, left, ph, pw, op, A.stream_ptr()), "crop_rot_flip")
+    return out.to(t.dtype)
+
+
+def random_crop_torch(gt_images, lr_images, gt_patch_size: int, upscale_factor: int):
+    """imgproc.random_crop_torch (Real_ESRGAN/imgproc.py:2081-2155), tensor inputs: one LR window drawn with ``random.randint``
+    (row, then column) for every tensor of both lists, the GT window at upscale_factor times its origin."""
+    gts, _ = _as_list(gt_images)
+    lrs, _ = _as_list(lr_images)
+    lh, lw = lrs[0].size()[-2:]
+    lps = gt_patch_size // upscale_factor
+    lr_top = random.randint(0, lh - lps)
+    lr_left = random.randint(0, lw - lps)
+    lrs = [_crop_rot_flip(t, lr_top, lr_left, lps, lps, 0) for t in lrs]
+    gts = [_crop_rot_flip(t, int(lr_top * upscale_factor), int(lr_left * upscale_factor), gt_patch_size, gt_patch_size, 0) for t in gts]
+    return (gts[0] if len(gts) == 1 else gts), (lrs[0] if len(lrs) == 1 else lrs)
+
+
+def random_rotate_torch(gt_images, lr_images, upscale_factor: int, angles: list, gt_center=None, lr_center=None, rotate_scale_factor: float = 1.0):
+    """imgproc.random_rotate_torch (Real_ESRGAN/imgproc.py:2158-2230), tensor inputs: one angle drawn with ``random.choice``;
+    the reference rotates with torchvision about the default centre [w // 2, h // 2], which for the multiples of 90 degrees the
+    train loops pass (train_realesrgan.py:401) and square even-sized batches is an exact counter-clockwise quarter-turn
+    permutation -- the only case with a HIP path."""
+    angle = random.choice(angles)
+    gts, _ = _as_list(gt_images)
+    lrs, _ = _as_list(lr_images)
+    if gt_center is not None or lr_center is not None or rotate_scale_factor != 1.0 or angle % 90 != 0:
+        raise A.SrganfdError("random_rotate_torch: only default-centre rotations by multiples of 90 degrees have a HIP path")
+    op = (angle // 90) % 4
+    out = []
+    for group in (gts, lrs):
+        res = []
+        for t in group:
+            h, w = t.shape[-2:]
+            if op in (1, 3) and (h != w or h % 2):
+                raise A.SrganfdError("random_rotate_torch: quarter turns need square, even-sized images")
+            res.append(_crop_rot_flip(t, 0, 0, h, w, op))
+        out.append(res)
+    return (out[0][0] if len(out[0]) == 1 else out[0]), (out[1][0] if len(out[1]) == 1 else out[1])
+
+
+def _random_flip(gt_images, lr_images, p: float, op: int):
+    flip_prob = random.random()
+    gts, _ = _as_list(gt_images)
+    lrs, _ = _as_list(lr_images)
+    if flip_prob > p:
+        lrs = [_crop_rot_flip(t, 0, 0, t.shape[-2], t.shape[-1], op) for t in lrs]
+        gts = [_crop_rot_flip(t, 0, 0, t.shape[-2], t.shape[-1], op) for t in gts]
+    return (gts[0] if len(gts) == 1 else gts), (lrs[0] if len(lrs) == 1 else lrs)
+
+
+def random_horizontally_flip_torch(gt_images, lr_images, p: float = 0.5):
+    """imgproc.random_horizontally_flip_torch (Real_ESRGAN/imgproc.py:2233-2275): flips when ``random.random() > p``"""
+    return _random_flip(gt_images, lr_images, p, 4)
+
+
+def random_vertically_flip_torch(gt_images, lr_images, p: float = 0.5):
+    """imgproc.random_vertically_flip_torch (Real_ESRGAN/imgproc.py:2278-2320)"""
+    return _random_flip(gt_images, lr_images, p, 5)

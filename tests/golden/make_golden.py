@@ -668,6 +668,13 @@ def gold_degradation():
                 break
         ip.random_add_gaussian_noise_torch, ip.random_add_poisson_noise_torch = orig_g, orig_p
         out["pipe_seeds"] = np.array(seeds)
+        # batch augmentation: random_crop_torch is pure slicing (the rotate / flip helpers call torchvision, absent here)
+        aug_gt, aug_lr = torch.rand(2, 3, 48, 64), torch.rand(2, 3, 12, 16)
+        out["aug_gt"], out["aug_lr"] = np_(aug_gt), np_(aug_lr)
+        for seed in (3, 8):
+            random.seed(seed)
+            (c_usm, c_gt), c_lr = ip.random_crop_torch([aug_gt * 0.5, aug_gt], aug_lr, 32, 4)
+            out[f"aug_crop{seed}_gt_usm"], out[f"aug_crop{seed}_gt"], out[f"aug_crop{seed}_lr"] = np_(c_usm), np_(c_gt), np_(c_lr)
     save("degradation.npz", **out)
 
 

@@ -225,3 +225,43 @@ def test_degradation_process_matches_reference(golden_dir):
     assert tuple(lr.shape) == (2, 3, 32, 32) and tuple(gt_usm.shape) == tuple(gt.shape) and not torch.equal(gt_usm, gt)
     lv = lr * 255
     assert float(lr.min()) >= 0 and float(lr.max()) <= 1 and float((lv - lv.round()).abs().max()) < 1e-4
+
+
+def test_batch_augmentation(golden_dir):
+    """random_crop_torch vs the reference's outputs (pure slicing, captured); rotate / flips vs the oracle's statement of the
+    torchvision calls the reference makes; list and single-tensor call forms; the Python `random` stream is consumed exactly as
+    the reference consumes it (randint x2 / choice / random)."""
+    import random
+    from oracle import degradation_oracle as D
+    from sr_gan_fd_amd import imgproc
+    g = load_golden(golden_dir, "degradation.npz")
+    gt, lr = torch.tensor(g["aug_gt"]).cuda(), torch.tensor(g["aug_lr"]).cuda()
+    for seed in (3, 8):
+        random.seed(seed)
+        (c_usm, c_gt), c_lr = imgproc.random_crop_torch([gt * 0.5, gt], lr, 32, 4)
+        assert np.array_equal(c_usm.cpu().numpy(), g[f"aug_crop{seed}_gt_usm"]) and np.array_equal(c_gt.cpu().numpy(), g[f"aug_crop{seed}_gt"])
+        assert np.array_equal(c_lr.cpu().numpy(), g[f"aug_crop{seed}_lr"]) and torch.is_tensor(c_lr)
+        assert random.random() == (random.seed(seed), random.randint(0, 4), random.randint(0, 8), random.random())[3]     # two randint draws, no more
+    sq_gt, sq_lr = gt[:, :, :48, :48].contiguous(), lr[:, :, :12, :12].contiguous()
+    for angle, op in ((0, 0), (90, 1), (180, 2), (270, 3)):
+        random.seed(1)
+        (r_usm, r_gt), r_lr = imgproc.random_rotate_torch([sq_gt * 0.5, sq_gt], sq_lr, 4, [angle])
+        assert torch.equal(r_gt.cpu(), D.rotate_flip(sq_gt.cpu(), op)) and torch.equal(r_lr.cpu(), D.rotate_flip(sq_lr.cpu(), op))
+        assert torch.equal(r_usm.cpu(), D.rotate_flip(sq_gt.cpu() * 0.5, op))
+    # a pixel follows the documented direction: 90 degrees counter-clockwise moves the top-right corner to the top-left
+    mark = torch.zeros(1, 1, 4, 4).cuda()
+    mark[0, 0, 0, 3] = 1
+    r, _ = imgproc.random_rotate_torch(mark, mark.clone(), 1, [90])
+    assert float(r[0, 0, 0, 0]) == 1 and float(r.sum()) == 1
+    with pytest.raises(Exception):
+        imgproc.random_rotate_torch(gt, lr, 4, [90])                 # 48x64 is not square
+    with pytest.raises(Exception):
+        imgproc.random_rotate_torch(sq_gt, sq_lr, 4, [45])
+    for fn, op in ((imgproc.random_horizontally_flip_torch, 4), (imgproc.random_vertically_flip_torch, 5)):
+        for seed in range(6):
+            random.seed(seed)
+            want_flip = random.random() > 0.5
+            random.seed(seed)
+            f_gt, f_lr = fn(gt, lr)
+            assert torch.equal(f_gt.cpu(), D.rotate_flip(gt.cpu(), op) if want_flip else gt.cpu())
+            assert torch.equal(f_lr.cpu(), D.rotate_flip(lr.cpu(), op) if want_flip else lr.cpu())

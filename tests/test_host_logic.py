@@ -192,6 +192,10 @@ def test_validation_side_argument_checks():
         assert L.srganfd_poisson_apply(p, p, None, p, None, p, None, p, None, 2, 3, 8, 8, 1, 0, p, None) == 0
         assert L.srganfd_poisson_apply(p, p, None, p, p, p, None, p, None, 2, 3, 8, 8, 1, 0, p, None) != 0
         assert L.srganfd_quantize_u8(p, p, 64, None) == 0 and L.srganfd_quantize_u8(p, p, 0, None) != 0
+        assert L.srganfd_crop_rot_flip(p, p, 6, 8, 8, 2, 2, 4, 4, 1, None) == 0
+        assert L.srganfd_crop_rot_flip(p, p, 6, 8, 8, 2, 2, 4, 6, 1, None) != 0              # quarter turn of a non-square window
+        assert L.srganfd_crop_rot_flip(p, p, 6, 8, 8, 6, 2, 4, 4, 0, None) != 0              # window leaves the image
+        assert L.srganfd_crop_rot_flip(p, p, 6, 8, 8, 0, 0, 8, 8, 6, None) != 0              # unknown op
     finally:
         A.set_dry_run(False)
 

@@ -343,6 +343,10 @@ def test_degradation_oracle(golden_dir):
         random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
         _, _, lr = D.degradation_process(T("pipe_gt"), T("pipe_k1"), T("pipe_k2"), T("pipe_sinc"), 4, PIPE_PARAMS)
         assert same(lr, f"pipe_lr_seed{seed}"), seed
+    for seed in (3, 8):                                            # random_crop_torch on [gt_usm, gt], lr
+        random.seed(seed)
+        (a, b), (c,) = D.random_crop_lists([T("aug_gt") * 0.5, T("aug_gt")], [T("aug_lr")], 32, 4)
+        assert same(a, f"aug_crop{seed}_gt_usm") and same(b, f"aug_crop{seed}_gt") and same(c, f"aug_crop{seed}_lr")
 
 
 def _esrgan_d():
