@@ -251,6 +251,24 @@ __global__ void clamp_grad_kernel(const float* __restrict__ dsr, const float* __
   }
 }
 
+// the generator's case (3 image channels, fp32 pre-clamp SR with a 4-channel pitch, bf16 gradient padded to 32 channels): one thread
+// per pixel, one 16-byte read of the pre-clamp pixel, three coalesced plane reads, four 16-byte stores (the 29 padding channels are
+// zeros the data-gradient conv multiplies by padded weights)
+__global__ __launch_bounds__(256) void clamp_grad_rgb_bf16_kernel(const float* __restrict__ dsr, const f32x4* __restrict__ pre, u32x4* __restrict__ dst,
+                                                                  size_t npix, size_t hw, int c) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const size_t img = p / hw, pix = p % hw;
+    const f32x4 q = pre[p];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < c && q[k] >= 0.f && q[k] <= 1.f) v[k] = dsr[(img * c + k) * hw + pix];
+    u32x4 w0 = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16), 0u, 0u};
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    dst[p * 4 + 0] = w0; dst[p * 4 + 1] = z; dst[p * 4 + 2] = z; dst[p * 4 + 3] = z;
+  }
+}
+
 // ---- backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:372,374): 2x2 sum ----
 template <typename T>
 __global__ void up2_nearest_bwd_kernel(const void* __restrict__ dy, int yC, int y0, void* dx, int xC, int x0, int n, int h, int w, int c) {
@@ -1139,6 +1157,13 @@ int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, f
 int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s) {
   if (!dsr || !pre.ptr || !dst.ptr || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "clamp_grad: bad args");
   const size_t total = (size_t)n * h * w * cpad;
+  if (dtype == SRGANFD_BF16 && c <= 4 && cpad == 32 && pre.cstride == 4 && pre.c0 == 0 && dst.cstride == 32 && dst.c0 == 0 &&
+      ((uintptr_t)pre.ptr & 15) == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
+    const size_t npix = (size_t)n * h * w;
+    SRGANFD_LAUNCH(clamp_grad_rgb_bf16_kernel, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (u32x4*)dst.ptr, npix, (size_t)h * w, c);
+    SRGANFD_HIP_CHECK(hipGetLastError());
+    return SRGANFD_OK;
+  }
   DISPATCH_T(dtype,
              SRGANFD_LAUNCH(clamp_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad),
              SRGANFD_LAUNCH(clamp_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad));

@@ -201,3 +201,23 @@ def test_wgrad_dense_block_fused(dtype):
     for o, gw, gb in refs:
         _assert_close(grads[o:o + gw.numel()].view_as(gw) - 1.0, gw, dtype, "fused dW")
         _assert_close(grads[o + gw.numel():o + gw.numel() + gb.numel()] - 1.0, gb, dtype, "fused db")
+
+
+def test_clamp_grad_rgb_fast_path_matches_definition():
+    """d pre = d sr where 0 <= pre <= 1 else 0, NCHW fp32 -> NHWC bf16 padded to 32 channels: the per-pixel vectorised kernel the
+    generator's backward starts with (3 channels, 4-channel fp32 pre-clamp pixels) against the definition, incl. the zero padding"""
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(0)
+    n, c, h, w = 3, 3, 37, 29
+    dsr = torch.randn(n, c, h, w, device="cuda")
+    pre = torch.randn(n, h, w, 4, device="cuda") * 0.8 + 0.5          # fp32 NHWC, pitch 4 (channel 3 unused)
+    pre[0, 0, 0, 0], pre[0, 0, 1, 1] = 0.0, 1.0                       # the closed interval's ends pass the gradient
+    dst = torch.full((n, h, w, 32), 7.0, device="cuda", dtype=torch.bfloat16)
+    A.check(A.lib().srganfd_clamp_grad_to_nhwc(dsr.data_ptr(), A.view(pre), n, c, h, w, A.view(dst), A.BF16, 32, A.stream_ptr()), "clamp_grad")
+    inside = (pre[..., :3] >= 0) & (pre[..., :3] <= 1)
+    want = torch.where(inside, dsr.permute(0, 2, 3, 1), torch.zeros((), device="cuda")).bfloat16()
+    assert torch.equal(dst[..., :3], want) and float(dst[..., 3:].abs().max()) == 0.0
+    # the generic kernel (any pitch / padding) agrees: same call with a 16-channel padding takes it
+    dst16 = torch.full((n, h, w, 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    A.check(A.lib().srganfd_clamp_grad_to_nhwc(dsr.data_ptr(), A.view(pre), n, c, h, w, A.view(dst16), A.BF16, 16, A.stream_ptr()), "clamp_grad")
+    assert torch.equal(dst16[..., :3], want) and float(dst16[..., 3:].abs().max()) == 0.0
