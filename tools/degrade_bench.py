@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Throughput of the on-device degradation stages at Real-ESRGAN's training shape (batch 48, 3x256x256 GT,
-realesrgan_config.py:116-117), each stage against the roof that bounds it, plus the whole degradation_process and -- with
---cpu -- the CPU oracle (the reference's own torch-CPU formulation) on a bounded sample.
+realesrgan_config.py:116-117), each stage against the roof that bounds it, plus the whole degradation_process (the CPU side of
+the comparison is bench.py's cpu_baseline leg of `--workload realesrgan_gan`; the oracle is not used from tools/).
 
-    python tools/degrade_bench.py [--batch 48] [--size 256] [--iters 20] [--cpu]
+    python tools/degrade_bench.py [--batch 48] [--size 256] [--iters 20]
 
 Prints one JSON line per stage: {"stage", "us", "GB/s" (algorithmic bytes: input read once + output written once),
 "hbm_frac" (of 8 TB/s), "GFLOP/s", "valu_frac" (of 157.3 TFLOP/s fp32 vector)}.  Timed with HIP events on the current stream.
@@ -13,7 +13,6 @@ import json
 import os
 import random
 import sys
-import time
 
 import numpy as np
 import torch
@@ -46,7 +45,6 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--cpu", action="store_true")
     a = ap.parse_args()
     imgproc = importlib.import_module("sr_gan_fd_amd.imgproc")
     b, n = a.batch, a.size
@@ -80,18 +78,6 @@ def main():
     t = timed(pipeline, a.iters)
     line = {"stage": "degradation_process (USM + 2nd-order pipeline, random branches)", "ms": round(t * 1e3, 3), "img/s": round(b / t, 1),
             "batch": b, "gt": f"3x{n}x{n}"}
-    if a.cpu:
-        from oracle import degradation_oracle as D
-        torch.set_num_threads(os.cpu_count() or 1)
-        g, k = gt[:4].cpu(), k21[:4].cpu()
-        random.seed(0); np.random.seed(0)
-        t0 = time.time()
-        reps = 0
-        while time.time() - t0 < 10:
-            D.degradation_process(g, k, k, k, 4, PARAMS, usm=(D.usm_kernel(), 0.5, 10))
-            reps += 1
-        tc = (time.time() - t0) / reps
-        line["cpu_oracle"] = {"img/s": round(4 / tc, 2), "cores": torch.get_num_threads(), "sample": f"{reps} batches of 4"}
     print(json.dumps(line))
 
 
