@@ -199,3 +199,35 @@ def test_reference_amp_wrappers_may_stay():
     fa = torch.cat([p.detach().reshape(-1) for p in a.parameters()])
     fb = torch.cat([p.detach().reshape(-1) for p in b.parameters()])
     assert ((fa - fb).abs().max() / fb.abs().max()).item() < 1e-5
+
+
+def test_runs_on_the_callers_stream():
+    """Every launch goes to torch's *current* stream (CUDAPrefetcher and user code switch streams): an iteration issued inside
+    ``torch.cuda.stream(side)`` right after asynchronous producers on that stream gives the results of the default-stream run, and
+    leaves the default stream idle (a kernel enqueued there beforehand is not waited for)."""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+
+    def build():
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(num_rrdb=2)
+        scaled_init(g, 3.0, 0.5)
+        g.compute_dtype = torch.bfloat16
+        return g.cuda().train()
+    lr0, gt0 = torch.rand(4, 3, 24, 24, device="cuda"), torch.rand(4, 3, 96, 96, device="cuda")
+    ref = GeneratorTrainer(build(), lr=1e-4)
+    want_loss = [ref.step(lr0, gt0).clone() for _ in range(2)]
+    want_flat = ref.opt.flat.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    tr = GeneratorTrainer(build(), lr=1e-4)
+    torch.cuda.synchronize()
+    got_loss = []
+    with torch.cuda.stream(side):
+        lr1 = (lr0 * 2.0) * 0.5                  # producers on the side stream: the step must be ordered after them
+        gt1 = (gt0 * 2.0) * 0.5
+        for _ in range(2):
+            got_loss.append(tr.step(lr1, gt1).clone())
+    side.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got_loss, want_loss))
+    assert torch.equal(tr.opt.flat, want_flat)
