@@ -45,6 +45,11 @@ typedef struct {
   void* ptr;
   int32_t cstride; /* channels of the underlying buffer */
   int32_t c0;      /* first channel of the view */
+  int32_t planar;  /* 0: NHWC, a pixel's cstride channels are contiguous.  1: per image, every group of 32 channels is its own
+                      (H, W, 32) plane -- element (p, c) of an image at (c / 32) * H*W*32 + p * 32 + c % 32 (same bytes per image).
+                      Only srganfd_conv2d and srganfd_conv2d_wgrad take planar views (the dense-block buffers: each 32-channel
+                      chunk pass then reads whole contiguous 128-byte lines); c0 must be a multiple of 32. */
+  int32_t pad_;
 } srganfd_view;
 
 /* Fused convolution (implicit GEMM on MFMA).  Replaces one nn.Conv2d call of

@@ -16,7 +16,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 
 
 class View(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("cstride", C.c_int32), ("c0", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("cstride", C.c_int32), ("c0", C.c_int32), ("planar", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
@@ -177,9 +177,9 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def view(t, cstride=None, c0=0) -> View:
-    """NHWC tensor (..., C) -> channel-slice view starting at channel c0."""
-    return View(t.data_ptr(), int(cstride if cstride is not None else t.shape[-1]), int(c0))
+def view(t, cstride=None, c0=0, planar=0) -> View:
+    """NHWC tensor (..., C) -> channel-slice view starting at channel c0 (planar=1: the buffer stores 32-channel group planes)."""
+    return View(t.data_ptr(), int(cstride if cstride is not None else t.shape[-1]), int(c0), int(planar), 0)
 
 
-NULL_VIEW = View(None, 0, 0)
+NULL_VIEW = View(None, 0, 0, 0, 0)

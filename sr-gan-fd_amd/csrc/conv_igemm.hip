@@ -43,6 +43,9 @@ struct ConvK {
   const void* x; void* y; void* y2; const void* r1; const void* r2; const void* mask; const void* w;
   const float* bias; const float* alpha_dev;
   int xC, x_c0, yC, y_c0, y2C, y2_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
+  // element (pixel p, channel c) of an operand's image sits at p * ps + (c >> 5) * gs + (c & 31): NHWC ps = C, gs = 32;
+  // planar 32-channel groups (srganfd_view.planar) ps = 32, gs = H*W*32.  x additionally: first chunk at x_base, next at + x_cs.
+  int x_ps, x_base, x_cs, y_ps, y_gs, y2_ps, y2_gs, r1_ps, r1_gs, r2_ps, r2_gs, m_ps, m_gs;
   int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
   int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
   int nChunks;        // cin / 32
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     const int py = pix / C::PC, px = pix % C::PC;
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !(a.dbg & 1);
-    xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + a.x_c0 + c16 * C::E16 : -1;
+    xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
   }
   // LDS destination of staging item i = ldsx0 + i * (PIX_PER_I * PIXB): the swizzle term is i-invariant
   int ldsx0;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   u32x4 wrg[WRG];
   auto load_x = [&](int i, int chunk) -> u32x4 {
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * C::KC);
+    if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * a.x_cs);
     return v;
   };
   auto load_w = [&](int i, int chunk) -> u32x4 {
@@ -336,8 +339,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
           v[4] = t4[0]; v[5] = t4[1]; v[6] = t4[2]; v[7] = t4[3];
         }
         const int cch = cbase + ck * C::E16;
-        auto load16 = [&](const void* base, int Cs, int c0, float* out) {
-          const T* src = (const T*)base + img * Cs + (p * Cs + c0 + cch);
+        auto load16 = [&](const void* base, int Cs, int c0, int ps, int gs, float* out) {
+          const int cc = c0 + cch;
+          const T* src = (const T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
             const u32x4 raw = *(const u32x4*)src;
             const unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
@@ -350,8 +354,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
             out[0] = rf[0]; out[1] = rf[1]; out[2] = rf[2]; out[3] = rf[3];
           }
         };
-        auto store16 = [&](void* base, int Cs, int c0, const float* vv) {
-          T* dstp = (T*)base + img * Cs + (p * Cs + c0 + cch);
+        auto store16 = [&](void* base, int Cs, int c0, int ps, int gs, const float* vv) {
+          const int cc = c0 + cch;
+          T* dstp = (T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
             u32x4 o;
             o[0] = (unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16);
@@ -364,18 +369,18 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
             *(f32x4*)dstp = o;
           }
         };
-        if (a.y2) store16(a.y2, a.y2C, a.y2_c0, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
+        if (a.y2) store16(a.y2, a.y2C, a.y2_c0, a.y2_ps, a.y2_gs, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
         float tt[C::E16];
-        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, tt);
+        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * tt[q]; }
-        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, tt);
+        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * tt[q]; }
-        if (a.mask) { load16(a.mask, a.mC, a.m_c0, tt);
+        if (a.mask) { load16(a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] *= tt[q] > 0.f ? 1.f : a.mask_slope; }
-        store16(a.y, a.yC, a.y_c0, v);
+        store16(a.y, a.yC, a.y_c0, a.y_ps, a.y_gs, v);
       }
     }
     return;
@@ -391,22 +396,24 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   for (int m = 0; m < MR; ++m) {
     const int oy = oy0 + wr * MR + m;
     if (!cok || oy >= a.Hout) continue;
-    const size_t prow = ((size_t)n * a.HoutF + oy * a.osy + a.ooy) * a.WoutF + a.oox;
+    const size_t imgp = (size_t)n * a.HoutF * a.WoutF;                       // pixels before this image
+    const int prow = (oy * a.osy + a.ooy) * a.WoutF + a.oox;                   // pixel inside the image
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ox = ox0 + mfma32_row(i, lane);
       if (ox < a.Wout) {
-        const size_t p = prow + ox * a.osx;
+        const int p = prow + ox * a.osx;
+        auto at = [&](int Cs, int c0, int ps, int gs) -> size_t { const int cc = c0 + co; return imgp * Cs + (size_t)(p * ps + (cc >> 5) * gs + (cc & 31)); };
         float v = alpha * acc[m][i] + bv;
         if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
         else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
         v *= a.post_scale;
-        if (a.y2) ((T*)a.y2)[p * a.y2C + a.y2_c0 + co] = Elem<T>::from_f(v);
-        if (r1g) v += a.r1s * Elem<T>::to_f(r1g[p * a.r1C + a.r1_c0 + co]);
-        if (r2g) v += a.r2s * Elem<T>::to_f(r2g[p * a.r2C + a.r2_c0 + co]);
-        if (mg) v *= (Elem<T>::to_f(mg[p * a.mC + a.m_c0 + co]) > 0.f) ? 1.f : a.mask_slope;
-        if (a.y_f32) ((float*)a.y)[p * a.yC + a.y_c0 + co] = v;
-        else yg[p * a.yC + a.y_c0 + co] = Elem<T>::from_f(v);
+        if (a.y2) ((T*)a.y2)[at(a.y2C, a.y2_c0, a.y2_ps, a.y2_gs)] = Elem<T>::from_f(v);
+        if (r1g) v += a.r1s * Elem<T>::to_f(r1g[at(a.r1C, a.r1_c0, a.r1_ps, a.r1_gs)]);
+        if (r2g) v += a.r2s * Elem<T>::to_f(r2g[at(a.r2C, a.r2_c0, a.r2_ps, a.r2_gs)]);
+        if (mg) v *= (Elem<T>::to_f(mg[at(a.mC, a.m_c0, a.m_ps, a.m_gs)]) > 0.f) ? 1.f : a.mask_slope;
+        if (a.y_f32) ((float*)a.y)[at(a.yC, a.y_c0, a.y_ps, a.y_gs)] = v;
+        else yg[at(a.yC, a.y_c0, a.y_ps, a.y_gs)] = Elem<T>::from_f(v);
       }
     }
   }
@@ -483,6 +490,19 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.xC = a->x.cstride; k.x_c0 = a->x.c0; k.yC = a->y.cstride; k.y_c0 = a->y.c0;
   k.r1C = a->r1.cstride; k.r1_c0 = a->r1.c0; k.r2C = a->r2.cstride; k.r2_c0 = a->r2.c0;
   k.mC = a->mask.cstride; k.m_c0 = a->mask.c0;
+  {
+    // addressing of every operand: NHWC or planar 32-channel groups (see ConvK)
+    const long long ipix = (long long)a->h_in * a->w_in;
+    for (const srganfd_view* v : {&a->x, &a->y, &a->y2, &a->r1, &a->r2, &a->mask})
+      if (v->ptr && v->planar && (v->c0 % 32 || v->cstride % 32)) return set_err(SRGANFD_EINVAL, "conv2d: a planar view needs c0 and cstride multiples of 32");
+    if (a->y.planar && a->y_f32) return set_err(SRGANFD_EINVAL, "conv2d: fp32 output views are NHWC only");
+    k.x_ps = a->x.planar ? 32 : a->x.cstride;
+    k.x_cs = a->x.planar ? (int)(ipix * 32) : 32;
+    k.x_base = a->x.planar ? (a->x.c0 / 32) * k.x_cs : a->x.c0;
+    auto out_strides = [&](const srganfd_view& v, int& ps, int& gs) { ps = v.planar ? 32 : v.cstride; gs = v.planar ? (int)(opix * 32) : 32; };
+    out_strides(a->y, k.y_ps, k.y_gs); out_strides(a->y2, k.y2_ps, k.y2_gs); out_strides(a->r1, k.r1_ps, k.r1_gs);
+    out_strides(a->r2, k.r2_ps, k.r2_gs); out_strides(a->mask, k.m_ps, k.m_gs);
+  }
   k.N = a->n; k.Hin = a->h_in; k.Win = a->w_in; k.up = a->up ? 1 : 0; k.pad_y = sub ? a->pad_y : a->pad; k.pad_x = sub ? a->pad_x : a->pad;
   k.osy = sub ? a->out_sy : 1; k.osx = sub ? a->out_sx : 1; k.ooy = sub ? a->out_oy : 0; k.oox = sub ? a->out_ox : 0;
   k.HoutF = sub ? a->out_h_full : a->h_out; k.WoutF = sub ? a->out_w_full : a->w_out;

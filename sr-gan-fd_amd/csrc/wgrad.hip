@@ -43,6 +43,7 @@ struct WgK {
   const void* x; const void* dy; float* slabs; float* bslabs;
   const WgGroup* groups;
   int xC, x_c0v, dyC, dy_c0v;
+  int x_ps, x_gs, dy_ps, dy_gs;   // pixel / 32-channel-group strides in elements: NHWC (C, 32) or planar groups (32, H*W*32), see srganfd_view
   int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y, ngroups;
   int dbg;   // timing experiments only (srganfd_set_debug): 1 no global loads, 4 no slab store, 8 no LDS commit, 16 no LDS reads, 32 no barriers
 };
@@ -127,8 +128,9 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   char* ldsX = smem;
   char* ldsY = smem + PR * PC * xRowB;
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
-  const T* __restrict__ xg = (const T*)a.x + a.x_c0v + G.x_c0;
-  const T* __restrict__ dyg = (const T*)a.dy + a.dy_c0v + G.dy_c0;
+  const int xcb = a.x_c0v + G.x_c0, ycb = a.dy_c0v + G.dy_c0;     // first channel this group stages
+  const T* __restrict__ xg = (const T*)a.x + ((xcb >> 5) * (size_t)a.x_gs + (xcb & 31));
+  const T* __restrict__ dyg = (const T*)a.dy + ((ycb >> 5) * (size_t)a.dy_gs + (ycb & 31));
 
   f32x16 acc[NT];
 #pragma unroll
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
       if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-        v = *(const u32x4*)(xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + c16 * E16));   // 64-bit image base + 32-bit offset (host-checked)
+        v = *(const u32x4*)(xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + ((c16 * E16) >> 5) * a.x_gs + ((c16 * E16) & 31)));   // 64-bit image base + 32-bit offset (host-checked)
     }
     return v;
   };
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
     if (item < yItems && !(a.dbg & 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dyC + c16 * E16));
+      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + ((c16 * E16) >> 5) * a.dy_gs + ((c16 * E16) & 31)));
     }
     return v;
   };
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
         const int py = pix / PC, px = pix - py * PC;
         const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
         if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl) {
-          const T* src = xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.xC + unit * 32 + w16 * E16);
+          const T* src = xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16);
           glds16(src, lds_addr(bx) + (unsigned)(piece * 1024));
         } else {
           *(u32x4*)(bx + item * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
         const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
         const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
         if (oy < a.Hout && ox < a.Wout) {
-          const T* src = dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dyC + unit * 32 + w16 * E16);
+          const T* src = dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + unit * a.dy_gs + w16 * E16);
           glds16(src, lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
         } else {
           *(u32x4*)(by + item * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -598,6 +600,10 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.x = x.ptr; k.dy = dy.ptr; k.slabs = (float*)workspace; k.bslabs = (float*)workspace + H.bias_slab_off;
   k.groups = (const WgGroup*)((const char*)plan_dev + H.groups_off);
   k.xC = x.cstride; k.x_c0v = x.c0; k.dyC = dy.cstride; k.dy_c0v = dy.c0;
+  if ((x.planar && (x.c0 % 32 || x.cstride % 32)) || (dy.planar && (dy.c0 % 32 || dy.cstride % 32)))
+    return set_err(SRGANFD_EINVAL, "wgrad: a planar view needs c0 and cstride multiples of 32");
+  k.x_ps = x.planar ? 32 : x.cstride; k.x_gs = x.planar ? H.Hin * H.Win * 32 : 32;
+  k.dy_ps = dy.planar ? 32 : dy.cstride; k.dy_gs = dy.planar ? H.Hout * H.Wout * 32 : 32;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
   k.dbg = g_debug; k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;

@@ -20,6 +20,7 @@ Data layout in HBM (per engine, per input shape):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -241,6 +242,12 @@ class TrunkEngine:
             catb = lambda i: cat[0] if i == 0 else cat[1 + (i - 1) % 4]
         sp.catb = catb
         V = A.view
+        # the dense-block buffers of the full generator are stored as planar 32-channel groups (srganfd_view.planar): every
+        # 32-channel chunk pass of a conv / weight-gradient launch then reads whole contiguous lines instead of 64 of the 384 bytes
+        # of each pixel, and the 96- / 160-channel convs stop fetching half-used lines.  Stand-alone blocks keep NHWC (their
+        # boundary kernels convert NCHW <-> NHWC directly into / out of these buffers).
+        sp.planar = 1 if (self.full and os.environ.get("SRGANFD_PLANAR", "1") != "0") else 0
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)
 
         def bias(name):
             return fptr + 4 * self._poff(name)
@@ -253,21 +260,21 @@ class TrunkEngine:
             sp.ups = [new(N, H << u, W << u, Cc) for u in range(1, self.n_up + 1)]
             sp.c3 = new(N, H * s, W * s, Cc)
             sp.srp = new(N, H * s, W * s, 4, dtype=torch.float32)
-            fw.append(ops.conv_args(dtc, V(sp.xin), V(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
+            fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
         for i, pre in enumerate(self._rdb_prefix):
             ci = catb(i)
             for k in range(1, 5):
-                fw.append(ops.conv_args(dtc, V(ci), V(ci, c0=Cc + (k - 1) * G), wptr + pk["offs"][("f", i, k)], N, H, W, Cc + (k - 1) * G, G,
+                fw.append(ops.conv_args(dtc, VC(ci), VC(ci, c0=Cc + (k - 1) * G), wptr + pk["offs"][("f", i, k)], N, H, W, Cc + (k - 1) * G, G,
                                         bias=bias(f"{pre}conv{k}.bias"), act=A.ACT_LRELU, slope=0.2))
             last = self.rrdb and i % 3 == 2
-            kw = dict(post_scale=0.04, r1=V(ci), r1_scale=0.2, r2=V(catb(i - 2)), r2_scale=1.0) if last else \
-                dict(post_scale=0.2, r1=V(ci), r1_scale=1.0)
-            fw.append(ops.conv_args(dtc, V(ci), V(catb(i + 1)), wptr + pk["offs"][("f", i, 5)], N, H, W, Ccat, Cc,
+            kw = dict(post_scale=0.04, r1=VC(ci), r1_scale=0.2, r2=VC(catb(i - 2)), r2_scale=1.0) if last else \
+                dict(post_scale=0.2, r1=VC(ci), r1_scale=1.0)
+            fw.append(ops.conv_args(dtc, VC(ci), VC(catb(i + 1)), wptr + pk["offs"][("f", i, 5)], N, H, W, Ccat, Cc,
                                     bias=bias(f"{pre}conv5.bias"), **kw))
         if self.full:
             tout = catb(R)
-            fw.append(ops.conv_args(dtc, V(tout), V(sp.f0), wptr + pk["offs"][("f", "conv2")], N, H, W, Cc, Cc, bias=bias("conv2.bias"),
-                                    r1=V(catb(0)), r1_scale=1.0))
+            fw.append(ops.conv_args(dtc, VC(tout), V(sp.f0), wptr + pk["offs"][("f", "conv2")], N, H, W, Cc, Cc, bias=bias("conv2.bias"),
+                                    r1=VC(catb(0)), r1_scale=1.0))
             src, h, w = sp.f0, H, W
             for u in range(1, self.n_up + 1):
                 nm = f"upsampling{u}.0"
@@ -291,6 +298,7 @@ class TrunkEngine:
         Cc, G, Ccat, R = self.Cc, self.G, self.Ccat, self.R
         wptr = pk["buf"].data_ptr()
         V = A.view
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)      # dense-block buffers (forward cat, stacked gradients)
 
         def new(*shape, dtype=dt):
             return torch.empty(*shape, dtype=dtype, device=device)
@@ -352,8 +360,8 @@ class TrunkEngine:
             d_f0 = cur if self.n_up else sp.gB
             sp.d_f0 = d_f0
             # conv2: f0 = out1 + conv2(trunk_out)
-            bw.append(("wgrad", wplan(N, H, W, Cc, Cc, one("conv2", Cc, Cc)), V(sp.catb(R)), V(d_f0), 0))
-            bw.append(("conv", ops.conv_args(dtc, V(d_f0), V(dyb(R - 1)), wptr + pk["offs"][("b", "conv2")], N, H, W, Cc, Cc)))
+            bw.append(("wgrad", wplan(N, H, W, Cc, Cc, one("conv2", Cc, Cc)), VC(sp.catb(R)), V(d_f0), 0))
+            bw.append(("conv", ops.conv_args(dtc, V(d_f0), VC(dyb(R - 1)), wptr + pk["offs"][("b", "conv2")], N, H, W, Cc, Cc)))
         # dense blocks, last to first
         rdb_names = ["conv%d" % k for k in range(1, 6)]
         plans = {}
@@ -375,14 +383,14 @@ class TrunkEngine:
                 plans[s5] = wplan(N, H, W, Ccat, Ccat, convs)
             for step in range(4):
                 kdim = Cc + step * G
-                bw.append(("conv", ops.conv_args(dtc, V(di), V(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
-                                                 mask=V(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
-            bw.append(("wgrad", plans[s5], V(ci), V(di), self._poff(pre + "conv1.weight")))
-            dst = V(dyb(i - 1)) if i > 0 else V(sp.dx0)
-            kw = dict(r1=V(di), r1_scale=s_out)
+                bw.append(("conv", ops.conv_args(dtc, VC(di), VC(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
+                                                 mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
+            bw.append(("wgrad", plans[s5], VC(ci), VC(di), self._poff(pre + "conv1.weight")))
+            dst = VC(dyb(i - 1)) if i > 0 else V(sp.dx0)
+            kw = dict(r1=VC(di), r1_scale=s_out)
             if first:
-                kw.update(r2=V(dyb(i + 2)), r2_scale=1.0)
-            bw.append(("conv", ops.conv_args(dtc, V(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw)))
+                kw.update(r2=VC(dyb(i + 2)), r2_scale=1.0)
+            bw.append(("conv", ops.conv_args(dtc, VC(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw)))
         if self.full:
             bw.append(("call", (lambda x=V(sp.d_f0), y=V(sp.dx0): A.check(
                 A.lib().srganfd_axpby(x, y, dtc, N * H * W, Cc, 1.0, 1.0, A.stream_ptr()), "axpby"))))
