@@ -48,17 +48,17 @@ BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32,
 #     traffic = (2 x RDREQ + WRREQ) x 64 B.
 # Infinity-Cache hits are inside these counts (they sit behind L2), i.e. this is fabric-side traffic, an upper bound of HBM's.
 PMC_TRAFFIC_BYTES = {
-    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": (2 * 1.559e6 + 5.271e5) * 64,
-    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": (2 * 2.533e6 + 1.622e6) * 64,
-    "wgrad_kernel<bf16,KS=3,S=1>+reduce": (2 * (4.339e6 + 2.959e5) + 5.907e5 + 1.112e5) * 64,
+    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": (2 * 1.104e6 + 5.944e5) * 64,
+    "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": (2 * 2.601e6 + 1.818e6) * 64,
+    "wgrad_kernel<bf16,KS=3,S=1>+reduce": (2 * (4.697e6 + 2.959e5) + 5.907e5 + 1.112e5) * 64,
 }
 # MFMA-pipe utilisation from a third rocprofv3 pass (profiles/r01_pmc_mfma_busy.txt):
 #     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); the counter is 32 cycles per v_mfma_f32_32x32x16_bf16.
 PMC_MFMA_UTIL = {
-    "g_only": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.246, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.394,
-               "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.387},
-    "gan": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.247, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.426,
-            "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.416},
+    "g_only": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.275, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.400,
+               "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.378},
+    "gan": {"conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=8,WN=1>": 0.270, "conv_igemm_kernel<bf16,KS=3,S=1,MR=2,WR=4,WN=2>": 0.422,
+            "wgrad_kernel<bf16,KS=3,S=1>+reduce": 0.405},
 }
 REALESRGAN_DEGRADATION = dict(      # realesrgan_config.py:67-90
     first_blur_probability=1.0, resize_probability1=[0.2, 0.7, 0.1], resize_range1=[0.15, 1.5], gray_noise_probability1=0.4,
