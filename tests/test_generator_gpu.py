@@ -231,3 +231,25 @@ def test_runs_on_the_callers_stream():
     side.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(got_loss, want_loss))
     assert torch.equal(tr.opt.flat, want_flat)
+
+
+def test_planar_dense_block_buffers_change_nothing_but_the_addresses(monkeypatch):
+    """The generator keeps its dense-block buffers as planar 32-channel groups; SRGANFD_PLANAR=0 keeps them NHWC.  Same
+    kernels, same summation order: SR, loss and the updated parameters of a training iteration are bitwise equal in both layouts,
+    at a size that is not a multiple of the tiles (ragged edges exercise the per-plane row ends)."""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    lr, gt = torch.rand(3, 3, 37, 52, device="cuda"), torch.rand(3, 3, 148, 208, device="cuda")
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SRGANFD_PLANAR", flag)
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(num_rrdb=2)
+        scaled_init(g, 3.0, 0.5)
+        g.compute_dtype = torch.bfloat16
+        tr = GeneratorTrainer(g.cuda().train(), lr=1e-4)
+        losses = [tr.step(lr, gt).clone() for _ in range(2)]
+        assert tr.eng._last.planar == int(flag)
+        res[flag] = (losses, tr.sr.clone(), tr.opt.flat.clone())
+    assert all(torch.equal(a, b) for a, b in zip(res["1"][0], res["0"][0]))
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])

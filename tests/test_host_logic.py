@@ -150,6 +150,25 @@ def test_content_losses_and_fused_trainers_dry_run():
         A.set_dry_run(False)
 
 
+def test_planar_views_are_validated():
+    """srganfd_view.planar (32-channel group planes): conv2d / conv2d_wgrad accept it for aligned channel ranges only"""
+    from sr_gan_fd_amd import _abi as A, ops
+    A.set_dry_run(True)
+    try:
+        L = A.lib()
+        x = torch.zeros(1, 8, 8, 192)
+        y = torch.zeros(1, 8, 8, 192)
+        wp = torch.zeros(ops.packed_bytes(A.BF16, 3, 96, 32), dtype=torch.uint8)
+        ok = ops.conv_args(A.BF16, A.view(x, planar=1), A.view(y, c0=96, planar=1), wp.data_ptr(), 1, 8, 8, 96, 32)
+        assert L.srganfd_conv2d(C.byref(ok), None) == 0
+        bad = ops.conv_args(A.BF16, A.view(x, planar=1), A.view(y, c0=104, planar=1), wp.data_ptr(), 1, 8, 8, 96, 32)
+        assert L.srganfd_conv2d(C.byref(bad), None) != 0 and b"planar" in L.srganfd_last_error()
+        f32out = ops.conv_args(A.BF16, A.view(x, planar=1), A.view(torch.zeros(1, 8, 8, 32), planar=1), wp.data_ptr(), 1, 8, 8, 96, 32, y_f32=True)
+        assert L.srganfd_conv2d(C.byref(f32out), None) != 0
+    finally:
+        A.set_dry_run(False)
+
+
 def test_validation_side_argument_checks():
     from sr_gan_fd_amd import _abi as A
     A.set_dry_run(True)
