@@ -1,7 +1,10 @@
-"""Micro-benchmark single fused-conv launches (layout / shape experiments).  python tools/kbench.py"""
+"""Micro-benchmark single fused-conv launches (layout / shape experiments).  python tools/kbench.py [--quick|--batch|--chain] [--dbg N] [--planar]"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from sr_gan_fd_amd import _abi as A, ops
+
+PLANAR = 1 if "--planar" in sys.argv else 0     # operand buffers as planar 32-channel groups (srganfd_view.planar)
+
 
 def run(name, n, h, w, cin, cout, xC, x0, yC, y0, reps=30, mask=False, dt=torch.bfloat16):
     dtc = ops.DT[dt]
@@ -12,8 +15,8 @@ def run(name, n, h, w, cin, cout, xC, x0, yC, y0, reps=30, mask=False, dt=torch.
     kw = {}
     if mask:
         m = torch.randn(n, h, w, yC, device='cuda').to(dt)
-        kw = dict(mask=A.view(m, c0=y0))
-    a = ops.conv_args(dtc, A.view(x, c0=x0), A.view(y, c0=y0), wp, n, h, w, cin, cout, act=A.ACT_LRELU, **kw)
+        kw = dict(mask=A.view(m, c0=y0, planar=PLANAR))
+    a = ops.conv_args(dtc, A.view(x, c0=x0, planar=PLANAR), A.view(y, c0=y0, planar=PLANAR), wp, n, h, w, cin, cout, act=A.ACT_LRELU, **kw)
     for _ in range(3): ops.conv2d(a)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
