@@ -247,7 +247,10 @@ class TrunkEngine:
         # of each pixel, and the 96- / 160-channel convs stop fetching half-used lines.  Stand-alone blocks keep NHWC (their
         # boundary kernels convert NCHW <-> NHWC directly into / out of these buffers).
         sp.planar = 1 if (self.full and os.environ.get("SRGANFD_PLANAR", "1") != "0") else 0
-        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)
+        _mode = os.environ.get("SRGANFD_PLANAR", "1")            # experiment: "2" forward buffers only, "3" gradient buffers only
+        sp.planar_cat = 1 if (sp.planar and _mode != "3") else 0
+        sp.planar_dy = 1 if (sp.planar and _mode != "2") else 0
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_cat)
 
         def bias(name):
             return fptr + 4 * self._poff(name)
@@ -298,7 +301,8 @@ class TrunkEngine:
         Cc, G, Ccat, R = self.Cc, self.G, self.Ccat, self.R
         wptr = pk["buf"].data_ptr()
         V = A.view
-        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)      # dense-block buffers (forward cat, stacked gradients)
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_cat)      # forward dense-block buffers
+        VD = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_dy)       # stacked-gradient buffers
 
         def new(*shape, dtype=dt):
             return torch.empty(*shape, dtype=dtype, device=device)
@@ -361,7 +365,7 @@ class TrunkEngine:
             sp.d_f0 = d_f0
             # conv2: f0 = out1 + conv2(trunk_out)
             bw.append(("wgrad", wplan(N, H, W, Cc, Cc, one("conv2", Cc, Cc)), VC(sp.catb(R)), V(d_f0), 0))
-            bw.append(("conv", ops.conv_args(dtc, V(d_f0), VC(dyb(R - 1)), wptr + pk["offs"][("b", "conv2")], N, H, W, Cc, Cc)))
+            bw.append(("conv", ops.conv_args(dtc, V(d_f0), VD(dyb(R - 1)), wptr + pk["offs"][("b", "conv2")], N, H, W, Cc, Cc)))
         # dense blocks, last to first
         rdb_names = ["conv%d" % k for k in range(1, 6)]
         plans = {}
@@ -383,14 +387,14 @@ class TrunkEngine:
                 plans[s5] = wplan(N, H, W, Ccat, Ccat, convs)
             for step in range(4):
                 kdim = Cc + step * G
-                bw.append(("conv", ops.conv_args(dtc, VC(di), VC(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
+                bw.append(("conv", ops.conv_args(dtc, VD(di), VD(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
                                                  mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
-            bw.append(("wgrad", plans[s5], VC(ci), VC(di), self._poff(pre + "conv1.weight")))
-            dst = VC(dyb(i - 1)) if i > 0 else V(sp.dx0)
-            kw = dict(r1=VC(di), r1_scale=s_out)
+            bw.append(("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight")))
+            dst = VD(dyb(i - 1)) if i > 0 else V(sp.dx0)
+            kw = dict(r1=VD(di), r1_scale=s_out)
             if first:
-                kw.update(r2=VC(dyb(i + 2)), r2_scale=1.0)
-            bw.append(("conv", ops.conv_args(dtc, VC(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw)))
+                kw.update(r2=VD(dyb(i + 2)), r2_scale=1.0)
+            bw.append(("conv", ops.conv_args(dtc, VD(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw)))
         if self.full:
             bw.append(("call", (lambda x=V(sp.d_f0), y=V(sp.dx0): A.check(
                 A.lib().srganfd_axpby(x, y, dtc, N * H * W, Cc, 1.0, 1.0, A.stream_ptr()), "axpby"))))
