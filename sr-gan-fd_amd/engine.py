@@ -247,10 +247,7 @@ class TrunkEngine:
         # of each pixel, and the 96- / 160-channel convs stop fetching half-used lines.  Stand-alone blocks keep NHWC (their
         # boundary kernels convert NCHW <-> NHWC directly into / out of these buffers).
         sp.planar = 1 if (self.full and os.environ.get("SRGANFD_PLANAR", "1") != "0") else 0
-        _mode = os.environ.get("SRGANFD_PLANAR", "1")            # experiment: "2" forward buffers only, "3" gradient buffers only
-        sp.planar_cat = 1 if (sp.planar and _mode != "3") else 0
-        sp.planar_dy = 1 if (sp.planar and _mode != "2") else 0
-        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_cat)
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)
 
         def bias(name):
             return fptr + 4 * self._poff(name)
@@ -301,8 +298,9 @@ class TrunkEngine:
         Cc, G, Ccat, R = self.Cc, self.G, self.Ccat, self.R
         wptr = pk["buf"].data_ptr()
         V = A.view
-        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_cat)      # forward dense-block buffers
-        VD = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar_dy)       # stacked-gradient buffers
+        VC = lambda t, c0=0: A.view(t, c0=c0, planar=sp.planar)      # forward dense-block buffers
+        VD = VC                                                       # stacked-gradient buffers (same layout: planar only one of
+        #                                                               the two measured half the gain each)
 
         def new(*shape, dtype=dt):
             return torch.empty(*shape, dtype=dtype, device=device)
