@@ -24,6 +24,7 @@ extern "C" {
 /* element type of activations / packed weights */
 #define SRGANFD_BF16 0
 #define SRGANFD_F32 1
+#define SRGANFD_F16 2   /* IEEE half: what the reference's amp.autocast() computes in on its GPU path (train_bsrgan.py:415-467) */
 
 /* epilogue activation */
 #define SRGANFD_ACT_NONE 0
@@ -35,9 +36,15 @@ int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
 void srganfd_set_dry_run(int on);
-/* timing experiments only: bit 0 skip activation loads, bit 1 skip weight loads, bit 2 skip the epilogue of
- * the conv kernel (results are wrong when non-zero; never set in production). */
+#ifdef SRGANFD_EXPERIMENT
+/* kernel timing experiments (tools/build_variant.sh builds only; the product library does not export it): bit 0 skip
+ * activation loads, bit 1 skip weight loads, bit 2 skip the epilogue of the conv kernels -- results are wrong when non-zero. */
 void srganfd_set_debug(int flags);
+#endif
+/* Which kernel serves the 3x3 stride-1 16-bit convolutions: 0 = conv_igemm tiles only, 1 = the LDS-DMA ring kernel with its
+ * default tile per shape (library default; also the environment variable SRGANFD_RING, read once), 2.. = other ring
+ * configurations (same results; tools/kbench.py times them against each other in one process).  -1 = back to the default. */
+void srganfd_set_ring_mode(int mode);
 
 /* A channel-slice view of an NHWC activation buffer: element (n,y,x,c) lives at
  * ptr[((n*H + y)*W + x)*cstride + c0 + c]. */
@@ -92,6 +99,9 @@ typedef struct {
 } srganfd_conv_args;
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream);
+/* Name of the kernel template srganfd_conv2d dispatches these arguments to (validates them, launches nothing): the class label
+ * of bench.py's per-kernel timing and of the rocprofv3 summaries under profiles/. */
+int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_len);
 
 /* Weight packing: NCHW fp32 parameters -> MFMA B-fragment order (dtype bf16/f32).
  * A packed operand is a logical matrix W[tap][k][n]; its k range is assembled from up to 5

@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRGANFD_LIB") or os.path.join(_HERE, "libsrganfd_hip.so")   # SRGANFD_LIB: A/B kernel builds (tools/)
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
+DT_NAME = {BF16: "bf16", F32: "f32", F16: "f16"}
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 
 
@@ -70,8 +71,9 @@ SYMBOLS = {
     "srganfd_last_error": (C.c_char_p, []),
     "srganfd_abi_version": (C.c_int, []),
     "srganfd_set_dry_run": (None, [C.c_int]),
-    "srganfd_set_debug": (None, [C.c_int]),
+    "srganfd_set_ring_mode": (None, [C.c_int]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "srganfd_conv2d_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_wgrad_plan_bytes": (C.c_size_t, [C.POINTER(WgradShape), C.POINTER(WgradConv)]),
@@ -151,6 +153,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if hasattr(l, "srganfd_set_debug"):        # -DSRGANFD_EXPERIMENT builds only (tools/build_variant.sh)
+            l.srganfd_set_debug.restype, l.srganfd_set_debug.argtypes = None, [C.c_int]
         _lib = l
     return _lib
 

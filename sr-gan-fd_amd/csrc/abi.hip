@@ -1,11 +1,14 @@
 // abi.hip -- extern "C" surface of libsrganfd_hip.so (see include/srganfd.h).
 #include "common.hpp"
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace srganfd {
 thread_local char g_err[512] = {0};
 int g_dry_run = 0;
 int g_debug = 0;
+thread_local char* g_describe = nullptr;
+thread_local size_t g_describe_len = 0;
 int set_err(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -81,13 +84,23 @@ extern "C" {
 const char* srganfd_last_error(void) { return g_err; }
 int srganfd_abi_version(void) { return 1; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
-void srganfd_set_debug(int flags) { g_debug = flags; }
+#ifdef SRGANFD_EXPERIMENT
+void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
+#endif
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }
+int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_len) {
+  if (!out || !out_len) return set_err(SRGANFD_EINVAL, "conv2d_describe: no buffer");
+  out[0] = 0;
+  g_describe = out; g_describe_len = out_len;
+  const int rc = conv2d_impl(a, nullptr);
+  g_describe = nullptr; g_describe_len = 0;
+  return rc;
+}
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n) {
   if (k <= 0 || n <= 0 || k % 32 || n % 32) return 0;
-  return (size_t)ksize * ksize * k * n * (dtype == SRGANFD_BF16 ? 2 : 4);
+  return (size_t)ksize * ksize * k * n * (dtype == SRGANFD_F32 ? 4 : 2);
 }
 int srganfd_pack_weights(const srganfd_pack_job* jobs_dev, int32_t njobs, int64_t max_elems, const float* params,
                          const float* scalars, void* packed, void* stream) {

@@ -17,6 +17,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 typedef unsigned short bf16_t;  // storage type for bf16
+typedef _Float16 f16_t;         // IEEE half (the reference's CUDA autocast dtype, train_bsrgan.py:415-467): same MFMA rate and bytes as
+                                // bf16, 3 more mantissa bits -- the mode whose SR meets the 1e-3 tolerance; gradients need loss scaling
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // round-to-nearest-even fp32 -> bf16 (plain cast keeps NaN a NaN: MI355X guide, correctness table)
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -34,6 +37,12 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
   __device__ static __forceinline__ bf16_t from_f(float f) { return f2bf(f); }
 };
+template <> struct Elem<f16_t> {
+  static constexpr int kDtype = SRGANFD_F16;
+  static constexpr int kStep = 16;  // K per MFMA (v_mfma_f32_32x32x16_f16)
+  __device__ static __forceinline__ float to_f(f16_t v) { return (float)v; }
+  __device__ static __forceinline__ f16_t from_f(float f) { return (f16_t)f; }   // round-to-nearest-even; overflow -> inf (caught by the loss scaler)
+};
 template <> struct Elem<float> {
   static constexpr int kDtype = SRGANFD_F32;
   static constexpr int kStep = 2;   // K per MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain)
@@ -48,9 +57,13 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) {
 }
 
 extern thread_local char g_err[512];
-extern int g_debug;    // srganfd_set_debug: kernel timing experiments (results are WRONG when non-zero)
+extern int g_debug;    // SRGANFD_EXPERIMENT builds only (srganfd_set_debug): kernel timing experiments, results are WRONG when non-zero
 extern int g_dry_run;  // srganfd_set_dry_run(1): validate arguments, build plans, launch nothing (host-logic tests on CPU)
 int set_err(int code, const char* fmt, ...);
+// srganfd_conv2d_describe: the launch functions write the label of the kernel they would run here instead of launching
+extern thread_local char* g_describe;
+extern thread_local size_t g_describe_len;
+template <typename T> inline const char* dtype_name() { return sizeof(T) == 4 ? "f32" : (Elem<T>::kDtype == SRGANFD_F16 ? "f16" : "bf16"); }
 
 #define SRGANFD_HIP_CHECK(expr)                                                          \
   do {                                                                                   \

@@ -1,0 +1,83 @@
+// conv_common.hpp -- launch arguments and MFMA helpers shared by the fused-convolution kernels
+// (conv_igemm.hip: every kernel shape, f32 parity mode; conv3x3_ring.hip: the 3x3 stride-1 16-bit hot path).
+#pragma once
+#include "common.hpp"
+
+namespace srganfd {
+
+// Kernel timing experiments (tools/build_variant.sh builds with -DSRGANFD_EXPERIMENT): the product library neither
+// carries the branches nor exports srganfd_set_debug.
+#ifdef SRGANFD_EXPERIMENT
+#define SRGANFD_DBG(flags, bit) ((flags) & (bit))
+#else
+#define SRGANFD_DBG(flags, bit) 0
+#endif
+
+struct ConvK {
+  const void* x; void* y; void* y2; const void* r1; const void* r2; const void* mask; const void* w;
+  const float* bias; const float* alpha_dev;
+  int xC, x_c0, yC, y_c0, y2C, y2_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
+  // element (pixel p, channel c) of an operand's image sits at p * ps + (c >> 5) * gs + (c & 31): NHWC ps = C, gs = 32;
+  // planar 32-channel groups (srganfd_view.planar) ps = 32, gs = H*W*32.  x additionally: first chunk at x_base, next at + x_cs.
+  int x_ps, x_base, x_cs, y_ps, y_gs, y2_ps, y2_gs, r1_ps, r1_gs, r2_ps, r2_gs, m_ps, m_gs;
+  int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
+  int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
+  int nChunks;        // cin / 32
+  int nNb;            // cout / (output channels per workgroup)
+  int cout_store;
+  int tiles_x, tiles_y;
+  float alpha, slope, post_scale, r1s, r2s, mask_slope;
+  int act, y_f32, fast_epi;
+  int dbg;            // SRGANFD_EXPERIMENT builds only: 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
+};
+
+template <typename T> struct FragAB;
+template <> struct FragAB<bf16_t> { typedef bf16x8 type; };
+template <> struct FragAB<f16_t> { typedef f16x8 type; };
+template <> struct FragAB<float> { typedef float type; };
+
+template <typename T> __device__ __forceinline__ f32x16 mfma32(typename FragAB<T>::type a, typename FragAB<T>::type b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma32<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<f16_t>(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<float>(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous range
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+}
+
+// 8 consecutive 16-bit elements (one 16-byte chunk) <-> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 raw, float* out);
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 raw, float* out) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { out[2 * q] = __uint_as_float(raw[q] << 16); out[2 * q + 1] = __uint_as_float(raw[q] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack8<f16_t>(const u32x4 raw, float* out) {
+  const f16x8 hv = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) out[q] = (float)hv[q];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float* v);
+template <> __device__ __forceinline__ u32x4 pack8<bf16_t>(const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = (unsigned)f2bf(v[2 * q]) | ((unsigned)f2bf(v[2 * q + 1]) << 16);
+  return o;
+}
+template <> __device__ __forceinline__ u32x4 pack8<f16_t>(const float* v) {
+  f16x8 hv;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) hv[q] = (_Float16)v[q];
+  return __builtin_bit_cast(u32x4, hv);
+}
+
+int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);
+
+}  // namespace srganfd

@@ -26,7 +26,7 @@
 //     16-byte stores (one pixel's channels are contiguous in NHWC).
 //   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32, an exact
 //     fp32 fma chain, used as the parity mode against the CPU oracle.
-#include "common.hpp"
+#include "conv_common.hpp"
 #include <utility>
 namespace srganfd {
 // compile-time loop (indices as types), for the software-pipelined MFMA phase
@@ -38,36 +38,6 @@ __host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need
 }
 
 namespace srganfd {
-
-struct ConvK {
-  const void* x; void* y; void* y2; const void* r1; const void* r2; const void* mask; const void* w;
-  const float* bias; const float* alpha_dev;
-  int xC, x_c0, yC, y_c0, y2C, y2_c0, r1C, r1_c0, r2C, r2_c0, mC, m_c0;
-  // element (pixel p, channel c) of an operand's image sits at p * ps + (c >> 5) * gs + (c & 31): NHWC ps = C, gs = 32;
-  // planar 32-channel groups (srganfd_view.planar) ps = 32, gs = H*W*32.  x additionally: first chunk at x_base, next at + x_cs.
-  int x_ps, x_base, x_cs, y_ps, y_gs, y2_ps, y2_gs, r1_ps, r1_gs, r2_ps, r2_gs, m_ps, m_gs;
-  int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
-  int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
-  int nChunks;        // cin / 32
-  int nNb;            // cout / (32*WN)
-  int cout_store;
-  int tiles_x, tiles_y;
-  float alpha, slope, post_scale, r1s, r2s, mask_slope;
-  int act, y_f32, fast_epi;
-  int dbg;            // timing experiments only (srganfd_set_debug): 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
-};
-
-template <typename T> struct FragAB;
-template <> struct FragAB<bf16_t> { typedef bf16x8 type; };
-template <> struct FragAB<float> { typedef float type; };
-
-template <typename T> __device__ __forceinline__ f32x16 mfma32(typename FragAB<T>::type a, typename FragAB<T>::type b, f32x16 c);
-template <> __device__ __forceinline__ f32x16 mfma32<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x16 mfma32<float>(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
 
 template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
 struct ConvCfg {
@@ -121,11 +91,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   const int r = lane & 31, h = lane >> 5;
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (L2), give each XCD a contiguous range
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  }
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int nb = bid % a.nNb;
   int t = bid / a.nNb;
   const int tx = t % a.tiles_x; t /= a.tiles_x;
@@ -145,7 +111,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     const int pix = item / C::CPP, c16 = item % C::CPP;
     const int py = pix / C::PC, px = pix % C::PC;
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
-    const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !(a.dbg & 1);
+    const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
     xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
   }
   // LDS destination of staging item i = ldsx0 + i * (PIX_PER_I * PIXB): the swizzle term is i-invariant
@@ -171,7 +137,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   auto load_w = [&](int i, int chunk) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < C::NW16 && !(a.dbg & 2)) {
+    if (item < C::NW16 && !SRGANFD_DBG(a.dbg, 2)) {
       // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]
       const int nn = item / (C::WN_BYTES / 16), rem = item % (C::WN_BYTES / 16);
       v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + rem];
@@ -230,9 +196,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
 
   prefetch(0);
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
-    if (!(a.dbg & 32)) __syncthreads();
-    if (!(a.dbg & 8)) commit(chunk);
-    if (!(a.dbg & 32)) __syncthreads();
+    if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
+    if (!SRGANFD_DBG(a.dbg, 8)) commit(chunk);
+    if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
 
     auto col_body = [&](int kx, int s) {
@@ -293,7 +259,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   }
 
   // ---- epilogue (see srganfd.h for the formula) ----
-  if (a.dbg & 4) { if (acc[0][0] == 123.456f) ((float*)a.y)[0] = 1.f; return; }
+  if (SRGANFD_DBG(a.dbg, 4)) { if (acc[0][0] == 123.456f) ((float*)a.y)[0] = 1.f; return; }
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
   const int co = (nb * WN + wn) * 32 + r;
@@ -343,12 +309,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
           const int cc = c0 + cch;
           const T* src = (const T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
-            const u32x4 raw = *(const u32x4*)src;
-            const unsigned w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
-            out[0] = __uint_as_float(w0 << 16); out[1] = __uint_as_float(w0 & 0xffff0000u);
-            out[2] = __uint_as_float(w1 << 16); out[3] = __uint_as_float(w1 & 0xffff0000u);
-            out[4] = __uint_as_float(w2 << 16); out[5] = __uint_as_float(w2 & 0xffff0000u);
-            out[6] = __uint_as_float(w3 << 16); out[7] = __uint_as_float(w3 & 0xffff0000u);
+            unpack8<T>(*(const u32x4*)src, out);
           } else {
             const f32x4 rf = *(const f32x4*)src;
             out[0] = rf[0]; out[1] = rf[1]; out[2] = rf[2]; out[3] = rf[3];
@@ -358,12 +319,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
           const int cc = c0 + cch;
           T* dstp = (T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
-            u32x4 o;
-            o[0] = (unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16);
-            o[1] = (unsigned)f2bf(vv[2]) | ((unsigned)f2bf(vv[3]) << 16);
-            o[2] = (unsigned)f2bf(vv[4]) | ((unsigned)f2bf(vv[5]) << 16);
-            o[3] = (unsigned)f2bf(vv[6]) | ((unsigned)f2bf(vv[7]) << 16);
-            *(u32x4*)dstp = o;
+            *(u32x4*)dstp = pack8<T>(vv);
           } else {
             f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
             *(f32x4*)dstp = o;
@@ -423,10 +379,15 @@ template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
   auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN>;
-  static bool attr_done = false;
-  if (!attr_done && !g_dry_run) {
-    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_done = true;
+  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d>", dtype_name<T>(), KS, STRIDE, MR, WR, WN); return SRGANFD_OK; }
+  static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
+  if (!g_dry_run) {
+    int dev = 0;
+    SRGANFD_HIP_CHECK(hipGetDevice(&dev));
+    if (!(attr_done >> (dev & 63) & 1ULL)) {
+      SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+      attr_done |= 1ULL << (dev & 63);
+    }
   }
   ConvK kk = k;
   kk.nNb = cout / C::NB;
@@ -473,7 +434,7 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   } else if (a->out_h_full < (a->h_out - 1) * a->out_sy + a->out_oy + 1 || a->out_w_full < (a->w_out - 1) * a->out_sx + a->out_ox + 1) {
     return set_err(SRGANFD_EINVAL, "conv2d: strided output does not fit the full image");
   }
-  const int align = a->dtype == SRGANFD_BF16 ? 8 : 4;
+  const int align = a->dtype == SRGANFD_F32 ? 4 : 8;
   if (a->x.cstride % align || a->x.c0 % align) return set_err(SRGANFD_EINVAL, "conv2d: x view not 16-byte aligned");
   if (a->x.c0 + a->cin > a->x.cstride) return set_err(SRGANFD_EINVAL, "conv2d: x view exceeds buffer channels");
   if (a->y.c0 + a->cout_store > a->y.cstride) return set_err(SRGANFD_EINVAL, "conv2d: y view exceeds buffer channels");
@@ -511,9 +472,19 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;
   auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
+#ifdef SRGANFD_EXPERIMENT
   k.dbg = g_debug;
+#else
+  k.dbg = 0;
+#endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
+  {
+    bool handled = false;
+    const int rc = conv3x3_ring_try(a, k, stream, &handled);   // 3x3 stride-1 16-bit launches large enough to fill the chip
+    if (rc != SRGANFD_OK || handled) return rc;
+  }
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);
+  if (a->dtype == SRGANFD_F16) return dispatch_conv<f16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F32) return dispatch_conv<float>(a, k, stream);
   return set_err(SRGANFD_EINVAL, "conv2d: bad dtype %d", a->dtype);
 }

@@ -1,7 +1,7 @@
 // pack.hip -- NCHW fp32 parameters -> MFMA B-fragment order (see srganfd.h, srganfd_pack_weights).
 // Layout of a packed operand W[tap][k][n] (k, n multiples of 32):
 //   [n/32][k/32][tap][kstep][lane 0..63][frag]   with
-//   bf16: kstep in 0..1, frag = 8 bf16, k = 32*chunk + 16*kstep + 8*(lane>>5) + j, n = 32*ntile + (lane&31)
+//   bf16 / f16: kstep in 0..1, frag = 8 elements, k = 32*chunk + 16*kstep + 8*(lane>>5) + j, n = 32*ntile + (lane&31)
 //   f32 : kstep in 0..15, frag = 1 float, k = 32*chunk + 2*kstep + (lane>>5)
 // i.e. exactly the order in which conv_igemm.hip's lanes consume B fragments, so staging a
 // (chunk, n-tile) slab into LDS is a linear 16-byte copy and the fragment read is conflict free.
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const srganfd_pack_job* __res
     const int tap = (int)(blk % KT); blk /= KT;
     const int chunk = (int)(blk % nChunks);
     const int ntile = (int)(blk / nChunks);
-    if (J.dtype == SRGANFD_BF16) {
+    if (J.dtype != SRGANFD_F32) {   // bf16 / f16: same fragment order
       const int j = within & 7; lane = (within >> 3) & 63; s = within >> 9;
       k_in = 16 * s + 8 * (lane >> 5) + j;
     } else {
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const srganfd_pack_job* __res
       }
     }
     if (J.dtype == SRGANFD_BF16) ((bf16_t*)(packed + J.dst_off))[e] = f2bf(v);
+    else if (J.dtype == SRGANFD_F16) ((f16_t*)(packed + J.dst_off))[e] = (f16_t)v;
     else ((float*)(packed + J.dst_off))[e] = v;
   }
 }

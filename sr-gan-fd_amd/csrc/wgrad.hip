@@ -15,7 +15,7 @@
 // each wave writes an fp32 partial slab and a second kernel reduces the slabs deterministically
 // (no float atomics: results are bitwise reproducible) straight into the NCHW fp32 gradient.
 // f32 mode (parity) uses v_mfma_f32_32x32x2_f32 with plain ds_read_b32 (channels on the lanes).
-#include "common.hpp"
+#include "conv_common.hpp"
 #include <string.h>
 #include <vector>
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   auto load_x = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < xItems && !(a.dbg & 1)) {
+    if (item < xItems && !SRGANFD_DBG(a.dbg, 1)) {
       const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   auto load_y = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < yItems && !(a.dbg & 1)) {
+    if (item < yItems && !SRGANFD_DBG(a.dbg, 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + ((c16 * E16) >> 5) * a.dy_gs + ((c16 * E16) & 31)));
@@ -292,13 +292,13 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       // ---- loader wavefronts: tile t+1 -> buffer cur^1 while the compute waves run tile t out of buffer cur ----
       int n, oy0, ox0;
       __builtin_amdgcn_s_setprio(3);   // the copy must not wait behind the compute waves' issue slots (334 -> 317 us)
-      if (tile < a.ntiles && !(a.dbg & 1)) { tile_origin(tile, n, oy0, ox0); dma_slots(n, oy0, ox0, 0); }
+      if (tile < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) { tile_origin(tile, n, oy0, ox0); dma_slots(n, oy0, ox0, 0); }
       for (; tile < a.ntiles; tile += a.S) {
         // own DMAs landed (vmcnt) and zero fills written (lgkmcnt in the barrier's fence); past the barrier the buffer
         // is published and nobody reads buffer cur^1 any more (its MFMA phase precedes this barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + a.S < a.ntiles && !(a.dbg & 1)) { tile_origin(tile + a.S, n, oy0, ox0); dma_slots(n, oy0, ox0, cur ^ 1); }
+        if (tile + a.S < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) { tile_origin(tile + a.S, n, oy0, ox0); dma_slots(n, oy0, ox0, cur ^ 1); }
         cur ^= 1;
       }
       return;
@@ -311,12 +311,12 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       ldsY = ldsX + PR * PC * xRowB;
       cur ^= 1;
     } else {
-      if (!(a.dbg & 32)) __syncthreads();  // previous tile's LDS reads done
-      if (!(a.dbg & 8)) commit(tile);
-      if (!(a.dbg & 32)) __syncthreads();
+      if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();  // previous tile's LDS reads done
+      if (!SRGANFD_DBG(a.dbg, 8)) commit(tile);
+      if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
       if (tile + a.S < a.ntiles) prefetch(tile + a.S);
     }
-    if (W.active && !(a.dbg & 16)) {
+    if (W.active && !SRGANFD_DBG(a.dbg, 16)) {
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
         if constexpr (sizeof(T) == 2) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       }
     }
   }
-  if (W.active && !(a.dbg & 4)) {
+  if (W.active && !SRGANFD_DBG(a.dbg, 4)) {
     float* slab = a.slabs + (size_t)(W.slab_base + split * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
@@ -564,11 +564,15 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
 static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
   auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP, DMA>;
-  static int attr_lds = 0;
+  static int attr_lds[64] = {0};   // per device: the attribute belongs to the device's code object
   const int lds = DMA ? 2 * H.lds_bytes : H.lds_bytes;
-  if (lds > attr_lds && !g_dry_run) {
-    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
+  if (!g_dry_run) {
+    int dev = 0;
+    SRGANFD_HIP_CHECK(hipGetDevice(&dev));
+    if (lds > attr_lds[dev & 63]) {
+      SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_lds[dev & 63] = lds;
+    }
   }
   SRGANFD_LAUNCH(kern, dim3(H.S * H.ngroups), dim3(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))), lds, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
@@ -577,7 +581,7 @@ static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
 template <typename T, int KS, int STRIDE, int XP, int YP>
 static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
-    if (H.dma_ok && !(g_debug & 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
+    if (H.dma_ok && !SRGANFD_DBG(g_debug, 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
   }
   return launch_wgrad3<T, KS, STRIDE, XP, YP, false>(H, k, stream);
 }
@@ -605,7 +609,7 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.x_ps = x.planar ? 32 : x.cstride; k.x_gs = x.planar ? H.Hin * H.Win * 32 : 32;
   k.dy_ps = dy.planar ? 32 : dy.cstride; k.dy_gs = dy.planar ? H.Hout * H.Wout * 32 : 32;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
-  k.dbg = g_debug; k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
+  k.dbg = SRGANFD_DBG(g_debug, ~0); k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
   const bool bf = H.dtype == SRGANFD_BF16;
   if (H.ks == 3 && H.stride == 1) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);

@@ -11,11 +11,11 @@ import torch
 
 from . import _abi as A
 
-DT = {torch.bfloat16: A.BF16, torch.float32: A.F32}
+DT = {torch.bfloat16: A.BF16, torch.float32: A.F32, torch.float16: A.F16}
 
 
 def esize(dtype_code: int) -> int:
-    return 2 if dtype_code == A.BF16 else 4
+    return 4 if dtype_code == A.F32 else 2
 
 
 def struct_array_to_device(arr, device) -> torch.Tensor:
@@ -115,11 +115,11 @@ class WgradPlan:
             w.alpha, w.beta, w.alpha_off = c.get("alpha", 1.0), c.get("beta", 0.0), c.get("alpha_off", -1)
         ho, wo = s.h_out, s.w_out
         self.flops = sum(2.0 * n * ho * wo * ksize * ksize * c["co_dst"] * c["ci_dst"] for c in convs)
-        es = 2 if dtype == A.BF16 else 4
+        es = 4 if dtype == A.F32 else 2
         # algorithmic bytes: x and dy read once, fp32 gradients written once
         self.nbytes = float(n * h_in * w_in * x_channels * es + n * ho * wo * dy_channels * es
                             + sum(4.0 * ksize * ksize * c["co_dst"] * c["ci_dst"] for c in convs))
-        self.label = f"wgrad_kernel<{'bf16' if dtype == A.BF16 else 'f32'},KS={ksize},S={stride}>+reduce"
+        self.label = f"wgrad_kernel<{A.DT_NAME[dtype]},KS={ksize},S={stride}>+reduce"
         L = A.lib()
         nbytes = L.srganfd_wgrad_plan_bytes(C.byref(s), carr)
         if nbytes == 0:

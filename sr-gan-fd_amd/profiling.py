@@ -54,16 +54,15 @@ def disable() -> None:
 
 
 def conv_label(a) -> str:
-    """kernel template the launch dispatches to (conv_igemm.hip: dispatch_conv)"""
-    dt = "bf16" if a.dtype == 0 else "f32"
-    wide = a.cout % 64 == 0
-    if a.ksize in (3, 2):
-        mr, wr, wn = (2, 4, 2) if wide else (2, 8, 1)
-    elif a.ksize == 4:
-        mr, wr, wn = (1, 4, 2) if (wide and a.dtype == 0) else (1, 4, 1)
-    else:
-        mr, wr, wn = 2, 4, 1
-    return f"conv_igemm_kernel<{dt},KS={a.ksize},S={a.stride},MR={mr},WR={wr},WN={wn}>"
+    """kernel template the launch dispatches to (asked from the library: srganfd_conv2d_describe)"""
+    lab = getattr(a, "_kernel_label", None)      # launch structs live in the engines' plans: ask once
+    if lab is None:
+        import ctypes as C
+        from . import _abi as A
+        buf = C.create_string_buffer(160)
+        A.check(A.lib().srganfd_conv2d_describe(C.byref(a), buf, 160), "conv2d_describe")
+        lab = a._kernel_label = buf.value.decode()
+    return lab
 
 
 def conv_flops(a) -> float:
@@ -74,7 +73,7 @@ def conv_work(a) -> tuple:
     """(algorithmic FLOP, algorithmic bytes) of one fused-conv launch: every input pixel's cin channels read once, every
     output pixel's cout_store channels written once, plus the epilogue tensors (residuals, mask read; pre-skip copy
     written); weights are negligible.  Element size 2 (bf16) / 4 (f32; also the fp32 SR / logits outputs)."""
-    es = 2 if a.dtype == 0 else 4
+    es = 4 if a.dtype == 1 else 2
     pin = a.n * a.h_in * a.w_in * a.cin * es
     pout = a.n * a.h_out * a.w_out * a.cout_store
     nb = pin + pout * (4 if a.y_f32 else es)

@@ -14,8 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_header_symbol():
     from sr_gan_fd_amd import _abi as A
     hdr = open(os.path.join(ROOT, "include", "srganfd.h")).read()
-    declared = set(re.findall(r"\b(srganfd_[a-z0-9_]+)\s*\(", hdr))
+    # declarations inside `#ifdef SRGANFD_EXPERIMENT` belong to the timing-experiment builds only (tools/build_variant.sh)
+    experiment = re.findall(r"#ifdef SRGANFD_EXPERIMENT(.*?)#endif", hdr, re.S)
+    product_hdr = re.sub(r"#ifdef SRGANFD_EXPERIMENT.*?#endif", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(srganfd_[a-z0-9_]+)\s*\(", product_hdr))
     lib = C.CDLL(A.LIB_PATH)
+    for name in re.findall(r"\b(srganfd_[a-z0-9_]+)\s*\(", " ".join(experiment)):
+        assert not hasattr(lib, name), f"{name} (experiment hook) must not be exported by the product library"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/srganfd.h but not exported"
     assert declared == set(A.SYMBOLS), f"binding/header mismatch: {declared ^ set(A.SYMBOLS)}"

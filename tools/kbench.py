@@ -1,60 +1,69 @@
-"""Micro-benchmark single fused-conv launches (layout / shape experiments).  python tools/kbench.py [--quick|--batch|--chain] [--dbg N] [--planar]"""
-import sys, time, torch
+"""Micro-benchmark single fused-conv launches, every kernel choice interleaved in ONE process (cdna guide rule 24).
+
+    python tools/kbench.py [--modes 0,1,2,3] [--rounds 5] [--reps 20] [--dtype bf16|f16] [--nhwc]
+
+mode 0 = conv_igemm tiles, 1.. = conv3x3_ring configurations (srganfd_set_ring_mode).  Shapes = the dense-block launches of
+BASELINE configs[1] (B=32, 128x128, planar 192-channel buffers) plus the 64->64 tail conv at 512x512."""
+import sys, torch
 sys.path.insert(0, '.')
-from sr_gan_fd_amd import _abi as A, ops
-
-PLANAR = 1 if "--planar" in sys.argv else 0     # operand buffers as planar 32-channel groups (srganfd_view.planar)
+from sr_gan_fd_amd import _abi as A, ops, profiling
 
 
-def run(name, n, h, w, cin, cout, xC, x0, yC, y0, reps=30, mask=False, dt=torch.bfloat16):
-    dtc = ops.DT[dt]
-    x = torch.randn(n, h, w, xC, device='cuda').to(dt)
-    y = torch.empty(n, h, w, yC, device='cuda', dtype=dt)
+def arg(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
+PLANAR = 0 if "--nhwc" in sys.argv else 1
+MODES = [int(m) for m in arg("--modes", "0,1,2,3").split(",")]
+ROUNDS, REPS = int(arg("--rounds", "5")), int(arg("--reps", "20"))
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}[arg("--dtype", "bf16")]
+
+
+def make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask=False, res=False):
+    dtc = ops.DT[DT]
+    x = (torch.randn(n, h, w, xC, device='cuda') * 0.5).to(DT)
+    y = torch.empty(n, h, w, yC, device='cuda', dtype=DT)
     wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
     wp = ops.pack_single(wt, dtc)
-    kw = {}
+    kw, keep = {}, [x, y, wp]
     if mask:
-        m = torch.randn(n, h, w, yC, device='cuda').to(dt)
-        kw = dict(mask=A.view(m, c0=y0, planar=PLANAR))
-    a = ops.conv_args(dtc, A.view(x, c0=x0, planar=PLANAR), A.view(y, c0=y0, planar=PLANAR), wp, n, h, w, cin, cout, act=A.ACT_LRELU, **kw)
-    for _ in range(3): ops.conv2d(a)
-    torch.cuda.synchronize()
+        m = torch.randn(n, h, w, yC, device='cuda').to(DT); keep.append(m)
+        kw.update(mask=A.view(m, c0=y0, planar=PLANAR))
+    if res:
+        kw.update(r1=A.view(x, c0=0, planar=PLANAR), r1_scale=1.0, post_scale=0.2)
+    a = ops.conv_args(dtc, A.view(x, c0=x0, planar=PLANAR), A.view(y, c0=y0, planar=PLANAR), wp, n, h, w, cin, cout, act=A.ACT_NONE if res else A.ACT_LRELU, **kw)
+    return name, a, keep, 2.0 * n * h * w * 9 * cin * cout
+
+
+def time_one(a, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): ops.conv2d(a)
+    for _ in range(reps):
+        ops.conv2d(a)
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    fl = 2.0 * n * h * w * 9 * cin * cout
-    print(f"{name:44s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
+    return e0.elapsed_time(e1) * 1e3 / reps
+
 
 if __name__ == "__main__":
-    N = 32
-    if "--dbg" in sys.argv:
-        A.lib().srganfd_set_debug(int(sys.argv[sys.argv.index("--dbg") + 1]))
-    if "--chain" in sys.argv:        # one tile per CU: the latency chain of a single workgroup
-        run("N=8 (1 tile/CU) cin=160 cout=32", 8, 128, 128, 160, 32, 192, 0, 192, 160)
-        run("N=16 (2 tiles/CU) cin=160 cout=32", 16, 128, 128, 160, 32, 192, 0, 192, 160)
-        sys.exit(0)
-    if "--batch" in sys.argv:
-        for n in (4, 8, 16, 32, 64):
-            run(f"N={n} fwd cin=160 cout=32 concat buffer", n, 128, 128, 160, 32, 192, 0, 192, 160)
-            run(f"N={n} cin=192 cout=64 x:192 y:192(next)", n, 128, 128, 192, 64, 192, 0, 192, 0)
-        sys.exit(0)
-    if "--quick" in sys.argv:
-        for cin in (64, 96, 128, 160):
-            run(f"fwd cin={cin} cout=32 concat buffer", N, 128, 128, cin, 32, 192, 0, 192, 64 + (cin - 64))
-        run("dgrad-like cin=192 cout=32 + mask", N, 128, 128, 192, 32, 192, 0, 192, 160, mask=True)
-        run("cin=192 cout=64 x:192 y:192(next)", N, 128, 128, 192, 64, 192, 0, 192, 0)
-        run("cin=64 cout=64 dense 512^2 N=8", 8, 512, 512, 64, 64, 64, 0, 64, 0)
-        sys.exit(0)
-    for cin in (64, 128, 160):
-        run(f"cin={cin} cout=32 x:192ch y:192ch(slice)", N, 128, 128, cin, 32, 192, 0, 192, 160)
-        run(f"cin={cin} cout=32 x:dense y:dense", N, 128, 128, cin, 32, cin, 0, 32, 0)
-        run(f"cin={cin} cout=32 x:192ch y:dense", N, 128, 128, cin, 32, 192, 0, 32, 0)
-        run(f"cin={cin} cout=32 x:dense y:192ch", N, 128, 128, cin, 32, cin, 0, 192, 160)
-    run("cin=192 cout=64 x:192 y:192(next)", N, 128, 128, 192, 64, 192, 0, 192, 0)
-    run("cin=192 cout=64 x:192 y:dense", N, 128, 128, 192, 64, 192, 0, 64, 0)
-    run("cin=64 cout=64 dense (tail-like, 128^2)", N, 128, 128, 64, 64, 64, 0, 64, 0)
-    run("cin=64 cout=64 dense 512^2 N=2", 2, 512, 512, 64, 64, 64, 0, 64, 0)
-    # L2-resident repeat: small problem
-    run("cin=128 cout=32 N=2 (L2-resident)", 2, 128, 128, 128, 32, 192, 0, 192, 160, reps=100)
+    N = int(arg("--batch", "32"))
+    shapes = [make(f"fwd cin={cin} cout=32", N, 128, 128, cin, 32, 192, 0, 192, cin) for cin in (64, 96, 128, 160)]
+    shapes.append(make("dgrad-like cin=192 cout=32 + mask", N, 128, 128, 192, 32, 192, 0, 192, 160, mask=True))
+    shapes.append(make("conv5 cin=192 cout=64 + residual", N, 128, 128, 192, 64, 192, 0, 192, 0, res=True))
+    shapes.append(make("tail cin=64 cout=64 512^2 N=8", 8, 512, 512, 64, 64, 64, 0, 64, 0))
+    L = A.lib()
+    res = {}
+    for rnd in range(ROUNDS + 1):                      # round 0 = warm-up
+        for name, a, keep, fl in shapes:
+            for m in MODES:
+                L.srganfd_set_ring_mode(m)
+                if hasattr(a, "_kernel_label"):
+                    del a._kernel_label
+                lab = profiling.conv_label(a)
+                us = time_one(a, 3 if rnd == 0 else REPS)
+                if rnd:
+                    res.setdefault((name, m, lab, fl), []).append(us)
+    L.srganfd_set_ring_mode(-1)
+    for (name, m, lab, fl), v in res.items():
+        v.sort()
+        med = v[len(v) // 2]
+        print(f"{name:38s} mode {m}: median {med:7.1f} us  min {v[0]:7.1f}  {fl / med / 1e6:7.1f} TFLOP/s   {lab}")
