@@ -7,6 +7,7 @@ namespace srganfd {
 thread_local char g_err[512] = {0};
 int g_dry_run = 0;
 int g_debug = 0;
+unsigned long long* g_stamp_buf = nullptr;
 thread_local char* g_describe = nullptr;
 thread_local size_t g_describe_len = 0;
 int set_err(int code, const char* fmt, ...) {
@@ -85,6 +86,7 @@ const char* srganfd_last_error(void) { return g_err; }
 int srganfd_abi_version(void) { return 1; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 #ifdef SRGANFD_EXPERIMENT
+void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
 void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
 #endif
 

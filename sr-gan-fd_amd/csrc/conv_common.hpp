@@ -29,7 +29,9 @@ struct ConvK {
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
   int act, y_f32, fast_epi;
   int dbg;            // SRGANFD_EXPERIMENT builds only: 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
+  unsigned long long* stamps;   // SRGANFD_EXPERIMENT builds only: s_memtime stamps of the first workgroups (tools/stamps.py), else NULL
 };
+extern unsigned long long* g_stamp_buf;
 
 template <typename T> struct FragAB;
 template <> struct FragAB<bf16_t> { typedef bf16x8 type; };

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
           const int cc = c0 + cch;
           T* dstp = (T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
-            *(u32x4*)dstp = pack8<T>(vv);
+            if (SRGANFD_DBG(a.dbg, 64)) __builtin_nontemporal_store(pack8<T>(vv), (u32x4*)dstp);
+            else *(u32x4*)dstp = pack8<T>(vv);
           } else {
             f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
             *(f32x4*)dstp = o;
@@ -400,11 +401,17 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   return SRGANFD_OK;
 }
 
+int g_igemm_variant = 0;
+
 template <typename T>
 static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t s) {
   const bool wide = (a->cout % 64) == 0;
   constexpr bool bf = sizeof(T) == 2;
   if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
+    if constexpr (bf) {
+      if (a->ksize == 3 && g_igemm_variant == 7)   // experiment: 4 rows per wave (0.75 fragment reads per MFMA), register staging
+        return wide ? launch_conv<T, 3, 1, 4, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 4, 4, 1>(k, a->cout, s);
+    }
     if (a->ksize == 3) return wide ? launch_conv<T, 3, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1>(k, a->cout, s);
     return wide ? launch_conv<T, 2, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1>(k, a->cout, s);
   }
@@ -473,9 +480,9 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;
   auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
 #ifdef SRGANFD_EXPERIMENT
-  k.dbg = g_debug;
+  k.dbg = g_debug; k.stamps = g_stamp_buf;
 #else
-  k.dbg = 0;
+  k.dbg = 0; k.stamps = nullptr;
 #endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   {
