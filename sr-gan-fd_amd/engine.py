@@ -63,8 +63,7 @@ class FlatParams:
         self.total = off
         self.index = {n: i for i, n in enumerate(self.names)}
         self.flat: Optional[Tensor] = None
-        self.version = -1                      # bumped by whoever writes the flat buffer
-        self._seen = None
+        self.version = 0                       # bumped by whoever writes the flat buffer behind autograd's back (touch())
 
     def off(self, name: str) -> int:
         return self.offsets[self.index[name]]
@@ -86,14 +85,24 @@ class FlatParams:
                     f[o:o + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
                     p.data = f[o:o + n].view(s)
             self.flat = f
-            self._seen = None
+            self.version += 1
         return f
 
-    def changed(self) -> bool:
-        """True if parameter values may differ from the last call (uses tensor version counters)."""
-        sig = (self.flat.data_ptr(), self.flat._version, tuple(p._version for p in self.params))
-        if sig != self._seen:
-            self._seen = sig
+    def touch(self) -> None:
+        """The flat buffer was written by a kernel (fused Adam): every packed copy, of every compute dtype, is stale."""
+        self.version += 1
+
+    def signature(self) -> tuple:
+        """Identity of the current parameter VALUES (tensor version counters + touch() count)."""
+        return (self.flat.data_ptr(), self.flat._version, self.version, tuple(p._version for p in self.params))
+
+    def stale(self, pk: dict) -> bool:
+        """True if the packed-weight record `pk` (one per compute dtype) was packed from other values; marks it fresh.
+        The signature is kept PER PACK: with one shared marker, the first forward in dtype A after an optimizer step consumed the
+        change and a following forward in dtype B ran on weights from before the step."""
+        sig = self.signature()
+        if pk.get("seen") != sig:
+            pk["seen"] = sig
             return True
         return False
 
@@ -115,6 +124,44 @@ class FlatParams:
 class _Shape:
     """Per-(N,H,W,training) buffers and pre-built launch lists."""
     pass
+
+
+class PlanCache:
+    """Per-shape plans, least-recently-used eviction.  Training plans are pinned (at most two are kept): a validation sweep over
+    many image sizes (inference.py / validate()) evicts only other inference plans, never the multi-GB training
+    plan of the step it runs between -- the earlier `clear()` on overflow dropped everything."""
+
+    def __init__(self, cap: int = 8, cap_pinned: int = 2):
+        from collections import OrderedDict
+        self.d: "OrderedDict[tuple, tuple]" = OrderedDict()
+        self.cap, self.cap_pinned = cap, cap_pinned
+
+    def get(self, key):
+        v = self.d.get(key)
+        if v is None:
+            return None
+        self.d.move_to_end(key)
+        return v[0]
+
+    def put(self, key, sp, pinned: bool = False) -> None:
+        self.d[key] = (sp, pinned)
+        self.d.move_to_end(key)
+        for want_pinned, cap in ((False, self.cap), (True, self.cap_pinned)):
+            keys = [k for k, (_, pin) in self.d.items() if pin == want_pinned]
+            for k in keys[:max(0, len(keys) - cap)]:
+                del self.d[k]
+
+    def __setitem__(self, key, sp) -> None:
+        self.put(key, sp)
+
+    def __len__(self) -> int:
+        return len(self.d)
+
+    def __contains__(self, key) -> bool:
+        return key in self.d
+
+    def clear(self) -> None:
+        self.d.clear()
 
 
 class TrunkEngine:
@@ -141,7 +188,7 @@ class TrunkEngine:
             self.in_ch = owner.conv1.weight.shape[1]
             self.out_ch = owner.conv4.weight.shape[0]
         self.fp = FlatParams(list(owner.named_parameters()))
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
         self._rdb_prefix = self._find_prefixes()
@@ -210,19 +257,17 @@ class TrunkEngine:
             pk = self._build_pack(dtc, device)
             pk["flat_ptr"] = flat.data_ptr()
             self.packed[dtc] = pk
-            self.fp._seen = None
-        if self.fp.changed():
+        if self.fp.stale(pk):
             pk["table"].run(flat, pk["buf"])
         return pk
 
     # -- per-shape plan -----------------------------------------------------------------------
     def _plan(self, N: int, H: int, W: int, dt: torch.dtype, dtc: int, device, train: bool, pk: dict) -> _Shape:
-        key = (N, H, W, dtc, train, str(device), pk["buf"].data_ptr())
+        # the launch lists bake absolute pointers into the packed buffer AND the flat parameter buffer (biases): both are in the key
+        key = (N, H, W, dtc, train, str(device), pk["buf"].data_ptr(), self.fp.flat.data_ptr())
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 8:
-            self.shapes.clear()
         sp = _Shape()
         Cc, G, Ccat, R = self.Cc, self.G, self.Ccat, self.R
         flat = self.fp.flat
@@ -290,7 +335,7 @@ class TrunkEngine:
         sp.N, sp.H, sp.W, sp.dt, sp.dtc, sp.device = N, H, W, dt, dtc, device
         if train:
             self._plan_backward(sp, pk)
-        self.shapes[key] = sp
+        self.shapes.put(key, sp, pinned=train)
         return sp
 
     def _plan_backward(self, sp: _Shape, pk: dict) -> None:

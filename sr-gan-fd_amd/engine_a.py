@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from . import _abi as A
 from . import ops
 from . import profiling
-from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape
+from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape, PlanCache
 
 # (name, ksize, stride, pad) of the spectral-normalised convs, in forward order
 SN_LAYERS = [("conv1", 3, 2, 1), ("conv2", 3, 2, 1), ("conv3", 3, 2, 1), ("gating", 1, 1, 1), ("cat_1.convU", 3, 1, 1),
@@ -49,7 +49,7 @@ class AesrganDiscriminatorEngine:
         self.in_ch = owner.conv0.weight.shape[1]
         if self.nf != 64:
             raise A.SrganfdError("UNetDiscriminatorAesrgan: num_feat must be 64 (channel counts are multiples of 32, BatchNorm <= 256 channels)")
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
 
@@ -127,12 +127,10 @@ class AesrganDiscriminatorEngine:
 
     # ---- plan ----
     def _plan(self, N, H, W, dt, dtc, device, pk):
-        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr())
+        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr(), self.fp.flat.data_ptr())
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 4:
-            self.shapes.clear()
         if H % 8 or W % 8:
             raise A.SrganfdError("UNetDiscriminatorAesrgan input height/width must be multiples of 8")
         sp = _Shape()

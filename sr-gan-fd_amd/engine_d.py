@@ -23,7 +23,7 @@ from torch import Tensor, nn
 from . import _abi as A
 from . import ops
 from . import profiling
-from .engine import FlatParams, _ENGINES, _dt, _engine, _require_gpu, _Shape
+from .engine import FlatParams, _ENGINES, _dt, _engine, _require_gpu, _Shape, PlanCache
 
 SN_LAYERS = [("down_block1", 4, 2), ("down_block2", 4, 2), ("down_block3", 4, 2), ("up_block1", 3, 1),
              ("up_block2", 3, 1), ("up_block3", 3, 1), ("conv2", 3, 1), ("conv3", 3, 1)]
@@ -43,7 +43,7 @@ class DiscriminatorEngine:
         for name, k, s in SN_LAYERS:
             w = getattr(owner, name)[0].weight_orig
             self.dims[name] = (w.shape[0], w.shape[1], k, s)
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
 
@@ -103,12 +103,10 @@ class DiscriminatorEngine:
 
     # ---- per-shape plan ----
     def _plan(self, N, S1, S2, dt, dtc, device, pk) -> _Shape:
-        key = (N, S1, S2, dtc, str(device), pk["buf"].data_ptr())
+        key = (N, S1, S2, dtc, str(device), pk["buf"].data_ptr(), self.fp.flat.data_ptr())
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 4:
-            self.shapes.clear()
         if S1 % 8 or S2 % 8:
             raise A.SrganfdError("DiscriminatorUNet input height/width must be multiples of 8")
         sp = _Shape()
@@ -357,7 +355,7 @@ class ContentLossEngine:
         self.pools = [int(n) for n, m in owner.features.named_children() if isinstance(m, nn.MaxPool2d)]
         self.fp = FlatParams([(f"features.{i}.{k}", getattr(m, k)) for i, m in self.convs for k in ("weight", "bias")])
         self.want = [int(n.split(".")[1]) for n in owner.feature_model_extractor_nodes]
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
 
     def _ensure_packed(self, dtc, device):
@@ -373,8 +371,7 @@ class ContentLossEngine:
                 cur += (ops.packed_bytes(dtc, 3, ops.pad32(ci), co) + 255) // 256 * 256
             pk = dict(table=ops.PackTable(jobs, device), offs=offs, buf=torch.empty(cur, dtype=torch.uint8, device=device), flat_ptr=flat.data_ptr())
             self.packed[dtc] = pk
-            self.fp._seen = None
-        if self.fp.changed():
+        if self.fp.stale(pk):
             pk["table"].run(flat, pk["buf"])
         return pk
 
@@ -387,11 +384,9 @@ class ContentLossEngine:
         if H < 16 or W < 16:
             raise A.SrganfdError("ContentLoss input height/width must be at least 16 (four 2x2 max-pools; odd sizes floor like torch)")
         L, st = A.lib(), A.stream_ptr()
-        key = (N, H, W, dtc, str(dev), pk["buf"].data_ptr())
+        key = (N, H, W, dtc, str(dev), pk["buf"].data_ptr(), self.fp.flat.data_ptr())
         sp = self.shapes.get(key)
         if sp is None:
-            if len(self.shapes) > 4:
-                self.shapes.clear()
             sp = _Shape()
             sp.xin = torch.empty(2 * N, H, W, 32, dtype=dt, device=dev)
             sp.bufs = {}

@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from . import _abi as A
 from . import ops
 from . import profiling
-from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape
+from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape, PlanCache
 
 CONV_IDX = (0, 2, 5, 8, 11, 14, 17, 20, 23, 26)          # positions of the convs inside `features`
 SLOPE = 0.2
@@ -44,7 +44,7 @@ class EsrganDiscriminatorEngine:
             raise A.SrganfdError("Discriminator: unexpected layer sizes (ESRGAN/model.py:88-141)")
         self.hid = owner.classifier[0].out_features            # 100
         self.hid_pad = ops.pad32(self.hid)
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
 
@@ -88,12 +88,10 @@ class EsrganDiscriminatorEngine:
     # ---- per-shape plan ----
     def _plan(self, N, H, W, dt, dtc, device, pk):
         self._fw_count = getattr(self, "_fw_count", 0) + 1
-        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr(), self._fw_count % RING)
+        key = (N, H, W, dtc, str(device), pk["buf"].data_ptr(), self.fp.flat.data_ptr(), self._fw_count % RING)
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 4 * RING:
-            self.shapes.clear()
         if H != 128 or W != 128:
             raise A.SrganfdError("Discriminator expects 3x128x128 inputs: its classifier is Linear(512*4*4, 100) (ESRGAN/model.py:129)")
         sp = _Shape()

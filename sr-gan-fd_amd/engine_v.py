@@ -18,7 +18,7 @@ from torch import Tensor, nn
 from . import _abi as A
 from . import ops
 from . import profiling
-from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape
+from .engine import FlatParams, _dt, _engine, _require_gpu, _Shape, PlanCache
 
 
 class ContentLossGradEngine:
@@ -30,7 +30,7 @@ class ContentLossGradEngine:
             raise A.SrganfdError("differentiable ContentLoss: the node must be a conv of vgg19.features (esrgan_config uses features.34)")
         self.convs = [(i, feats[i]) for i in range(self.last + 1) if isinstance(feats[i], nn.Conv2d)]
         self.fp = FlatParams([(f"features.{i}.{k}", getattr(m, k)) for i, m in self.convs for k in ("weight", "bias")])
-        self.shapes: Dict[tuple, _Shape] = {}
+        self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
 
@@ -50,18 +50,15 @@ class ContentLossGradEngine:
                     cur += (ops.packed_bytes(dtc, 3, k, n) + 255) // 256 * 256
             pk = dict(table=ops.PackTable(jobs, device), offs=offs, buf=torch.empty(cur, dtype=torch.uint8, device=device), flat_ptr=flat.data_ptr())
             self.packed[dtc] = pk
-            self.fp._seen = None
-        if self.fp.changed():
+        if self.fp.stale(pk):
             pk["table"].run(flat, pk["buf"])
         return pk
 
     def _plan(self, N, H, W, dt, dtc, dev, pk):
-        key = (N, H, W, dtc, str(dev), pk["buf"].data_ptr())
+        key = (N, H, W, dtc, str(dev), pk["buf"].data_ptr(), self.fp.flat.data_ptr())
         sp = self.shapes.get(key)
         if sp is not None:
             return sp
-        if len(self.shapes) > 4:
-            self.shapes.clear()
         sp = _Shape()
         sp.N, sp.H, sp.W, sp.dt, sp.dtc, sp.device = N, H, W, dt, dtc, dev
         es = torch.empty(0, dtype=dt).element_size()

@@ -37,9 +37,12 @@ class GanTrainer:
         self.ge, self.de = generator_engine(g_model), d_engine(d_model)
         dev = next(g_model.parameters()).device
         self.dev = dev
-        self.g_opt = FlatAdamEMA(self.ge.fp.sync(dev), g_lr, betas, eps, weight_decay, ema_decay)
-        self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None)
+        self.g_opt = FlatAdamEMA(self.ge.fp.sync(dev), g_lr, betas, eps, weight_decay, ema_decay, layout=self.ge.fp)
+        self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None, layout=self.de.fp)
         self.pw, self.cw, self.aw = pixel_weight, content_weight, adversarial_weight
+        # per-node content weights (Real-ESRGAN's list): built once -- a host list turned into a device tensor inside step() is a
+        # host->device copy per iteration and cannot be captured into a graph
+        self._cw_t = None if isinstance(content_weight, (int, float)) else torch.tensor(list(content_weight), dtype=torch.float32, device=dev)
         self.train_generator = train_generator
         self.generator_first = generator_first
         self.pg = process_group
@@ -59,6 +62,29 @@ class GanTrainer:
     def _allreduce(self, grad: Tensor) -> float:
         return allreduce_sum_(grad, self.pg)
 
+    def state_dict(self) -> dict:
+        """Trainer-side entries of the reference's two checkpoint files (train_bsrgan.py:203-260: d_*.pth.tar holds the
+        discriminator + its optimizer, g_*.pth.tar the generator + optimizer + EMA), keyed "g" / "d"."""
+        g = {"state_dict": self.g.state_dict(), "optimizer": self.g_opt.state_dict()}
+        if self.g_opt.ema is not None:
+            g["ema_state_dict"] = self.g_opt.ema_state_dict()
+        return {"g": g, "d": {"state_dict": self.d.state_dict(), "optimizer": self.d_opt.state_dict()}}
+
+    def load_state_dict(self, ckpt: dict) -> None:
+        with torch.no_grad():
+            for net, eng, opt, c in ((self.g, self.ge, self.g_opt, ckpt.get("g")), (self.d, self.de, self.d_opt, ckpt.get("d"))):
+                if c is None:
+                    continue
+                own = net.state_dict()
+                for k, v in c["state_dict"].items():        # spectral-norm u / v buffers included
+                    if k in own and tuple(own[k].shape) == tuple(v.shape):
+                        own[k].copy_(v)
+                eng.fp.touch()
+                if "optimizer" in c:
+                    opt.load_state_dict(c["optimizer"])
+                if "ema_state_dict" in c and opt.ema is not None:
+                    opt.load_ema_state_dict(c["ema_state_dict"])
+
     def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
         s = self.scalars.data_ptr()
         A.check(A.lib().srganfd_bce_logits(logits.data_ptr(), logits.numel(), target, weight, s + 4 * slot, 0,
@@ -67,7 +93,7 @@ class GanTrainer:
 
     def _content(self, sr: Tensor, gt: Tensor) -> None:
         if self.content is not None:
-            cw = self.cw if isinstance(self.cw, (int, float)) else torch.tensor(list(self.cw), dtype=torch.float32, device=self.dev)
+            cw = self.cw if self._cw_t is None else self._cw_t
             self.content_vals = self.content(sr, gt) * cw      # per-node weights broadcast over the (1, nodes) tensor
 
     def _step_generator_first(self, lr_img: Tensor, gt: Tensor, gt_usm: Optional[Tensor]) -> Tensor:
@@ -93,7 +119,7 @@ class GanTrainer:
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             gg, _ = ge.backward(g_sp, g_tok, dsr, False)
             self.g_opt.step(gg, self._allreduce(gg))
-            ge.fp._seen = None
+            ge.fp.touch()
         s = self.scalars.data_ptr()
         gt_out = de.forward(gt, True)
         self._bce(gt_out, 1.0, 1.0, 0, None, dl)
@@ -143,6 +169,6 @@ class GanTrainer:
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             gg, _ = ge.backward(g_sp, g_tok, dsr, False)
             self.g_opt.step(gg, self._allreduce(gg))
-            ge.fp._seen = None
+            ge.fp.touch()
         self.sr = sr
         return self.scalars

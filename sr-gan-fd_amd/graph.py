@@ -31,23 +31,40 @@ class GraphedStep:
                 trainer.step(self.lr, self.gt)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._capture()
+
+    def _opts(self):
+        return [o for o in (getattr(self.trainer, "opt", None), getattr(self.trainer, "g_opt", None), getattr(self.trainer, "d_opt", None)) if o is not None]
+
+    def _capture(self) -> None:
+        """Kernel arguments are frozen at capture: learning rate, betas, eps and the loss weights are by-value arguments of the
+        Adam / loss kernels (only the step count lives in device memory).  They are recorded here and checked at every replay;
+        a change (the reference steps MultiStepLR every epoch, train_bsrgan.py:193-195) re-captures the graph."""
+        opts = self._opts()
+        before = [(o.t, o.n_averaged) for o in opts]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = trainer.step(self.lr, self.gt)
-        # the host-side counters advanced once during capture although nothing ran: undo
-        for opt in (getattr(trainer, "opt", None), getattr(trainer, "g_opt", None), getattr(trainer, "d_opt", None)):
-            if opt is not None:
-                opt.t -= 1
-                if opt.ema is not None:
-                    opt.n_averaged -= 1
+            self.out = self.trainer.step(self.lr, self.gt)
+        # the host-side counters advanced during capture although nothing ran: undo exactly what moved (an optimizer that
+        # did not step -- train_generator=False -- keeps its counters)
+        self._delta = []
+        for o, (t0, n0) in zip(opts, before):
+            self._delta.append((o.t - t0, o.n_averaged - n0))
+            o.t, o.n_averaged = t0, n0
+        self._frozen = self._hyper()
+
+    def _hyper(self):
+        tr = self.trainer
+        return ([(o.lr, tuple(o.betas), o.eps, o.wd, o.ema_decay) for o in self._opts()],
+                tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")))
 
     def __call__(self, lr_img: Tensor, gt: Tensor) -> Tensor:
+        if self._hyper() != self._frozen:
+            self._capture()
         self.lr.copy_(lr_img)
         self.gt.copy_(gt)
         self.graph.replay()
-        for opt in (getattr(self.trainer, "opt", None), getattr(self.trainer, "g_opt", None), getattr(self.trainer, "d_opt", None)):
-            if opt is not None:
-                opt.t += 1
-                if opt.ema is not None:
-                    opt.n_averaged += 1
+        for o, (dt, dn) in zip(self._opts(), self._delta):
+            o.t += dt
+            o.n_averaged += dn
         return self.out

@@ -138,8 +138,8 @@ class DiscriminatorUNet(nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, channels: int, upsample_method: str = "bilinear") -> None:
         super().__init__()
-        if upsample_method != "bilinear":
-            raise ValueError(f"DiscriminatorUNet: only the reference's default upsample_method='bilinear' has a HIP path (got {upsample_method!r})")
+        # stored and never read, exactly as the reference does (BSRGAN/model.py:97-100): its forward hard-codes
+        # F.interpolate(..., mode="bilinear") at :150,154,158 whatever this says, and so does the HIP path
         self.upsample_method = upsample_method
         self.conv1 = nn.Conv2d(in_channels, 64, (3, 3), (1, 1), (1, 1))
 

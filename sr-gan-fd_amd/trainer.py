@@ -27,7 +27,10 @@ class FlatAdamEMA:
     """torch.optim.Adam maths (amsgrad=False) + AveragedModel(avg_fn=(1-d)*ema + d*p) over one flat buffer."""
 
     def __init__(self, flat: Tensor, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float = 0.0,
-                 ema_decay: Optional[float] = None):
+                 ema_decay: Optional[float] = None, layout=None):
+        """``layout``: the engine's FlatParams (names / offsets / shapes of the tensors inside ``flat``); needed only by
+        state_dict() / load_state_dict(), which speak the reference checkpoint's per-parameter format."""
+        self.layout = layout
         self.flat = flat
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
@@ -44,7 +47,76 @@ class FlatAdamEMA:
             self.step_dev = torch.tensor([self.t], dtype=torch.int32, device=self.flat.device)
             self.bc_dev = torch.zeros(2, dtype=torch.float32, device=self.flat.device)
 
+    # -- checkpoints in the reference's format (train_bsrnet.py:124-130: {"optimizer": Adam.state_dict(), "ema_state_dict": ...}) --
+    def _views(self, buf: Tensor):
+        lay = self.layout
+        if lay is None:
+            raise A.SrganfdError("FlatAdamEMA: state_dict needs the parameter layout (pass layout=engine.fp)")
+        return [buf[o:o + n].view(s) for o, n, s in zip(lay.offsets, lay.numels, lay.shapes)]
+
+    def state_dict(self) -> dict:
+        """What ``torch.optim.Adam(module.parameters(), ...).state_dict()`` holds after the same steps: per parameter (in
+        named_parameters() order) ``step`` / ``exp_avg`` / ``exp_avg_sq``, and one param group."""
+        m, v = self._views(self.m), self._views(self.v)
+        state = {}
+        if self.t > 0:
+            state = {i: {"step": torch.tensor(float(self.t)), "exp_avg": m[i].detach().clone(), "exp_avg_sq": v[i].detach().clone()}
+                     for i in range(len(m))}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(m)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Accepts a checkpoint's ``optimizer`` entry written by torch.optim.Adam over the same module (or by state_dict() above).
+        Restores moments, step count (host and, if in use, device copy) and the hyper-parameters of the param group."""
+        m, v = self._views(self.m), self._views(self.v)
+        st = sd.get("state", {})
+        if len(st) not in (0, len(m)):
+            raise A.SrganfdError(f"optimizer state holds {len(st)} parameters, the module has {len(m)}")
+        steps = set()
+        with torch.no_grad():
+            self.m.zero_()
+            self.v.zero_()
+            for i in range(len(m)):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    continue
+                m[i].copy_(e["exp_avg"].reshape(m[i].shape))
+                v[i].copy_(e["exp_avg_sq"].reshape(v[i].shape))
+                steps.add(int(float(e["step"])))
+        if len(steps) > 1:
+            raise A.SrganfdError(f"parameters carry different step counts {sorted(steps)}: not a state the fused optimizer can resume")
+        self.t = steps.pop() if steps else 0
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.t)
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g.get("weight_decay", 0.0))
+
+    def ema_state_dict(self) -> dict:
+        """``AveragedModel(module).state_dict()`` layout (torch/optim/swa_utils.py): ``module.<name>`` tensors + ``n_averaged``."""
+        if self.ema is None:
+            raise A.SrganfdError("this optimizer keeps no EMA copy")
+        out = {"n_averaged": torch.tensor(self.n_averaged, dtype=torch.long)}
+        src = self._views(self.ema if self.n_averaged > 0 else self.flat)      # AveragedModel starts as a deep copy of the module
+        for name, t in zip(self.layout.names, src):
+            out["module." + name] = t.detach().clone()
+        return out
+
+    def load_ema_state_dict(self, sd: dict) -> None:
+        if self.ema is None:
+            raise A.SrganfdError("this optimizer keeps no EMA copy")
+        dst = self._views(self.ema)
+        with torch.no_grad():
+            for name, t in zip(self.layout.names, dst):
+                src = sd.get("module." + name)
+                if src is not None and tuple(src.shape) == tuple(t.shape):
+                    t.copy_(src)
+        self.n_averaged = int(sd.get("n_averaged", 0))
+
     def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True) -> None:
+        if self.layout is not None and self.layout.flat is not self.flat:
+            raise A.SrganfdError("the module's flat parameter buffer was rebuilt (.to() / deepcopy) after this optimizer captured it: "
+                                 "build the trainer after moving the module")
         self.t += 1
         mode = 0
         if self.ema is not None and update_ema:
@@ -71,12 +143,33 @@ class GeneratorTrainer:
         self.eng = generator_engine(g_model)
         dev = next(g_model.parameters()).device
         self.flat = self.eng.fp.sync(dev)
-        self.opt = FlatAdamEMA(self.flat, lr, betas, eps, weight_decay, ema_decay)
+        self.opt = FlatAdamEMA(self.flat, lr, betas, eps, weight_decay, ema_decay, layout=self.eng.fp)
         self.loss_weight = loss_weight
         self.pg = process_group
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
         self.dsr: Optional[Tensor] = None
+
+    def state_dict(self) -> dict:
+        """The entries of the reference's checkpoint that belong to the trainer (train_bsrnet.py:124-130)."""
+        out = {"state_dict": self.g.state_dict(), "optimizer": self.opt.state_dict()}
+        if self.opt.ema is not None:
+            out["ema_state_dict"] = self.opt.ema_state_dict()
+        return out
+
+    def load_state_dict(self, ckpt: dict) -> None:
+        """Resume from a checkpoint written by the reference's train script or by state_dict(): weights (in place, into the
+        flat buffer), Adam moments + step, EMA copy + n_averaged."""
+        with torch.no_grad():
+            own = self.g.state_dict()
+            for k, v in ckpt["state_dict"].items():
+                if k in own and tuple(own[k].shape) == tuple(v.shape):
+                    own[k].copy_(v)
+        self.eng.fp.touch()
+        if "optimizer" in ckpt:
+            self.opt.load_state_dict(ckpt["optimizer"])
+        if "ema_state_dict" in ckpt and self.opt.ema is not None:
+            self.opt.load_ema_state_dict(ckpt["ema_state_dict"])
 
     def step(self, lr_img: Tensor, gt: Tensor) -> Tensor:
         """Returns the (device, 1-element) loss tensor; no host sync inside."""
@@ -91,6 +184,6 @@ class GeneratorTrainer:
         grad, _ = eng.backward(sp, token, self.dsr, False)
         scale = allreduce_sum_(grad, self.pg)          # RCCL over xGMI: ONE flat 67 MB buffer per step
         self.opt.step(grad, scale)
-        eng.fp._seen = None                             # parameters changed behind autograd's back -> re-pack
+        eng.fp.touch()                             # parameters changed behind autograd's back -> re-pack
         self.sr = sr
         return self.loss_buf

@@ -253,3 +253,68 @@ def test_planar_dense_block_buffers_change_nothing_but_the_addresses(monkeypatch
         res[flag] = (losses, tr.sr.clone(), tr.opt.flat.clone())
     assert all(torch.equal(a, b) for a, b in zip(res["1"][0], res["0"][0]))
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+
+
+@pytest.mark.parametrize("name,fac,kw,B,h,lr,eps", [
+    ("esrgan_small", "rrdbnet_x4", dict(num_blocks=2), 2, 16, 2e-4, 1e-8),        # ESRGAN/rrdbnet_config.py:68-78
+    ("bsrnet_small", "bsrgan_x4", dict(num_rrdb=2), 2, 16, 1e-4, 1e-4),           # BSRGAN/bsrnet_config.py:86-96
+    ("cfg1_esrgan_b4_32", "rrdbnet_x4", dict(num_blocks=23), 4, 32, 2e-4, 1e-8),  # BASELINE.json configs[0]: batch 4, 32 -> 128, 23 RRDB
+])
+def test_g_only_steps(golden_dir, name, fac, kw, B, h, lr, eps):
+    """trainer.GeneratorTrainer.step == two iterations of ESRGAN/train_rrdbnet.py:244-267 / BSRGAN/train_bsrnet.py:244-272 run on
+    the reference's own modules with torch.optim.Adam (g_only_steps.npz): loss, SR and per-tensor parameter checksums after each
+    iteration, f32 mode, 1e-3.  The configs[0] inputs are not stored (1.5 MB): they are the next draws of the seeded generator after
+    the module's construction, which this repo's module reproduces draw for draw."""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    g = load_golden(golden_dir, "g_only_steps.npz")
+    torch.manual_seed(0)
+    net = getattr(M, fac)(in_channels=3, out_channels=3, channels=64, growth_channels=32, **kw)
+    scaled_init(net, 3.0, 0.5)
+    net.compute_dtype = torch.float32
+    stored = f"{name}/it0_lr" in g.files
+    draws = [(torch.rand(B, 3, h, h), torch.rand(B, 3, 4 * h, 4 * h)) for _ in range(2)]     # the generator state right after construction
+    net.cuda().train()
+    tr = GeneratorTrainer(net, lr=lr, betas=(0.9, 0.99), eps=eps, ema_decay=None)
+    for it in range(2):
+        x, gt = draws[it]
+        if stored:
+            assert torch.equal(x, torch.tensor(g[f"{name}/it{it}_lr"])) and torch.equal(gt, torch.tensor(g[f"{name}/it{it}_gt"]))
+        loss = tr.step(x.cuda(), gt.cuda()).item()
+        want = float(g[f"{name}/losses"][it])
+        print(f"{name} it{it}: loss {loss:.7f} (reference {want:.7f})")
+        assert abs(loss - want) < 1e-3 * abs(want)
+        if stored:
+            assert _rel(tr.sr, g[f"{name}/it{it}_sr"]) < 1e-3
+        sd = net.state_dict()
+        for k, want_c in table(g, f"{name}/it{it}_wsum").items():
+            assert np.allclose(checksum(sd[k]), want_c, rtol=2e-3, atol=2e-4 * abs(want_c[1])), f"{name} it{it} {k}: {checksum(sd[k])} vs {want_c}"
+    assert _rel(net.conv4.bias, g[f"{name}/conv4_bias"]) < 1e-3
+
+
+def test_packed_weights_follow_updates_in_every_dtype():
+    """Each compute dtype keeps its own packed copy of the weights; after a fused optimizer step EVERY copy is stale, not only the
+    one of the dtype that runs next (a shared 'seen' marker let a bf16 forward run on pre-step weights after an f32 forward
+    had consumed the change)."""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    torch.manual_seed(0)
+    net = M.bsrgan_x4(num_rrdb=1)
+    scaled_init(net, 3.0, 0.5)
+    net.cuda().train()
+    x, gt = torch.rand(1, 3, 16, 16).cuda(), torch.rand(1, 3, 64, 64).cuda()
+
+    def fwd(dt):
+        net.compute_dtype = dt
+        with torch.no_grad():
+            return net(x).clone()
+    b0, f0 = fwd(torch.bfloat16), fwd(torch.float32)
+    net.compute_dtype = torch.float32
+    tr = GeneratorTrainer(net, lr=5e-2, betas=(0.9, 0.99), eps=1e-8, ema_decay=None)     # a step large enough to move SR visibly
+    tr.step(x, gt)
+    f1 = fwd(torch.float32)          # consumes the change for the f32 pack ...
+    b1 = fwd(torch.bfloat16)         # ... the bf16 pack must notice it too
+    moved = (f1 - f0).abs().max().item()
+    assert moved > 5e-2, moved
+    assert (b1 - f1).abs().max().item() < 0.25 * moved, "bf16 forward ran on weights from before the optimizer step"
+    assert (b1 - b0).abs().max().item() > 0.5 * moved

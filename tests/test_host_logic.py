@@ -300,3 +300,63 @@ def test_engines_release_their_buffers_by_reference_counting():
         gc.garbage.clear()
         gc.enable()
         A.set_dry_run(False)
+
+
+def test_fused_optimizer_checkpoint_round_trip(tmp_path):
+    """FlatAdamEMA.state_dict() / load_state_dict() speak torch.optim.Adam's per-parameter format and AveragedModel's
+    ``module.<name>`` + ``n_averaged`` layout (the reference's checkpoint, train_bsrnet.py:124-130): a state written by
+    torch's own classes loads into the flat buffers and comes back identical."""
+    from torch.optim.swa_utils import AveragedModel
+    from sr_gan_fd_amd import model as M, utils
+    from sr_gan_fd_amd.engine import FlatParams
+    from sr_gan_fd_amd.trainer import FlatAdamEMA
+    torch.manual_seed(0)
+    net = M.bsrgan_x4(num_rrdb=1)
+    opt = torch.optim.Adam(net.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+    ema = AveragedModel(net, avg_fn=lambda a, p, n: 0.001 * a + 0.999 * p)
+    for _ in range(3):
+        for p in net.parameters():
+            p.grad = torch.randn_like(p) * 1e-3
+        opt.step()
+        ema.update_parameters(net)
+    path = str(tmp_path / "g_last.pth.tar")
+    torch.save({"epoch": 7, "best_psnr": 1.0, "best_ssim": 2.0, "state_dict": net.state_dict(), "ema_state_dict": ema.state_dict(),
+                "optimizer": opt.state_dict()}, path)
+
+    net2 = M.bsrgan_x4(num_rrdb=1)
+    fp = FlatParams(list(net2.named_parameters()))
+    flat = fp.sync(torch.device("cpu"))
+    fused = FlatAdamEMA(flat, 5e-5, (0.9, 0.999), 1e-8, 0.0, ema_decay=0.999, layout=fp)
+    out = utils.load_state_dict(net2, path, ema_model=fused, optimizer=fused, load_mode="resume")
+    assert out[2] == 7 and fused.t == 3 and fused.n_averaged == 3 and fused.lr == 1e-4 and fused.eps == 1e-4 and fused.betas == (0.9, 0.99)
+    for (k, a), b in zip(net.state_dict().items(), net2.state_dict().values()):
+        assert torch.equal(a, b), k
+    want = opt.state_dict()["state"]
+    got = fused.state_dict()
+    assert got["param_groups"][0]["params"] == list(range(len(want)))
+    for i in want:
+        assert torch.equal(want[i]["exp_avg"], got["state"][i]["exp_avg"]) and torch.equal(want[i]["exp_avg_sq"], got["state"][i]["exp_avg_sq"])
+        assert float(got["state"][i]["step"]) == 3.0
+    for k, v in ema.state_dict().items():
+        assert torch.equal(v, fused.ema_state_dict()[k]), k
+    # and back into torch's own classes (what the reference's resume path does with a file the fused trainer wrote)
+    utils.save_checkpoint(str(tmp_path / "again.pth.tar"), net2, fused, ema=fused, epoch=8)
+    net3 = M.bsrgan_x4(num_rrdb=1)
+    opt3 = torch.optim.Adam(net3.parameters(), 1.0)
+    ema3 = AveragedModel(net3)
+    utils.load_state_dict(net3, str(tmp_path / "again.pth.tar"), ema_model=ema3, optimizer=opt3, load_mode="resume")
+    assert opt3.state_dict()["param_groups"][0]["lr"] == 1e-4
+    for i in want:
+        assert torch.equal(opt3.state_dict()["state"][i]["exp_avg_sq"], want[i]["exp_avg_sq"])
+    assert int(ema3.n_averaged) == 3
+
+
+def test_plan_cache_keeps_training_plan():
+    from sr_gan_fd_amd.engine import PlanCache
+    c = PlanCache(cap=3, cap_pinned=2)
+    c.put("train", "T", pinned=True)
+    for i in range(10):
+        c.put(("eval", i), i)
+    assert c.get("train") == "T" and len(c) == 4 and c.get(("eval", 9)) == 9 and c.get(("eval", 0)) is None
+    c.put("train2", "T2", pinned=True); c.put("train3", "T3", pinned=True)
+    assert c.get("train") is None and c.get("train3") == "T3"
