@@ -73,7 +73,7 @@ typedef struct {
  *   y[c] = v                                       for c < cout_store
  */
 typedef struct {
-  int32_t dtype;            /* SRGANFD_BF16 | SRGANFD_F32 */
+  int32_t dtype;            /* SRGANFD_BF16 | SRGANFD_F16 | SRGANFD_F32 */
   int32_t n, h_in, w_in;    /* stored input dims */
   int32_t up;               /* 1: logical input = nearest-x2 upsample of the stored input */
   int32_t ksize, stride, pad; /* 3,1,1 | 4,2,1 | 1,1,0 */
@@ -226,15 +226,21 @@ int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const
 /* ---- fused Adam + EMA over flat buffers (torch.optim.Adam maths, train_bsrgan.py:311-323,436,466;
  * AveragedModel with the reference's avg_fn, :290-291,470).  ema_mode: 0 none, 1 copy (first
  * update), 2 ema = (1-decay)*ema + decay*param.  grad_scale multiplies the gradient first
- * (1/world_size after an all-reduce(sum)). */
+ * (1/world_size after an all-reduce(sum), times 1/loss_scale in f16 mode).  skip_flag (device float or NULL): when *skip_flag != 0
+ * the parameter / moment update is skipped and only the EMA advances -- torch.cuda.amp.GradScaler.step() on a non-finite gradient
+ * followed by the unconditional ema update of train_bsrgan.py:466-470. */
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                      int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
-                     int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
+                     int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, const float* skip_flag, void* stream);
+/* *flag = 1.0 if any element of x is inf or NaN, else 0.0 (accumulate != 0: keeps an earlier 1.0): the found_inf of
+ * GradScaler.unscale_ (train_bsrgan.py:436,466), computed on the flat (all-reduced) gradient. */
+int srganfd_nonfinite_flag(const float* x, int64_t numel, float* flag, int32_t accumulate, void* stream);
 /* Same update with the step count in device memory: *step_dev is advanced by one and the bias corrections are computed on
  * the device (bc_dev: 2 floats of scratch), so that a captured hipGraph of the iteration can be replayed. */
 int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                          int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode, void* stream);
+                         int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode,
+                         const float* skip_flag, void* stream);
 
 /* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
 /* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);

@@ -94,13 +94,14 @@ SYMBOLS = {
     "srganfd_spectral_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "srganfd_adam_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                   C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+                                   C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "srganfd_nonfinite_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "srganfd_resize_bilinear": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_add_relu": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "srganfd_sigmoid": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_adam_ema_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "srganfd_l1_grad_views": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]),
     "srganfd_maxpool2_relu_bwd": (C.c_int, [View, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_nhwc_to_nchw_scaled": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -40,14 +40,15 @@ int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, i
 int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
                             float beta, float* ws, hipStream_t s);
 int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                  float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
+                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s);
+int nonfinite_flag_impl(const float* x, size_t n, float* flag, int accumulate, hipStream_t s);
 int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s);
 int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s);
 int l1_grad_views_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, const float* upstream, float scale, hipStream_t s);
 int maxpool2_relu_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, int n, int h, int w, int c, hipStream_t s);
 int nhwc_to_nchw_scaled_impl(srganfd_view src, int n, int c, int h, int w, float* dst, const float* ch_div, hipStream_t s);
 int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s);
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
 int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
@@ -83,7 +84,7 @@ using namespace srganfd;
 extern "C" {
 
 const char* srganfd_last_error(void) { return g_err; }
-int srganfd_abi_version(void) { return 1; }
+int srganfd_abi_version(void) { return 2; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 #ifdef SRGANFD_EXPERIMENT
 void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
@@ -166,9 +167,13 @@ int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const
   return spectral_norm_grad_impl(g_weight, w_orig, u, v, inv_sigma, dw_orig, rows, cols, beta, workspace, (hipStream_t)stream);
 }
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
-                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, void* stream) {
+                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode,
+                     const float* skip_flag, void* stream) {
   return adam_ema_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay,
-                       ema_mode, (hipStream_t)stream);
+                       ema_mode, skip_flag, (hipStream_t)stream);
+}
+int srganfd_nonfinite_flag(const float* x, int64_t numel, float* flag, int32_t accumulate, void* stream) {
+  return nonfinite_flag_impl(x, (size_t)numel, flag, accumulate, (hipStream_t)stream);
 }
 
 int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
@@ -177,9 +182,9 @@ int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t
 }
 int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay,
-                         int32_t ema_mode, void* stream) {
+                         int32_t ema_mode, const float* skip_flag, void* stream) {
   return adam_ema_dev_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step_dev, bc_dev, grad_scale,
-                           ema_decay, ema_mode, (hipStream_t)stream);
+                           ema_decay, ema_mode, skip_flag, (hipStream_t)stream);
 }
 int srganfd_l1_grad_views(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, const float* upstream,
                           float scale, void* stream) {

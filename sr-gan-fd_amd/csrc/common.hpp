@@ -50,6 +50,31 @@ template <> struct Elem<float> {
   __device__ static __forceinline__ float from_f(float f) { return f; }
 };
 
+// 8 consecutive 16-bit elements (one 16-byte chunk) <-> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 raw, float* out);
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 raw, float* out) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { out[2 * q] = __uint_as_float(raw[q] << 16); out[2 * q + 1] = __uint_as_float(raw[q] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack8<f16_t>(const u32x4 raw, float* out) {
+  const f16x8 hv = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) out[q] = (float)hv[q];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float* v);
+template <> __device__ __forceinline__ u32x4 pack8<bf16_t>(const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = (unsigned)f2bf(v[2 * q]) | ((unsigned)f2bf(v[2 * q + 1]) << 16);
+  return o;
+}
+template <> __device__ __forceinline__ u32x4 pack8<f16_t>(const float* v) {
+  f16x8 hv;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) hv[q] = (_Float16)v[q];
+  return __builtin_bit_cast(u32x4, hv);
+}
+
 // MFMA 32x32 C/D layout (dtype independent on gfx950): col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ int mfma32_row(int reg, int lane) {

@@ -30,12 +30,7 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 template <typename T> struct VecN { static constexpr int N = 16 / (int)sizeof(T); };
 template <typename T> __device__ __forceinline__ void ldv(const void* p, size_t i, float* o) {
   if constexpr (sizeof(T) == 2) {
-    const u32x4 r = *(const u32x4*)((const bf16_t*)p + i);
-    const unsigned w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3];
-    o[0] = __uint_as_float(w0 << 16); o[1] = __uint_as_float(w0 & 0xffff0000u);
-    o[2] = __uint_as_float(w1 << 16); o[3] = __uint_as_float(w1 & 0xffff0000u);
-    o[4] = __uint_as_float(w2 << 16); o[5] = __uint_as_float(w2 & 0xffff0000u);
-    o[6] = __uint_as_float(w3 << 16); o[7] = __uint_as_float(w3 & 0xffff0000u);
+    unpack8<T>(*(const u32x4*)((const T*)p + i), o);
   } else {
     const f32x4 r = *(const f32x4*)((const float*)p + i);
     o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
@@ -43,12 +38,7 @@ template <typename T> __device__ __forceinline__ void ldv(const void* p, size_t 
 }
 template <typename T> __device__ __forceinline__ void stv(void* p, size_t i, const float* v) {
   if constexpr (sizeof(T) == 2) {
-    u32x4 o;
-    o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    o[2] = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    o[3] = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-    *(u32x4*)((bf16_t*)p + i) = o;
+    *(u32x4*)((T*)p + i) = pack8<T>(v);
   } else {
     const f32x4 o = {v[0], v[1], v[2], v[3]};
     *(f32x4*)((float*)p + i) = o;
@@ -251,11 +241,12 @@ __global__ void clamp_grad_kernel(const float* __restrict__ dsr, const float* __
   }
 }
 
-// the generator's case (3 image channels, fp32 pre-clamp SR with a 4-channel pitch, bf16 gradient padded to 32 channels): one thread
+// the generator's case (3 image channels, fp32 pre-clamp SR with a 4-channel pitch, 16-bit gradient padded to 32 channels): one thread
 // per pixel, one 16-byte read of the pre-clamp pixel, three coalesced plane reads, four 16-byte stores (the 29 padding channels are
 // zeros the data-gradient conv multiplies by padded weights)
-__global__ __launch_bounds__(256) void clamp_grad_rgb_bf16_kernel(const float* __restrict__ dsr, const f32x4* __restrict__ pre, u32x4* __restrict__ dst,
-                                                                  size_t npix, size_t hw, int c) {
+template <typename T>
+__global__ __launch_bounds__(256) void clamp_grad_rgb16_kernel(const float* __restrict__ dsr, const f32x4* __restrict__ pre, u32x4* __restrict__ dst,
+                                                               size_t npix, size_t hw, int c) {
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     const size_t img = p / hw, pix = p % hw;
     const f32x4 q = pre[p];
@@ -263,7 +254,8 @@ __global__ __launch_bounds__(256) void clamp_grad_rgb_bf16_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (k < c && q[k] >= 0.f && q[k] <= 1.f) v[k] = dsr[(img * c + k) * hw + pix];
-    u32x4 w0 = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16), 0u, 0u};
+    const float v8[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
+    const u32x4 w0 = pack8<T>(v8);
     const u32x4 z = {0u, 0u, 0u, 0u};
     dst[p * 4 + 0] = w0; dst[p * 4 + 1] = z; dst[p * 4 + 2] = z; dst[p * 4 + 3] = z;
   }
@@ -565,8 +557,17 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ 
 // ---- fused Adam (torch.optim.Adam maths, train_bsrgan.py:311-323) + EMA (train_bsrgan.py:290-291,470) ----
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                       float bc1, float bc2_sqrt, float gscale, float ema_decay, int ema_mode) {
+                                                       float bc1, float bc2_sqrt, float gscale, float ema_decay, int ema_mode,
+                                                       const float* __restrict__ skip) {
+  // loss-scaled (f16) training: a non-finite gradient skips the parameter update (GradScaler.step, train_bsrgan.py:436,466); the
+  // EMA still advances -- the reference calls update_parameters() after every iteration (:470)
+  const bool skipped = skip && *skip != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (skipped) {
+      if (ema_mode == 1) ema[i] = p[i];
+      else if (ema_mode == 2) ema[i] = (1.f - ema_decay) * ema[i] + ema_decay * p[i];
+      continue;
+    }
     float gi = g[i] * gscale;
     float pi = p[i];
     if (wd != 0.f) gi += wd * pi;
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 
 // Step counter and bias corrections in device memory (hipGraph replays cannot change kernel arguments): one thread
 // advances *step and writes bc = {1 - b1^t, sqrt(1 - b2^t)}; the Adam kernel then reads them.
-__global__ void adam_step_kernel(int* __restrict__ step, float b1, float b2, float* __restrict__ bc) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void adam_step_kernel(int* __restrict__ step, float b1, float b2, float* __restrict__ bc, const float* __restrict__ skip) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip != 0.f)) {      // a skipped step does not count (torch: state["step"] unchanged)
     const int t = *step + 1;
     *step = t;
     bc[0] = (float)(1.0 - pow((double)b1, (double)t));
@@ -593,9 +594,16 @@ __global__ void adam_step_kernel(int* __restrict__ step, float b1, float b2, flo
 }
 __global__ __launch_bounds__(256) void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                           const float* __restrict__ bc, float gscale, float ema_decay, int ema_mode) {
+                                                           const float* __restrict__ bc, float gscale, float ema_decay, int ema_mode,
+                                                           const float* __restrict__ skip) {
   const float bc1 = bc[0], bc2_sqrt = bc[1];
+  const bool skipped = skip && *skip != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (skipped) {
+      if (ema_mode == 1) ema[i] = p[i];
+      else if (ema_mode == 2) ema[i] = (1.f - ema_decay) * ema[i] + ema_decay * p[i];
+      continue;
+    }
     float gi = g[i] * gscale;
     float pi = p[i];
     if (wd != 0.f) gi += wd * pi;
@@ -1122,26 +1130,26 @@ static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 81
   if (g > cap) g = cap;
   return (unsigned)g;
 }
-#define DISPATCH_T(dtype, CALL_BF, CALL_F32)                                  \
-  if ((dtype) == SRGANFD_BF16) { CALL_BF; } else if ((dtype) == SRGANFD_F32) { CALL_F32; } \
+// CALL names the element type as TT
+#define DISPATCH_T(dtype, CALL)                                                              \
+  if ((dtype) == SRGANFD_BF16) { using TT = bf16_t; CALL; } else if ((dtype) == SRGANFD_F16) { using TT = f16_t; CALL; } \
+  else if ((dtype) == SRGANFD_F32) { using TT = float; CALL; }                               \
   else return set_err(SRGANFD_EINVAL, "bad dtype %d", (int)(dtype));
 
 int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s) {
   if (!src || !dst.ptr || n <= 0 || c <= 0 || cpad < c || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "nchw_to_nhwc: bad args");
   const size_t total = (size_t)n * h * w * cpad;
   {
-    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    const int vn = dtype == SRGANFD_F32 ? 4 : 8;
     if (cpad % vn == 0 && dst.c0 % vn == 0 && dst.cstride % vn == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
       DISPATCH_T(dtype,
-                 SRGANFD_LAUNCH(nchw_to_nhwc_vec_kernel<bf16_t>, dim3(grid_for(total / vn, 256, 65536)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv),
-                 SRGANFD_LAUNCH(nchw_to_nhwc_vec_kernel<float>, dim3(grid_for(total / vn, 256, 65536)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
+                 SRGANFD_LAUNCH(nchw_to_nhwc_vec_kernel<TT>, dim3(grid_for(total / vn, 256, 65536)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
       SRGANFD_HIP_CHECK(hipGetLastError());
       return SRGANFD_OK;
     }
   }
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv),
-             SRGANFD_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
+             SRGANFD_LAUNCH(nchw_to_nhwc_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, s, src, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad, mean, stdv));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -1149,24 +1157,23 @@ int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, f
   if (!src.ptr || !dst || src.c0 + c > src.cstride) return set_err(SRGANFD_EINVAL, "nhwc_to_nchw: bad args");
   const size_t total = (size_t)n * h * w * c;
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src.ptr, src.cstride, src.c0, dst, n, c, h * w, clamp01),
-             SRGANFD_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src.ptr, src.cstride, src.c0, dst, n, c, h * w, clamp01));
+             SRGANFD_LAUNCH(nhwc_to_nchw_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, s, src.ptr, src.cstride, src.c0, dst, n, c, h * w, clamp01));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s) {
   if (!dsr || !pre.ptr || !dst.ptr || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "clamp_grad: bad args");
   const size_t total = (size_t)n * h * w * cpad;
-  if (dtype == SRGANFD_BF16 && c <= 4 && cpad == 32 && pre.cstride == 4 && pre.c0 == 0 && dst.cstride == 32 && dst.c0 == 0 &&
+  if (dtype != SRGANFD_F32 && c <= 4 && cpad == 32 && pre.cstride == 4 && pre.c0 == 0 && dst.cstride == 32 && dst.c0 == 0 &&
       ((uintptr_t)pre.ptr & 15) == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
     const size_t npix = (size_t)n * h * w;
-    SRGANFD_LAUNCH(clamp_grad_rgb_bf16_kernel, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (u32x4*)dst.ptr, npix, (size_t)h * w, c);
+    if (dtype == SRGANFD_BF16) SRGANFD_LAUNCH(clamp_grad_rgb16_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (u32x4*)dst.ptr, npix, (size_t)h * w, c);
+    else SRGANFD_LAUNCH(clamp_grad_rgb16_kernel<f16_t>, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (u32x4*)dst.ptr, npix, (size_t)h * w, c);
     SRGANFD_HIP_CHECK(hipGetLastError());
     return SRGANFD_OK;
   }
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(clamp_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad),
-             SRGANFD_LAUNCH(clamp_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad));
+             SRGANFD_LAUNCH(clamp_grad_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, s, dsr, (const float*)pre.ptr, pre.cstride, pre.c0, dst.ptr, dst.cstride, dst.c0, n, c, h * w, cpad));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -1175,14 +1182,12 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
   if (!a.ptr || !b.ptr || a.c0 + c > a.cstride || b.c0 + c > b.cstride) return set_err(SRGANFD_EINVAL, "resample: bad args");
   const size_t lo = (size_t)n * h * w * c;
 #define RS(K, TOTAL) DISPATCH_T(dtype, \
-    SRGANFD_LAUNCH(K<bf16_t>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c), \
-    SRGANFD_LAUNCH(K<float>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    SRGANFD_LAUNCH(K<TT>, dim3(grid_for(TOTAL)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   const bool vec = c % vn == 0 && a.c0 % vn == 0 && b.c0 % vn == 0 && a.cstride % vn == 0 && b.cstride % vn == 0 &&
                    ((uintptr_t)a.ptr & 15) == 0 && ((uintptr_t)b.ptr & 15) == 0;
 #define RSV(OP, TOTAL) DISPATCH_T(dtype, \
-    SRGANFD_LAUNCH((resample_vec_kernel<bf16_t, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c), \
-    SRGANFD_LAUNCH((resample_vec_kernel<float, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
+    SRGANFD_LAUNCH((resample_vec_kernel<TT, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
   if (vec) {
     if (op == 0) { RSV(0, lo); }
     else if (op == 1) { RSV(1, lo * 4); }
@@ -1205,22 +1210,18 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
 int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int dtype, size_t npix, int c, float slope, hipStream_t s) {
   if (!dy.ptr || !act.ptr || !out.ptr) return set_err(SRGANFD_EINVAL, "lrelu_bwd: null");
   {
-    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    const int vn = dtype == SRGANFD_F32 ? 4 : 8;
     auto ok = [&](const srganfd_view& v) { return !v.ptr || (v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0); };
     if (c % vn == 0 && ok(dy) && ok(act) && ok(skip) && ok(out)) {
       DISPATCH_T(dtype,
-                 SRGANFD_LAUNCH(lrelu_bwd_vec_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
-                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope),
-                 SRGANFD_LAUNCH(lrelu_bwd_vec_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+                 SRGANFD_LAUNCH(lrelu_bwd_vec_kernel<TT>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
                                 skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope));
       SRGANFD_HIP_CHECK(hipGetLastError());
       return SRGANFD_OK;
     }
   }
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
-                                skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope),
-             SRGANFD_LAUNCH(lrelu_bwd_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
+             SRGANFD_LAUNCH(lrelu_bwd_kernel<TT>, dim3(grid_for(npix * c)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, act.ptr, act.cstride, act.c0,
                                 skip.ptr, skip.cstride, skip.c0, out.ptr, out.cstride, out.c0, npix, c, slope));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
@@ -1228,19 +1229,17 @@ int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd
 int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s) {
   if (!x.ptr || !y.ptr) return set_err(SRGANFD_EINVAL, "axpby: null");
   {
-    const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+    const int vn = dtype == SRGANFD_F32 ? 4 : 8;
     auto ok = [&](const srganfd_view& v) { return v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0; };
     if (c % vn == 0 && ok(x) && ok(y)) {
       DISPATCH_T(dtype,
-                 SRGANFD_LAUNCH(axpby_vec_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b),
-                 SRGANFD_LAUNCH(axpby_vec_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
+                 SRGANFD_LAUNCH(axpby_vec_kernel<TT>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
       SRGANFD_HIP_CHECK(hipGetLastError());
       return SRGANFD_OK;
     }
   }
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(axpby_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b),
-             SRGANFD_LAUNCH(axpby_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
+             SRGANFD_LAUNCH(axpby_kernel<TT>, dim3(grid_for(npix * c)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, y.ptr, y.cstride, y.c0, npix, c, a, b));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -1259,15 +1258,13 @@ int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c,
   if (!a.ptr || !b.ptr || !out || !ws) return set_err(SRGANFD_EINVAL, "l1_views: bad args");
   const size_t n = npix * c;
   const unsigned g = grid_for(n, 256, kRedBlocks);
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   if (c % vn == 0 && a.c0 % vn == 0 && b.c0 % vn == 0 && a.cstride % vn == 0 && b.cstride % vn == 0 && ((uintptr_t)a.ptr & 15) == 0 && ((uintptr_t)b.ptr & 15) == 0) {
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(l1_views_vec_partial_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws),
-               SRGANFD_LAUNCH(l1_views_vec_partial_kernel<float>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
+               SRGANFD_LAUNCH(l1_views_vec_partial_kernel<TT>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
   } else
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(l1_views_partial_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws),
-             SRGANFD_LAUNCH(l1_views_partial_kernel<float>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
+             SRGANFD_LAUNCH(l1_views_partial_kernel<TT>, dim3(g), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, npix, c, relu, ws));
   SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, out, accumulate);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
@@ -1315,28 +1312,47 @@ int spectral_norm_grad_impl(const float* G, const float* W, const float* u, cons
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
+// flag = 1 if any element of x is inf or NaN (the found_inf of torch.cuda.amp.GradScaler.unscale_, train_bsrgan.py:436,466)
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, float* __restrict__ flag) {
+  bool bad = false;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    bad |= !(fabsf(v[0]) <= 3.402823466e38f) | !(fabsf(v[1]) <= 3.402823466e38f) | !(fabsf(v[2]) <= 3.402823466e38f) | !(fabsf(v[3]) <= 3.402823466e38f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(x[n4 * 4 + threadIdx.x]) <= 3.402823466e38f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;      // every writer stores the same value
+}
+int nonfinite_flag_impl(const float* x, size_t n, float* flag, int accumulate, hipStream_t s) {
+  if (!x || !flag || n == 0 || ((uintptr_t)x & 15)) return set_err(SRGANFD_EINVAL, "nonfinite_flag: bad args");
+  if (!accumulate) SRGANFD_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(float), s));
+  SRGANFD_LAUNCH(nonfinite_flag_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, x, n, flag);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
 int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                  float grad_scale, float ema_decay, int ema_mode, hipStream_t s) {
+                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s) {
   if (!p || !g || !m || !v || n == 0 || step < 1 || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam: bad args");
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   SRGANFD_LAUNCH(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2),
-                     grad_scale, ema_decay, ema_mode);
+                     grad_scale, ema_decay, ema_mode, skip_flag);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 
 int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, hipStream_t s) {
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s) {
   if (!p || !g || !m || !v || n == 0 || !step_dev || !bc_dev || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam(dev): bad args");
-  SRGANFD_LAUNCH(adam_step_kernel, dim3(1), dim3(64), 0, s, step_dev, b1, b2, bc_dev);
+  SRGANFD_LAUNCH(adam_step_kernel, dim3(1), dim3(64), 0, s, step_dev, b1, b2, bc_dev, skip_flag);
   SRGANFD_LAUNCH(adam_ema_dev_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (const float*)bc_dev, grad_scale,
-                 ema_decay, ema_mode);
+                 ema_decay, ema_mode, skip_flag);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 
 static bool vec_ok(int dtype, int c, std::initializer_list<srganfd_view> vs) {
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   if (c % vn) return false;
   for (const auto& v : vs)
     if (v.ptr && (v.c0 % vn || v.cstride % vn || ((uintptr_t)v.ptr & 15))) return false;
@@ -1344,27 +1360,24 @@ static bool vec_ok(int dtype, int c, std::initializer_list<srganfd_view> vs) {
 }
 int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s) {
   if (!a.ptr || !b.ptr || !vec_ok(dtype, c, {a, b})) return set_err(SRGANFD_EINVAL, "resize_bilinear: views must be 16-byte aligned channel multiples");
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   if (!bwd) {
     const size_t total = (size_t)n * ho * wo * c / vn;
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(resize_fwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c),
-               SRGANFD_LAUNCH(resize_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
+               SRGANFD_LAUNCH(resize_fwd_kernel<TT>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
   } else {
     const size_t total = (size_t)n * hi * wi * c / vn;
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(resize_bwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c),
-               SRGANFD_LAUNCH(resize_bwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
+               SRGANFD_LAUNCH(resize_bwd_kernel<TT>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, hi, wi, ho, wo, c));
   }
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s) {
   if (!a.ptr || !b.ptr || !out.ptr || !vec_ok(dtype, c, {a, b, out})) return set_err(SRGANFD_EINVAL, "add_relu: bad views");
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(add_relu_kernel<bf16_t>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c),
-             SRGANFD_LAUNCH(add_relu_kernel<float>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c));
+             SRGANFD_LAUNCH(add_relu_kernel<TT>, dim3(grid_for(npix * c / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -1381,25 +1394,23 @@ int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hip
   return SRGANFD_OK;
 }
 int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s) {
-  const int vn = dtype == SRGANFD_BF16 ? 8 : 4;
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
   const int cv = c / vn;
   if (!x.ptr || !gate || !y.ptr || !vec_ok(dtype, c, {x, y, dx}) || cv > 64 || (cv & (cv - 1))) return set_err(SRGANFD_EINVAL, "gate_mul: bad args");
   if (!bwd) {
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(gate_fwd_kernel<bf16_t>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, npix, c),
-               SRGANFD_LAUNCH(gate_fwd_kernel<float>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, npix, c));
+               SRGANFD_LAUNCH(gate_fwd_kernel<TT>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, npix, c));
   } else {
     if (!dx.ptr || !dgate) return set_err(SRGANFD_EINVAL, "gate_mul(bwd): null");
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(gate_bwd_kernel<bf16_t>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, dx.ptr, dx.cstride, dx.c0, dgate, npix, c),
-               SRGANFD_LAUNCH(gate_bwd_kernel<float>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, dx.ptr, dx.cstride, dx.c0, dgate, npix, c));
+               SRGANFD_LAUNCH(gate_bwd_kernel<TT>, dim3(grid_for(npix * cv, 256, 65536)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, gate, y.ptr, y.cstride, y.c0, dx.ptr, dx.cstride, dx.c0, dgate, npix, c));
   }
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 static constexpr int kBnBlocks = 1024;  // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
-static inline bool bn_chunks_ok(int dtype, int c) { const int cv = c / (dtype == SRGANFD_BF16 ? 8 : 4); return cv > 0 && 256 % cv == 0; }
-static inline unsigned bn_grid(size_t npix, int dtype, int c) { const int lanes = 256 / (c / (dtype == SRGANFD_BF16 ? 8 : 4)); return grid_for((npix + lanes - 1) / lanes, 1, 16384); }
+static inline bool bn_chunks_ok(int dtype, int c) { const int cv = c / (dtype == SRGANFD_F32 ? 4 : 8); return cv > 0 && 256 % cv == 0; }
+static inline unsigned bn_grid(size_t npix, int dtype, int c) { const int lanes = 256 / (c / (dtype == SRGANFD_F32 ? 4 : 8)); return grid_for((npix + lanes - 1) / lanes, 1, 16384); }
 // Channels are processed in blocks of <= 256 (the statistics kernels map one thread to one channel); `save` is
 // [block][mean | invstd | scale | shift] and is only read back by batchnorm_bwd_impl with the same blocking.
 static inline srganfd_view sub_view(srganfd_view v, int cb) { if (v.ptr) v.c0 += cb; return v; }
@@ -1414,14 +1425,11 @@ int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, i
     float* sv = save + 4 * cb;
     if (training) {
       DISPATCH_T(dtype,
-                 SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f),
-                 SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f));
+                 SRGANFD_LAUNCH(bn_partial_kernel<TT>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f));
     }
     SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, beta + cb, rm + cb, rv + cb, momentum, eps, training, sv);
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
-                              ys.ptr, ys.cstride, ys.c0, (const float*)(sv + 2 * cc), (const float*)nullptr, (const float*)(sv + 3 * cc), npix, cc, act_slope, (const void*)nullptr, 0, 0, 1.f),
-               SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
+               SRGANFD_LAUNCH(chan_affine_kernel<TT>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
                               ys.ptr, ys.cstride, ys.c0, (const float*)(sv + 2 * cc), (const float*)nullptr, (const float*)(sv + 3 * cc), npix, cc, act_slope, (const void*)nullptr, 0, 0, 1.f));
   }
   SRGANFD_HIP_CHECK(hipGetLastError());
@@ -1438,13 +1446,10 @@ int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dty
     const float* sv = save + 4 * cb;
     float* coef = ws + (size_t)kBnBlocks * 2 * cc;
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(bn_partial_kernel<bf16_t>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope),
-               SRGANFD_LAUNCH(bn_partial_kernel<float>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope));
+               SRGANFD_LAUNCH(bn_partial_kernel<TT>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope));
     SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, sv, dgamma + cb, dbeta + cb, acc, coef);
     DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(chan_affine_kernel<bf16_t>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
-                              dxs.ptr, dxs.cstride, dxs.c0, (const float*)coef, (const float*)(coef + cc), (const float*)(coef + 2 * cc), npix, cc, 1.f, (const void*)as.ptr, as.cstride, as.c0, act_slope),
-               SRGANFD_LAUNCH(chan_affine_kernel<float>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
+               SRGANFD_LAUNCH(chan_affine_kernel<TT>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
                               dxs.ptr, dxs.cstride, dxs.c0, (const float*)coef, (const float*)(coef + cc), (const float*)(coef + 2 * cc), npix, cc, 1.f, (const void*)as.ptr, as.cstride, as.c0, act_slope));
   }
   SRGANFD_HIP_CHECK(hipGetLastError());
@@ -1492,8 +1497,7 @@ int ssim_impl(const float* a, const float* b, int n, int c, int h, int w, int cr
 int l1_grad_views_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, const float* upstream, float scale, hipStream_t s) {
   if (!a.ptr || !b.ptr || !out.ptr || npix == 0 || c <= 0) return set_err(SRGANFD_EINVAL, "l1_grad_views: bad args");
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(l1_grad_views_kernel<bf16_t>, dim3(grid_for(npix * c)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c, upstream, scale),
-             SRGANFD_LAUNCH(l1_grad_views_kernel<float>, dim3(grid_for(npix * c)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c, upstream, scale));
+             SRGANFD_LAUNCH(l1_grad_views_kernel<TT>, dim3(grid_for(npix * c)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, out.ptr, out.cstride, out.c0, npix, c, upstream, scale));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
@@ -1501,8 +1505,7 @@ int maxpool2_relu_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int
   if (!x.ptr || !dy.ptr || !dx.ptr || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0) return set_err(SRGANFD_EINVAL, "maxpool2_relu_bwd: bad args");
   const size_t total = (size_t)n * (h / 2) * (w / 2) * c;
   DISPATCH_T(dtype,
-             SRGANFD_LAUNCH(maxpool2_relu_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, dy.ptr, dy.cstride, dy.c0, dx.ptr, dx.cstride, dx.c0, n, h, w, c),
-             SRGANFD_LAUNCH(maxpool2_relu_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, dy.ptr, dy.cstride, dy.c0, dx.ptr, dx.cstride, dx.c0, n, h, w, c));
+             SRGANFD_LAUNCH(maxpool2_relu_bwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, s, x.ptr, x.cstride, x.c0, dy.ptr, dy.cstride, dy.c0, dx.ptr, dx.cstride, dx.c0, n, h, w, c));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -53,10 +53,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // two transposed 4-element reads -> one 8-element MFMA fragment: pure register concatenation (no VALU)
-__device__ __forceinline__ bf16x8 cat_frag(s16x4 lo, s16x4 hi) {
+template <typename T> __device__ __forceinline__ typename FragAB<T>::type cat_frag(s16x4 lo, s16x4 hi) {
   const u32x2 l = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
   const u32x4 v = {l.x, l.y, h2.x, h2.y};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(typename FragAB<T>::type, v);
 }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS [dst, dst + 1 KiB) (dst wave-uniform).
@@ -333,18 +333,19 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
             const char* yb = ldsY + ay + hh * 16 * dyRowB;
             const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb));
             const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 4 * dyRowB));
-            const bf16x8 bfrag = cat_frag(blo, bhi);
+            const auto bfrag = cat_frag<T>(blo, bhi);
             if (W.bias_slab >= 0) {
               const u32x2 l = __builtin_bit_cast(u32x2, blo), h2 = __builtin_bit_cast(u32x2, bhi);
-              bsum += __uint_as_float(l.x << 16) + __uint_as_float(l.x & 0xffff0000u) + __uint_as_float(l.y << 16) + __uint_as_float(l.y & 0xffff0000u) +
-                      __uint_as_float(h2.x << 16) + __uint_as_float(h2.x & 0xffff0000u) + __uint_as_float(h2.y << 16) + __uint_as_float(h2.y & 0xffff0000u);
+              float f8[8];
+              unpack8<T>(u32x4{l.x, l.y, h2.x, h2.y}, f8);
+              bsum += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
             }
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
               const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
               const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
               const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
-              acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat_frag(lo, hi), bfrag, acc[dx], 0, 0, 0);
+              acc[dx] = mfma32<T>(cat_frag<T>(lo, hi), bfrag, acc[dx]);
             }
           }
         } else {
@@ -529,11 +530,11 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.bias_slab_off = slab * NT * 1024;
   H.x_upad = 1; H.dy_upad = 1;
   for (auto& g : pb.groups) { if (g.x_units > H.x_upad) H.x_upad = g.x_units; if (g.dy_units > H.dy_upad) H.dy_upad = g.dy_units; }
-  const int UB = 32 * (s->dtype == SRGANFD_BF16 ? 2 : 4);
+  const int UB = 32 * (s->dtype == SRGANFD_F32 ? 4 : 2);
   const int PR = (kTH - 1) * s->stride + s->ksize, PC = 31 * s->stride + s->ksize;
   H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
   if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
-  H.dma_ok = (s->dtype == SRGANFD_BF16 && 2 * H.lds_bytes <= 160 * 1024) ? 1 : 0;
+  H.dma_ok = (s->dtype != SRGANFD_F32 && 2 * H.lds_bytes <= 160 * 1024) ? 1 : 0;
   for (auto& g : pb.groups) if (g.x_units != H.x_upad || g.dy_units != H.dy_upad) H.dma_ok = 0;
   H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
   H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;
@@ -611,12 +612,13 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
   k.dbg = SRGANFD_DBG(g_debug, ~0); k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
-  const bool bf = H.dtype == SRGANFD_BF16;
-  if (H.ks == 3 && H.stride == 1) rc = bf ? launch_wgrad<bf16_t, 3, 1>(H, k, stream) : launch_wgrad<float, 3, 1>(H, k, stream);
-  else if (H.ks == 3) rc = bf ? launch_wgrad<bf16_t, 3, 2>(H, k, stream) : launch_wgrad<float, 3, 2>(H, k, stream);
-  else if (H.ks == 4) rc = bf ? launch_wgrad<bf16_t, 4, 2>(H, k, stream) : launch_wgrad<float, 4, 2>(H, k, stream);
-  else if (H.ks == 2) rc = bf ? launch_wgrad<bf16_t, 2, 2>(H, k, stream) : launch_wgrad<float, 2, 2>(H, k, stream);
-  else rc = bf ? launch_wgrad<bf16_t, 1, 1>(H, k, stream) : launch_wgrad<float, 1, 1>(H, k, stream);
+#define WG_BY_TYPE(KS_, S_) (H.dtype == SRGANFD_BF16 ? launch_wgrad<bf16_t, KS_, S_>(H, k, stream) : H.dtype == SRGANFD_F16 ? launch_wgrad<f16_t, KS_, S_>(H, k, stream) : launch_wgrad<float, KS_, S_>(H, k, stream))
+  if (H.ks == 3 && H.stride == 1) rc = WG_BY_TYPE(3, 1);
+  else if (H.ks == 3) rc = WG_BY_TYPE(3, 2);
+  else if (H.ks == 4) rc = WG_BY_TYPE(4, 2);
+  else if (H.ks == 2) rc = WG_BY_TYPE(2, 2);
+  else rc = WG_BY_TYPE(1, 1);
+#undef WG_BY_TYPE
   if (rc != SRGANFD_OK) return rc;
   const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
   SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(H.ntap_wave, H.ntasks), dim3(1024), 0, stream, tasks_dev,

@@ -21,7 +21,7 @@ from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
 from .parallel import allreduce_sum_
-from .trainer import FlatAdamEMA
+from .trainer import FlatAdamEMA, LossScaler, needs_loss_scaling
 
 
 class GanTrainer:
@@ -40,6 +40,7 @@ class GanTrainer:
         self.g_opt = FlatAdamEMA(self.ge.fp.sync(dev), g_lr, betas, eps, weight_decay, ema_decay, layout=self.ge.fp)
         self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None, layout=self.de.fp)
         self.pw, self.cw, self.aw = pixel_weight, content_weight, adversarial_weight
+        self.scaler = LossScaler(dev, enabled=needs_loss_scaling(g_model, d_model))   # ONE scaler for both networks (train_bsrgan.py:109)
         # per-node content weights (Real-ESRGAN's list): built once -- a host list turned into a device tensor inside step() is a
         # host->device copy per iteration and cannot be captured into a graph
         self._cw_t = None if isinstance(content_weight, (int, float)) else torch.tensor(list(content_weight), dtype=torch.float32, device=dev)
@@ -85,10 +86,11 @@ class GanTrainer:
                 if "ema_state_dict" in c and opt.ema is not None:
                     opt.load_ema_state_dict(c["ema_state_dict"])
 
-    def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
+    def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor, S: float = 1.0) -> None:
+        """loss value weighted by ``weight``; its gradient by ``weight * S`` (S = the loss scale of the backward pass it seeds)"""
         s = self.scalars.data_ptr()
         A.check(A.lib().srganfd_bce_logits(logits.data_ptr(), logits.numel(), target, weight, s + 4 * slot, 0,
-                                           (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight,
+                                           (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight * S,
                                            self.ws.data_ptr(), A.stream_ptr()), "bce_logits")
 
     def _content(self, sr: Tensor, gt: Tensor) -> None:
@@ -108,29 +110,31 @@ class GanTrainer:
         sr = ge.forward(lr_img, True)
         g_sp, g_tok = ge._last, ge.token
         dsr = self._buf("dsr", sr)
-        A.check(L.srganfd_l1_loss(sr.data_ptr(), gtu.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+        Sg = self.scaler.current()
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gtu.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw * Sg,
                                   self.ws.data_ptr(), st), "l1_loss")
         self._content(sr, gtu)
         adv_out = de.forward(sr, True)
         dl = self._buf("dl", adv_out)
-        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl, Sg)
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             gg, _ = ge.backward(g_sp, g_tok, dsr, False)
-            self.g_opt.step(gg, self._allreduce(gg))
+            self.scaler.step(self.g_opt, gg, self._allreduce(gg), Sg)
             ge.fp.touch()
         s = self.scalars.data_ptr()
+        Sd = self.scaler.current()
         gt_out = de.forward(gt, True)
-        self._bce(gt_out, 1.0, 1.0, 0, None, dl)
+        self._bce(gt_out, 1.0, 1.0, 0, None, dl, Sd)
         A.check(L.srganfd_sigmoid_of_mean(gt_out.data_ptr(), gt_out.numel(), s + 16, self.ws.data_ptr(), st), "sigmoid_of_mean")
         gd1, _ = de.backward(de._last, de.token, dl, True, False)
         sr_out = de.forward(sr, True)
-        self._bce(sr_out, 0.0, 1.0, 1, None, dl)
+        self._bce(sr_out, 0.0, 1.0, 1, None, dl, Sd)
         A.check(L.srganfd_sigmoid_of_mean(sr_out.data_ptr(), sr_out.numel(), s + 20, self.ws.data_ptr(), st), "sigmoid_of_mean")
         gd2, _ = de.backward(de._last, de.token, dl, True, False)
         A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
-        self.d_opt.step(gd2, self._allreduce(gd2))
+        self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd)
         self.sr = sr
         return self.scalars
 
@@ -146,29 +150,31 @@ class GanTrainer:
         ge, de = self.ge, self.de
         gt = gt.contiguous().float()
         # ---- discriminator ----
+        Sd = self.scaler.current()                          # scaler.scale(d_loss_*): train_bsrgan.py:420,430
         gt_out = de.forward(gt, True)
         dl = self._buf("dl", gt_out)
-        self._bce(gt_out, 1.0, 1.0, 0, 4, dl)
+        self._bce(gt_out, 1.0, 1.0, 0, 4, dl, Sd)
         gd1, _ = de.backward(de._last, de.token, dl, True, False)
         sr = ge.forward(lr_img, True)
         g_sp, g_tok = ge._last, ge.token
         sr_out = de.forward(sr, True)
-        self._bce(sr_out, 0.0, 1.0, 1, 5, dl)
+        self._bce(sr_out, 0.0, 1.0, 1, 5, dl, Sd)
         gd2, _ = de.backward(de._last, de.token, dl, True, False)
         A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
-        self.d_opt.step(gd2, self._allreduce(gd2))
+        self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd)      # scaler.step(d_optimizer); scaler.update()  (:436-437)
         # ---- generator ----
+        Sg = self.scaler.current()                          # the scale after the discriminator's update()  (:463)
         dsr = self._buf("dsr", sr)
-        A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw * Sg,
                                   self.ws.data_ptr(), st), "l1_loss")
         self._content(sr, gt)
         adv_out = de.forward(sr, True)                      # updated D, SN state advances again (train_bsrgan.py:452)
-        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl, Sg)
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             gg, _ = ge.backward(g_sp, g_tok, dsr, False)
-            self.g_opt.step(gg, self._allreduce(gg))
+            self.scaler.step(self.g_opt, gg, self._allreduce(gg), Sg)    # scaler.step(g_optimizer); scaler.update(); EMA  (:466-470)
             ge.fp.touch()
         self.sr = sr
         return self.scalars

@@ -56,7 +56,7 @@ class GraphedStep:
     def _hyper(self):
         tr = self.trainer
         return ([(o.lr, tuple(o.betas), o.eps, o.wd, o.ema_decay) for o in self._opts()],
-                tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")))
+                tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")) + (getattr(getattr(tr, "scaler", None), "scale", 1.0),))
 
     def __call__(self, lr_img: Tensor, gt: Tensor) -> Tensor:
         if self._hyper() != self._frozen:

@@ -7,9 +7,11 @@
 They call the same engines as the ``nn.Module`` surface (``model.py``) but skip the autograd
 bookkeeping: loss + dLoss/dSR come from one HIP kernel, the flat gradient goes straight to the fused
 Adam + EMA kernel, and under data parallelism the flat gradient is all-reduced once (RCCL).
-Mixed precision note: the reference runs ``amp.autocast()`` + ``GradScaler`` (fp16 on CUDA).  Here the
-compute dtype is bf16 with fp32 master weights / fp32 accumulation, which needs no loss scaling, so
-the scaler is the identity (as it is on the reference's CPU path).
+Mixed precision: the reference runs ``amp.autocast()`` + ``GradScaler`` (fp16 on CUDA, train_bsrgan.py:109,415-467).
+``compute_dtype = torch.float16`` is that mode here -- f16 activations, packed weights and gradients, fp32 master weights and
+accumulation -- with ``LossScaler`` below playing GradScaler's part (scaled loss seeds, unscale folded into the Adam kernel,
+found-inf check on the flat gradient, skipped step, dynamic scale).  bf16 / f32 need no loss scaling: the scaler is then the
+identity, as GradScaler is on the reference's CPU path.
 """
 from __future__ import annotations
 
@@ -21,6 +23,84 @@ from torch import Tensor
 from . import _abi as A
 from .engine import generator_engine
 from .parallel import allreduce_sum_
+
+
+class LossScaler:
+    """``torch.cuda.amp.GradScaler()`` as the reference uses it (one instance for both networks, ``scale(loss).backward()``,
+    ``step(optimizer)``, ``update()`` after EACH optimizer step: train_bsrgan.py:109,420,430,436-437,463,466-467), defaults of
+    torch/amp/grad_scaler.py: init_scale 65536, growth x2 after 2000 consecutive finite steps, backoff x0.5 on a non-finite one.
+
+    Differences in mechanics, not in arithmetic: the loss is never materialised scaled -- the factor multiplies the gradient
+    seeds that the loss kernels emit; the unscale is the Adam kernel's ``grad_scale``; found_inf is one reduction over the flat
+    (already all-reduced: every rank sees the same value) gradient; the skip happens on the device (``skip_flag``), so the host
+    never waits for the flag -- it reads it back asynchronously and applies backoff / growth one or two optimizer steps late."""
+
+    def __init__(self, device, enabled: bool = True, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.enabled = enabled
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.good_steps = 0
+        self.n_steps = self.n_skipped = 0
+        self.pending = []           # (event, pinned host flag) of optimizer steps whose found_inf has not been read yet
+        if enabled:
+            self.flags = torch.zeros(8, dtype=torch.float32, device=device)      # ring: one slot per optimizer step in flight
+            self.slot = 0
+
+    def current(self) -> float:
+        """Scale for the backward pass that starts now (finished found_inf flags are folded in first, without blocking)."""
+        if self.enabled:
+            self._drain(block=False)
+        return self.scale
+
+    def _drain(self, block: bool) -> None:
+        while self.pending and (block or self.pending[0][0].query()):
+            ev, host = self.pending.pop(0)
+            ev.synchronize()
+            self.n_steps += 1
+            if host.item() != 0.0:
+                self.n_skipped += 1
+                self.scale *= self.backoff_factor
+                self.good_steps = 0
+            else:
+                self.good_steps += 1
+                if self.good_steps >= self.growth_interval:
+                    self.scale *= self.growth_factor
+                    self.good_steps = 0
+
+    def step(self, opt: "FlatAdamEMA", grad: Tensor, grad_scale: float, scale_used: float, update_ema: bool = True) -> None:
+        """GradScaler.step(optimizer) + update(): unscale, found_inf, (skipped) Adam step, flag queued for the scale update."""
+        if not self.enabled:
+            opt.step(grad, grad_scale, update_ema)
+            return
+        if len(self.pending) >= 6:
+            self._drain(block=True)
+        flag = self.flags[self.slot:self.slot + 1]
+        self.slot = (self.slot + 1) % 8
+        A.check(A.lib().srganfd_nonfinite_flag(grad.data_ptr(), grad.numel(), flag.data_ptr(), 0, A.stream_ptr()), "nonfinite_flag")
+        opt.step(grad, grad_scale / scale_used, update_ema, skip_flag=flag)
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host))
+
+    def report(self) -> dict:
+        if self.enabled:
+            self._drain(block=True)
+        return {"enabled": self.enabled, "scale": self.scale, "optimizer_steps": self.n_steps, "skipped": self.n_skipped}
+
+    def state_dict(self) -> dict:
+        """torch GradScaler.state_dict() keys (the reference does not checkpoint its scaler; kept for symmetry)."""
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self.good_steps}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.scale, self.good_steps = float(sd["scale"]), int(sd.get("_growth_tracker", 0))
+
+
+def needs_loss_scaling(*modules) -> bool:
+    return any(getattr(m, "compute_dtype", None) == torch.float16 for m in modules if m is not None)
 
 
 class FlatAdamEMA:
@@ -59,8 +139,9 @@ class FlatAdamEMA:
         named_parameters() order) ``step`` / ``exp_avg`` / ``exp_avg_sq``, and one param group."""
         m, v = self._views(self.m), self._views(self.v)
         state = {}
-        if self.t > 0:
-            state = {i: {"step": torch.tensor(float(self.t)), "exp_avg": m[i].detach().clone(), "exp_avg_sq": v[i].detach().clone()}
+        t = int(self.step_dev.item()) if self.step_dev is not None else self.t      # skipped (non-finite) steps count on the device only
+        if t > 0:
+            state = {i: {"step": torch.tensor(float(t)), "exp_avg": m[i].detach().clone(), "exp_avg_sq": v[i].detach().clone()}
                      for i in range(len(m))}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(m)))}
@@ -113,7 +194,11 @@ class FlatAdamEMA:
                     t.copy_(src)
         self.n_averaged = int(sd.get("n_averaged", 0))
 
-    def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True) -> None:
+    def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True, skip_flag: Optional[Tensor] = None) -> None:
+        """``skip_flag`` (device float, LossScaler): non-zero skips the update on the device; the step count then has to live on
+        the device too (a skipped step does not advance torch's ``state["step"]``), so the device-step kernel is used."""
+        if skip_flag is not None:
+            self.use_device_step()
         if self.layout is not None and self.layout.flat is not self.flat:
             raise A.SrganfdError("the module's flat parameter buffer was rebuilt (.to() / deepcopy) after this optimizer captured it: "
                                  "build the trainer after moving the module")
@@ -126,12 +211,13 @@ class FlatAdamEMA:
             A.check(A.lib().srganfd_adam_ema_dev(self.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                                  self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                                  self.betas[0], self.betas[1], self.eps, self.wd, self.step_dev.data_ptr(),
-                                                 self.bc_dev.data_ptr(), grad_scale, self.ema_decay or 0.0, mode, A.stream_ptr()), "adam_ema_dev")
+                                                 self.bc_dev.data_ptr(), grad_scale, self.ema_decay or 0.0, mode,
+                                                 skip_flag.data_ptr() if skip_flag is not None else None, A.stream_ptr()), "adam_ema_dev")
             return
         A.check(A.lib().srganfd_adam_ema(self.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale,
-                                         self.ema_decay or 0.0, mode, A.stream_ptr()), "adam_ema")
+                                         self.ema_decay or 0.0, mode, None, A.stream_ptr()), "adam_ema")
 
 
 class GeneratorTrainer:
@@ -145,6 +231,7 @@ class GeneratorTrainer:
         self.flat = self.eng.fp.sync(dev)
         self.opt = FlatAdamEMA(self.flat, lr, betas, eps, weight_decay, ema_decay, layout=self.eng.fp)
         self.loss_weight = loss_weight
+        self.scaler = LossScaler(dev, enabled=needs_loss_scaling(g_model))      # train_rrdbnet.py:94 / train_bsrnet.py:94
         self.pg = process_group
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
@@ -179,11 +266,12 @@ class GeneratorTrainer:
         if self.dsr is None or self.dsr.shape != sr.shape:
             self.dsr = torch.empty_like(sr)
         gt = gt.contiguous().float()
+        S = self.scaler.current()                       # scaler.scale(loss): the factor rides on the gradient seed
         A.check(A.lib().srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.loss_weight, self.loss_buf.data_ptr(), 0,
-                                        self.dsr.data_ptr(), self.loss_weight, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
+                                        self.dsr.data_ptr(), self.loss_weight * S, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
         grad, _ = eng.backward(sp, token, self.dsr, False)
         scale = allreduce_sum_(grad, self.pg)          # RCCL over xGMI: ONE flat 67 MB buffer per step
-        self.opt.step(grad, scale)
+        self.scaler.step(self.opt, grad, scale, S)     # scaler.step(optimizer); scaler.update(); ema update
         eng.fp.touch()                             # parameters changed behind autograd's back -> re-pack
         self.sr = sr
         return self.loss_buf

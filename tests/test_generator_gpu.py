@@ -3,7 +3,8 @@ C ABI) against the golden vectors captured from the reference (tests/golden/*.np
 
 Tolerances (relative to the tensor's max magnitude):
   f32 mode  (exact-fp32 MFMA): SR pixels / losses 1e-3 as BASELINE.json's north_star states (observed ~1e-5);
-  bf16 mode (the benchmark dtype): reported and bounded at 5e-2 -- 8-bit mantissa through >=30 chained convs.
+  f16 mode  (the benchmark dtype; the reference's autocast dtype): the same 1e-3;
+  bf16 mode: reported and bounded at 1.5e-2 -- 8-bit mantissa through >=30 chained convs.
 """
 import numpy as np
 import pytest
@@ -14,8 +15,11 @@ from tests.util import checksum, load_golden, scaled_init, table
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 1e-3, torch.bfloat16: 5e-2}
-GTOL = {torch.float32: 2e-3, torch.bfloat16: 1.5e-1}
+# SR / loss bounds.  f32 and f16 carry BASELINE.json's tolerance (1e-3); bf16 cannot (8-bit mantissa through 351 chained convs:
+# observed 5-7e-3 of the SR range) and is bounded at twice what is observed.  Gradients: f16 backward runs loss-scaled.
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1.5e-2, torch.float16: 1e-3}
+GTOL = {torch.float32: 2e-3, torch.bfloat16: 1.5e-1, torch.float16: 2e-2}
+LOSS_SCALE = {torch.float32: 1.0, torch.bfloat16: 1.0, torch.float16: 4096.0}   # what GradScaler does for the reference's fp16 autocast
 
 
 def _rel(a, b):
@@ -24,7 +28,7 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kind", ["rdb", "rrdb"])
 def test_blocks(golden_dir, dtype, kind):
     from sr_gan_fd_amd import model as M
@@ -62,7 +66,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("name,fac,kw,s,scale", CASES)
 def test_generator(golden_dir, dtype, name, fac, kw, s, scale):
     from sr_gan_fd_amd import model as M
@@ -80,11 +84,12 @@ def test_generator(golden_dir, dtype, name, fac, kw, s, scale):
     assert e < TOL[dtype]
     loss = torch.nn.functional.l1_loss(sr, gt)
     assert abs(loss.item() - float(g[f"{name}/loss"])) < TOL[dtype] * abs(float(g[f"{name}/loss"]))
-    loss.backward()
+    S = LOSS_SCALE[dtype]
+    (loss * S).backward()
     named = dict(net.named_parameters())
     worst = 0.0
     for k in ("conv1.weight", "conv4.weight", "conv4.bias", "trunk.0.rdb1.conv1.bias", "trunk.1.rdb3.conv5.bias", "conv2.bias"):
-        worst = max(worst, _rel(named[k].grad, g[f"{name}/grad/{k}"]))
+        worst = max(worst, _rel(named[k].grad / S, g[f"{name}/grad/{k}"]))
     print(f"{name} {dtype}: worst grad err {worst:.2e}")
     assert worst < GTOL[dtype]
     if dtype == torch.float32:
