@@ -586,9 +586,9 @@ int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t str
   if (mode == 0 || a->ksize != 3 || a->stride != 1 || !k.fast_epi || k.osy != 1 || k.osx != 1) return SRGANFD_OK;
   if (a->dtype != SRGANFD_BF16 && a->dtype != SRGANFD_F16) return SRGANFD_OK;
   if (mode >= 4 && a->cout > 512) return SRGANFD_OK;
-  // small launches keep conv_igemm's 8-row tiles: the 16-row grid has to fill two workgroups on each of the 256 CUs a few times over
-  const long long tiles16 = (long long)a->n * ceil_div(a->h_out, 16) * ceil_div(a->w_out, 32) * (a->cout / ((a->cout % 64) ? 32 : 64));
-  if ((tiles16 < 2048 || a->h_out < 64) && !force) return SRGANFD_OK;
+  // The choice depends on the IMAGE only, never on the batch: an image's pixels are then summed in the same order whatever batch it
+  // sits in (tests/test_fullsize_gpu.py checks that bitwise).  Small images keep conv_igemm's 8-row tiles.
+  if ((a->h_out < 64 || a->w_out < 64) && !force) return SRGANFD_OK;
   if (a->dtype == SRGANFD_BF16) return ring_dispatch<bf16_t>(a, k, stream, mode, handled);
   return ring_dispatch<f16_t>(a, k, stream, mode, handled);
 }
