@@ -214,7 +214,7 @@ int srganfd_bce_logits(const float* logits, int64_t numel, float target, float w
 int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, float* workspace, void* stream);
 
 /* ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132).
- * One power iteration in place on u, v when training; sigma = u^T W v; workspace >= rows+cols floats. */
+ * One power iteration in place on u, v when training; sigma = u^T W v; workspace >= ceil(rows / 32) * cols + rows floats. */
 int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols,
                           int32_t training, float eps, float* sigma_out, float* inv_sigma_out,
                           float* workspace, void* stream);

@@ -133,6 +133,7 @@ SYMBOLS = {
 }
 
 LOSS_WS_FLOATS = 2049
+SN_WS_FLOATS = 16 * 8192 + 1024        # srganfd_spectral_norm: ceil(rows / 32) * cols + rows for rows <= 512, cols <= 8192
 _lib = None
 
 

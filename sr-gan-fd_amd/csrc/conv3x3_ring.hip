@@ -576,7 +576,11 @@ static int ring_dispatch(const srganfd_conv_args* a, const ConvK& k, hipStream_t
 
 static int g_ring_mode_override = -1;
 extern int g_igemm_variant;
-extern "C" void srganfd_set_ring_mode(int mode) { g_ring_mode_override = mode; g_igemm_variant = (mode & 0xff) == 7 ? 7 : 0; }
+extern int g_wgrad_variant;
+extern "C" void srganfd_set_ring_mode(int mode) {
+  if (mode >= 0 && (mode & 0x1000)) { g_wgrad_variant = (mode >> 9) & 3; return; }      // A/B of the weight-gradient loop variants
+  g_ring_mode_override = mode; g_igemm_variant = (mode & 0xff) == 7 ? 7 : 0;
+}
 
 int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled) {
   *handled = false;

@@ -489,22 +489,31 @@ __global__ __launch_bounds__(256) void finish_sigmoid_mean_kernel(const float* _
 
 // ---- spectral norm (torch/nn/utils/spectral_norm.py:62-114 as applied at model.py:104-132) ----
 // W is (rows=Cout, cols=Cin*k*k) row-major fp32.
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw, int rows, int cols) {
+// W^T u in row chunks of kSnRows: block (x, y) sums rows [y*kSnRows, ...) of 256 columns into part[y][k]; the normalise kernel adds the
+// chunks in order (deterministic).  One thread per column over ALL rows left the chip with <= 18 workgroups for 71 us per layer.
+static constexpr int kSnRows = 32;
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ part, int rows, int cols) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= cols) return;
+  const int r0 = blockIdx.y * kSnRows, r1 = min(rows, r0 + kSnRows);
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += W[(size_t)r * cols + k] * u[r];
-  vraw[k] = s;
+  for (int r = r0; r < r1; ++r) s += W[(size_t)r * cols + k] * u[r];
+  part[(size_t)blockIdx.y * cols + k] = s;
 }
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float eps) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out, int n, float eps) {
+  __shared__ float sh[16];
   __shared__ float inv;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += in[i] * in[i];
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float v = 0.f;
+    for (int p = 0; p < nparts; ++p) v += part[(size_t)p * n + i];
+    out[i] = v;                      // raw W^T u, scaled in place below
+    s += v * v;
+  }
   const float r = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) inv = 1.f / fmaxf(sqrtf(r), eps);
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) out[i] = in[i] * inv;
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] *= inv;
 }
 __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ t, int rows, int cols) {
   __shared__ float sh[4];
@@ -1290,10 +1299,11 @@ int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStr
 // ws: cols + rows floats
 int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s) {
   if (!W || !u || !v || !sigma || !inv_sigma || !ws || rows <= 0 || cols <= 0) return set_err(SRGANFD_EINVAL, "spectral_norm: bad args");
-  float* vraw = ws; float* t = ws + cols;
+  const int nparts = (rows + kSnRows - 1) / kSnRows;
+  float* part = ws; float* t = ws + (size_t)nparts * cols;
   if (training) {
-    SRGANFD_LAUNCH(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, W, (const float*)u, vraw, rows, cols);
-    SRGANFD_LAUNCH(sn_normalize_kernel, dim3(1), dim3(256), 0, s, (const float*)vraw, v, cols, eps);
+    SRGANFD_LAUNCH(sn_wt_u_kernel, dim3((cols + 255) / 256, nparts), dim3(256), 0, s, W, (const float*)u, part, rows, cols);
+    SRGANFD_LAUNCH(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)part, nparts, v, cols, eps);
   }
   SRGANFD_LAUNCH(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, W, (const float*)v, t, rows, cols);
   SRGANFD_LAUNCH(sn_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)t, u, rows, eps, training, sigma, inv_sigma);

@@ -92,7 +92,9 @@ static constexpr int kLoaderWaves = 4;
 // (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, so the LDS image is lane-linear and the 64-byte-unit swizzle
 // is applied to the per-lane SOURCE address); tile t+1 lands while tile t is in the MFMA phase, one barrier per tile,
 // no staging registers.  DMA = 0: global -> register -> LDS staging through one buffer.
-template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
+// VAR (3x3 stride-1 16-bit only; srganfd_set_ring_mode bits 9-10 pick it for A/B runs): 0 = six transposed x reads per half row
+// (one pair per kernel column); 1 = three reads + register shifts (see the loop); 2 = variant 1 software-pipelined one half row ahead.
+template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
 __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) void wgrad_kernel(const WgK a) {
   constexpr int TH = WgTile<KS, STRIDE>::TH;
   constexpr int NTHR = 64 * WgWaves<KS>::NW;
@@ -317,6 +319,53 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       if (tile + a.S < a.ntiles) prefetch(tile + a.S);
     }
     if (W.active && !SRGANFD_DBG(a.dbg, 16)) {
+      if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 2) {
+        // software-pipelined form of the shifted-fragment loop: the five transposed reads of half row i+1 are issued before the
+        // three MFMAs of half row i (two named register sets, every index compile-time)
+        using Fr = typename FragAB<T>::type;
+        struct HalfRow { u32x2 lo, hi, nx, blo, bhi; };
+        auto rd = [&](int rr, int hh) __attribute__((always_inline)) -> HalfRow {
+          const int ro = W.ks_idx * rows_per + rr, prow = ro + ky;
+          const char* xb = ldsX + ((prow & 1) ? tabX[1][0] : tabX[0][0]) + prow * PC * xRowB + hh * 16 * xRowB;
+          const char* yb = ldsY + tabY + ro * 32 * dyRowB + hh * 16 * dyRowB;
+          HalfRow r;
+          r.blo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb)));
+          r.bhi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 4 * dyRowB)));
+          r.lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb)));
+          r.hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * xRowB)));
+          r.nx = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 8 * xRowB)));
+          return r;
+        };
+        auto fm = [&](const HalfRow& r) __attribute__((always_inline)) {
+          const u32x4 bq = {r.blo.x, r.blo.y, r.bhi.x, r.bhi.y};
+          if (W.bias_slab >= 0) {
+            float f8[8];
+            unpack8<T>(bq, f8);
+            bsum += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
+          }
+          const Fr bfrag = __builtin_bit_cast(Fr, bq);
+          const u32x4 f0 = {r.lo.x, r.lo.y, r.hi.x, r.hi.y};
+          const u32x4 f1 = {__builtin_amdgcn_alignbit(r.lo.y, r.lo.x, 16), __builtin_amdgcn_alignbit(r.hi.x, r.lo.y, 16),
+                            __builtin_amdgcn_alignbit(r.hi.y, r.hi.x, 16), __builtin_amdgcn_alignbit(r.nx.x, r.hi.y, 16)};
+          const u32x4 f2 = {r.lo.y, r.hi.x, r.hi.y, r.nx.x};
+          acc[0] = mfma32<T>(__builtin_bit_cast(Fr, f0), bfrag, acc[0]);
+          acc[1] = mfma32<T>(__builtin_bit_cast(Fr, f1), bfrag, acc[1]);
+          acc[2] = mfma32<T>(__builtin_bit_cast(Fr, f2), bfrag, acc[2]);
+        };
+        if (rows_per > 0) {
+          HalfRow ra = rd(0, 0);
+          for (int rr = 0; rr < rows_per; ++rr) {
+            const HalfRow rb = rd(rr, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rr + 1 < rows_per) ra = rd(rr + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(rb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
         if constexpr (sizeof(T) == 2) {
@@ -340,12 +389,31 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
               unpack8<T>(u32x4{l.x, l.y, h2.x, h2.y}, f8);
               bsum += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
             }
+            if constexpr (KS == 3 && STRIDE == 1 && VAR >= 1) {
+              // The three kernel columns read the SAME channel at pixels p, p+1, p+2: a lane's fragment for column dx is its
+              // 8-pixel run shifted by dx elements.  Three transposed reads (pixels p0..p0+11 of the lane's channel) replace six:
+              // dx = 2 is a whole-dword shift (register renaming), dx = 1 four v_alignbit_b32 -- 5 instead of 8 LDS reads per
+              // 3 MFMAs (the loop was LDS-read bound: 67 % of the LDS cycles at full MFMA rate, before the DMA fills).
+              const char* xb = ldsX + ax[0] + hh * 16 * xRowB;
+              const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb)));
+              const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * xRowB)));
+              const u32x2 nx = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 8 * xRowB)));
+              using Fr = typename FragAB<T>::type;
+              const u32x4 f0 = {lo.x, lo.y, hi.x, hi.y};
+              const u32x4 f1 = {__builtin_amdgcn_alignbit(lo.y, lo.x, 16), __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                                __builtin_amdgcn_alignbit(hi.y, hi.x, 16), __builtin_amdgcn_alignbit(nx.x, hi.y, 16)};
+              const u32x4 f2 = {lo.y, hi.x, hi.y, nx.x};
+              acc[0] = mfma32<T>(__builtin_bit_cast(Fr, f0), bfrag, acc[0]);
+              acc[1] = mfma32<T>(__builtin_bit_cast(Fr, f1), bfrag, acc[1]);
+              acc[2] = mfma32<T>(__builtin_bit_cast(Fr, f2), bfrag, acc[2]);
+            } else {
 #pragma unroll
-            for (int dx = 0; dx < KS; ++dx) {
-              const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
-              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
-              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
-              acc[dx] = mfma32<T>(cat_frag<T>(lo, hi), bfrag, acc[dx]);
+              for (int dx = 0; dx < KS; ++dx) {
+                const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
+                acc[dx] = mfma32<T>(cat_frag<T>(lo, hi), bfrag, acc[dx]);
+              }
             }
           }
         } else {
@@ -562,9 +630,11 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
   return SRGANFD_OK;
 }
 
-template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
-static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
-  auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP, DMA>;
+int g_wgrad_variant = 1;   // shifted fragments: same-box A/B 336.6 / 329.9 / 336.0 us for variants 0 / 1 / 2 (profiles/r02_wgrad_variants.txt)
+
+template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
+static int launch_wgrad4(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  auto kern = wgrad_kernel<T, KS, STRIDE, XP, YP, DMA, VAR>;
   static int attr_lds[64] = {0};   // per device: the attribute belongs to the device's code object
   const int lds = DMA ? 2 * H.lds_bytes : H.lds_bytes;
   if (!g_dry_run) {
@@ -578,6 +648,18 @@ static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
   SRGANFD_LAUNCH(kern, dim3(H.S * H.ngroups), dim3(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))), lds, stream, k);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
+}
+template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
+static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DMA) {
+    if (g_wgrad_variant == 1) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
+#ifdef SRGANFD_EXPERIMENT
+    if (g_wgrad_variant == 2) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 2>(H, k, stream);
+    if (g_wgrad_variant == 0) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
+#endif
+    return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
+  }
+  return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
 }
 template <typename T, int KS, int STRIDE, int XP, int YP>
 static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {

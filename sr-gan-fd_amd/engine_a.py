@@ -109,7 +109,7 @@ class AesrganDiscriminatorEngine:
             pk = self._build_pack(dtc, device)
             pk["flat_ptr"] = flat.data_ptr()
             pk["scalars"] = torch.ones(2 * len(SN_LAYERS), dtype=torch.float32, device=device)
-            pk["sn_ws"] = torch.empty(8192, dtype=torch.float32, device=device)
+            pk["sn_ws"] = torch.empty(A.SN_WS_FLOATS, dtype=torch.float32, device=device)
             self.packed[dtc] = pk
         return pk
 

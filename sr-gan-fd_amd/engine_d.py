@@ -82,7 +82,7 @@ class DiscriminatorEngine:
             pk = self._build_pack(dtc, device)
             pk["flat_ptr"] = flat.data_ptr()
             pk["scalars"] = torch.ones(2 * len(SN_LAYERS), dtype=torch.float32, device=device)
-            pk["sn_ws"] = torch.empty(512 * 16 + 4096 + 2048, dtype=torch.float32, device=device)
+            pk["sn_ws"] = torch.empty(A.SN_WS_FLOATS, dtype=torch.float32, device=device)
             self.packed[dtc] = pk
         return pk
 

@@ -1,0 +1,57 @@
+"""bench.py end to end on the GPU box: the self-launch path (--gpus N without torchrun's environment starts N ranks before any
+GPU call), the JSON contract of the single line rank 0 prints, and the refusal to report n_gpus it does not have."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--lr-size", "16", "--num-rrdb", "1", "--no-cpu-baseline"]
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+
+
+def _line(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_over_gloo():
+    """--gpus 2 with no WORLD_SIZE: two child ranks (sharing the box's one GPU, gloo collectives), one line, n_gpus == 2,
+    both workloads in it, weak scaling (global batch = 2 x per-GPU batch)."""
+    out = _run(["--gpus", "2", "--dist-backend", "gloo"] + SMALL)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+    assert r["steps"] == 2 and r["warmup"] == 1 and r["unit"] == "img/s" and r["value"] > 0 and r["dtype"] == "f16"
+    assert "gan" in r and r["gan"]["value"] > 0 and "roofline" in r and r["roofline"]["bound"] in ("hbm", "mfma")
+    for k in ("achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r["roofline"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """RCCL ranks need a GPU each: asking for more than the box has must fail loudly, not fall back to one rank."""
+    import torch
+    n = torch.cuda.device_count()
+    out = _run(["--gpus", str(n + 1)] + SMALL)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rejects_mismatched_world_size():
+    out = _run(["--gpus", "4"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0
+
+
+def test_bench_single_gpu_line():
+    out = _run(["--workload", "g_only", "--dtype", "bf16"] + SMALL)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 1 and r["dtype"] == "bf16" and "gan" not in r and r["config"]["workload"].startswith("BSRGAN RRDBNet x4 generator-only")
