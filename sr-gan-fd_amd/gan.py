@@ -20,7 +20,7 @@ from . import _abi as A
 from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
-from .parallel import allreduce_sum_
+from .parallel import SideStreamReducer, allreduce_sum_
 from .trainer import FlatAdamEMA, LossScaler, needs_loss_scaling
 
 
@@ -47,6 +47,7 @@ class GanTrainer:
         self.train_generator = train_generator
         self.generator_first = generator_first
         self.pg = process_group
+        self.d_reducer = SideStreamReducer(dev, process_group)      # D's gradient exchange + Adam beside the generator-side losses
         # [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt) prob, D(sr) prob]
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)
         self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
@@ -161,13 +162,16 @@ class GanTrainer:
         self._bce(sr_out, 0.0, 1.0, 1, 5, dl, Sd)
         gd2, _ = de.backward(de._last, de.token, dl, True, False)
         A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
-        self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd)      # scaler.step(d_optimizer); scaler.update()  (:436-437)
+        # scaler.step(d_optimizer); scaler.update()  (:436-437).  Under data parallelism the all-reduce and the Adam kernel go to a
+        # side stream: the pixel loss and the VGG-19 content forwards below do not read D's parameters
+        self.d_reducer.launch(lambda: self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd), tensors=(gd2,))
         # ---- generator ----
         Sg = self.scaler.current()                          # the scale after the discriminator's update()  (:463)
         dsr = self._buf("dsr", sr)
         A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw * Sg,
                                   self.ws.data_ptr(), st), "l1_loss")
         self._content(sr, gt)
+        self.d_reducer.wait()                               # D's updated parameters from here on
         adv_out = de.forward(sr, True)                      # updated D, SN state advances again (train_bsrgan.py:452)
         self._bce(adv_out, 1.0, self.aw, 3, None, dl, Sg)
         if self.train_generator:

@@ -44,6 +44,43 @@ def allreduce_sum_(flat_grad: torch.Tensor, pg) -> float:
     return 1.0 / dist.get_world_size(pg)
 
 
+class SideStreamReducer:
+    """All-reduce + optimizer step of one network on a side HIP stream, so that it overlaps whatever the main stream does next
+    that does not read that network's parameters (GAN iteration: the discriminator's 17.5 MB reduce + Adam run beside the
+    generator's pixel loss and the two VGG-19 forwards, train_bsrgan.py:436-452).  RCCL's ring over xGMI is per-link bound and
+    needs no compute units to speak of; the point is to take the exchange off the critical path, not to shorten it.
+
+        ev = reducer.launch(lambda: scaler.step(opt, grad, allreduce_sum_(grad, pg), S))   # enqueued behind the main stream's work
+        ...                                                                               # main stream: independent work
+        reducer.wait()                                                                    # before the first reader of the parameters
+
+    Single-process runs (pg is None) execute the function inline on the main stream: nothing to overlap, nothing to get wrong."""
+
+    def __init__(self, device, pg):
+        self.pg = pg
+        self.stream = torch.cuda.Stream(device=device) if pg is not None else None
+        self.event = None
+
+    def launch(self, fn, tensors=()) -> None:
+        """``tensors``: buffers allocated on the main stream that ``fn`` reads or writes (the flat gradient): the caching allocator
+        must not hand their memory out again before the side stream is done with it."""
+        if self.stream is None:
+            fn()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())        # the gradient is complete on the main stream first
+        for t in tensors:
+            t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            fn()                                                    # collective + Adam kernels go to the side stream (A.stream_ptr())
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+
+    def wait(self) -> None:
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+
+
 def broadcast_(flat: torch.Tensor, pg, src: int = 0) -> None:
     """Make parameters / optimizer state / spectral-norm buffers identical on every rank."""
     if pg is not None:

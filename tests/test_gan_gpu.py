@@ -499,3 +499,26 @@ def test_fused_gan_trainer_discriminator_learns():
     assert np.isfinite(hist).all()
     assert d_loss[-3:].mean() < d_loss[0] - 0.1 and d_loss[-1] < d_loss[12] < d_loss[0]      # steady descent from ~2 ln 2
     assert hist[-1, 4] > hist[-1, 5]                      # real scored above fake
+
+
+def test_side_stream_discriminator_update_equals_inline():
+    """Data-parallel runs put D's all-reduce + Adam on a side stream beside the pixel loss / VGG forwards (parallel.SideStreamReducer);
+    the iteration must not change by a bit: same two GAN iterations with the update inline and on the side stream (the collective
+    itself replaced by the identity: one rank)."""
+    from sr_gan_fd_amd.gan import GanTrainer
+    from sr_gan_fd_amd.parallel import SideStreamReducer
+    torch.manual_seed(11)
+    batches = [(torch.rand(2, 3, 16, 16).cuda(), torch.rand(2, 3, 64, 64).cuda()) for _ in range(2)]
+    outs = []
+    for side in (False, True):
+        gen, d = _build_gan(torch.float32)
+        tr = GanTrainer(gen, d, None)
+        if side:
+            tr.d_reducer = SideStreamReducer(torch.device("cuda"), pg="one-rank stand-in")
+            assert tr.d_reducer.stream is not None
+        sc = [tr.step(x, y).cpu().numpy().copy() for x, y in batches]
+        torch.cuda.synchronize()
+        outs.append((sc, tr.g_opt.flat.clone(), tr.d_opt.flat.clone(), tr.sr.clone()))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])

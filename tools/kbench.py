@@ -34,9 +34,9 @@ def make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask=False, res=False, up=0, 
 
 def _make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask, res, up):
     dtc = ops.DT[DT]
-    x = (torch.randn(n, h, w, xC, device='cuda') * 0.5).to(DT)
+    x = (torch.randn(n, h, w, xC, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.5)).to(DT)
     y = torch.empty(n, h << up, w << up, yC, device='cuda', dtype=DT)
-    wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
+    wt = torch.randn(cout, cin, 3, 3, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.05)
     wp = ops.pack_single(wt, dtc)
     kw, keep = {}, [x, y, wp]
     if mask:
