@@ -130,11 +130,17 @@ typedef struct {
   int32_t dtype, ksize;
   int32_t k, n;           /* packed K and N, multiples of 32 */
   int32_t nseg;
-  int32_t pad_;
+  int32_t layout;         /* 0: B fragments of v_mfma_f32_32x32x16; 1: of v_mfma_f32_16x16x32 -- what the 3x3 16-bit kernels with
+                             32-channel output tiles read while srganfd_get_mfma16() is 1 (ksize == 3, n % 64 != 0 operands only) */
   srganfd_pack_seg seg[5];
 } srganfd_pack_job;
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n);
+/* MFMA form of the 3x3 16-bit convolutions with 32-channel output tiles: 1 = v_mfma_f32_16x16x32 (default; environment
+ * SRGANFD_MFMA16=0 at load turns it off), 0 = v_mfma_f32_32x32x16.  Weights must be packed
+ * (layout field above) under the setting they are consumed with; switch before the first forward, or re-pack. */
+void srganfd_set_mfma16(int on);
+int srganfd_get_mfma16(void);
 /* max_elems = max over jobs of ksize*ksize*k*n (grid sizing; host knows it) */
 int srganfd_pack_weights(const srganfd_pack_job* jobs_dev, int32_t njobs, int64_t max_elems,
                          const float* params, const float* scalars, void* packed, void* stream);

@@ -46,7 +46,7 @@ class PackSeg(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [
         ("dst_off", C.c_int64), ("dtype", C.c_int32), ("ksize", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
-        ("nseg", C.c_int32), ("pad_", C.c_int32), ("seg", PackSeg * 5),
+        ("nseg", C.c_int32), ("layout", C.c_int32), ("seg", PackSeg * 5),
     ]
 
 
@@ -72,6 +72,8 @@ SYMBOLS = {
     "srganfd_abi_version": (C.c_int, []),
     "srganfd_set_dry_run": (None, [C.c_int]),
     "srganfd_set_ring_mode": (None, [C.c_int]),
+    "srganfd_set_mfma16": (None, [C.c_int]),
+    "srganfd_get_mfma16": (C.c_int, []),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_conv2d_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -27,6 +27,7 @@
 //   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32, an exact
 //     fp32 fma chain, used as the parity mode against the CPU oracle.
 #include "conv_common.hpp"
+#include <stdlib.h>
 #include <utility>
 namespace srganfd {
 // compile-time loop (indices as types), for the software-pipelined MFMA phase
@@ -74,9 +75,42 @@ struct ConvCfg {
 // pixel, dword index XOR (pix & 31) so 32 lanes reading one channel of 32 consecutive pixels hit 32 banks.
 __device__ __forceinline__ int lds_x_bf16_off(int pix, int c16) { return pix * 64 + ((c16 ^ ((pix >> 2) & 3)) << 4); }
 __device__ __forceinline__ int lds_x_f32_off(int pix, int k) { return pix * 128 + ((k ^ (pix & 31)) << 2); }
+// 16x16x32 form: lane l reads pixel (l & 15), 16-byte slot (l >> 4); slot XOR 2*((pix>>2)&1) gives every 16-lane group of
+// ds_read_b128 sixteen distinct slots of the 256-byte bank row for any patch alignment
+__device__ __forceinline__ int lds_x16_m16_off(int pix, int c16) { return pix * 64 + ((c16 ^ (((pix >> 2) & 1) << 1)) << 4); }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
+// accumulators of one wave: MR rows x 32 pixels x 32 channels = 16 floats per lane and row in both MFMA forms
+template <bool M16, int MR> struct AccSet;
+template <int MR> struct AccSet<false, MR> {
+  f32x16 a[MR];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[m][i] = 0.f;
+  }
+  __device__ __forceinline__ float get(int m, int e) const { return a[m][e]; }
+  static __device__ __forceinline__ int pixel(int e, int lane) { return mfma32_row(e, lane); }
+  static __device__ __forceinline__ int chan(int e, int lane) { return lane & 31; }
+};
+template <int MR> struct AccSet<true, MR> {
+  f32x4_t a[MR][2][2];     // [row][pixel half][channel half]
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[m][q >> 1][q & 1][i] = 0.f;
+  }
+  __device__ __forceinline__ float get(int m, int e) const { return a[m][(e >> 3) & 1][(e >> 2) & 1][e & 3]; }
+  static __device__ __forceinline__ int pixel(int e, int lane) { return 16 * ((e >> 3) & 1) + 4 * (lane >> 4) + (e & 3); }
+  static __device__ __forceinline__ int chan(int e, int lane) { return 16 * ((e >> 2) & 1) + (lane & 15); }
+};
+
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false>
 __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+  static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
   using Frag = typename FragAB<T>::type;
   constexpr int NTHR = C::NTHR;
@@ -118,7 +152,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   int ldsx0;
   {
     const int pix = tid / C::CPP, c16 = tid % C::CPP;
-    if constexpr (sizeof(T) == 2) ldsx0 = lds_x_bf16_off(pix, c16);
+    if constexpr (M16) ldsx0 = lds_x16_m16_off(pix, c16);
+    else if constexpr (sizeof(T) == 2) ldsx0 = lds_x_bf16_off(pix, c16);
     else ldsx0 = pix * 128;   // f32: per-dword XOR below
   }
   const u32x4* __restrict__ wgp = (const u32x4*)a.w + (size_t)nb * WN * a.nChunks * (C::WN_BYTES / 16);
@@ -184,11 +219,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     }
   };
 
-  f32x16 acc[MR];
-#pragma unroll
-  for (int m = 0; m < MR; ++m)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+  AccSet<M16, MR> A_;
+  A_.zero();
+  auto& acc = A_.a;
 
   // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
   const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
@@ -202,6 +235,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
 
     auto col_body = [&](int kx, int s) {
+      if constexpr (!M16) {
       Frag av[C::NROWS];
 #pragma unroll
       for (int rr = 0; rr < C::NROWS; ++rr) {
@@ -215,8 +249,34 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[m] = mfma32<T>(av[m * STRIDE + ky], bq, acc[m]);
       }
+      }
     };
-    if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MR == 2) {
+    if constexpr (M16) {
+      // one K step = the whole 32-channel chunk; per kernel column: (NROWS x 2 pixel halves) A fragments, (KS x 2 channel halves) B
+      const int l15 = lane & 15, sl = lane >> 4;
+      const int pixb = (wr * MR * STRIDE) * C::PC + l15 * STRIDE;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        Frag av[C::NROWS][2];
+#pragma unroll
+        for (int rr = 0; rr < C::NROWS; ++rr)
+#pragma unroll
+          for (int ph = 0; ph < 2; ++ph) av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + rr * C::PC + kx + 16 * ph * STRIDE, sl));
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            const Frag bq = *(const Frag*)(ldsWn + ((ky * KS + kx) * 2 + nh) * 64 * C::FRAGB);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+              for (int ph = 0; ph < 2; ++ph) acc[m][ph][nh] = mfma16<T>(av[m * STRIDE + ky][ph], bq, acc[m][ph][nh]);
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MR == 2) {
       // Software-pipelined fragment reads: the chunk's 42 ds_read_b128 and 36 MFMAs in one fixed issue order, every read kD
       // fragments ahead of the MFMA that consumes it (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> MFMA on two
       // fragment registers: each MFMA eats a full LDS round trip).  Same accumulation order as the plain loop below, so the
@@ -259,10 +319,10 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   }
 
   // ---- epilogue (see srganfd.h for the formula) ----
-  if (SRGANFD_DBG(a.dbg, 4)) { if (acc[0][0] == 123.456f) ((float*)a.y)[0] = 1.f; return; }
+  if (SRGANFD_DBG(a.dbg, 4)) { if (A_.get(0, 0) == 123.456f) ((float*)a.y)[0] = 1.f; return; }
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
-  const int co = (nb * WN + wn) * 32 + r;
+  const int cow = (nb * WN + wn) * 32;      // first output channel of this wave; element e of a lane sits at channel cow + chan(e, lane)
   if (a.fast_epi) {
     // (1) per-channel part (alpha, bias, activation, scale) on the accumulators -> fp32 LDS tile
     // [pixel][channel]; (2) 16 output bytes per lane: residuals / LeakyReLU' mask via 16-byte global
@@ -270,15 +330,16 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     float* tile = (float*)smem;
     __syncthreads();   // all waves are done with the staging buffers
     {
-      const float bv = a.bias ? a.bias[co] : 0.f;
+      // a lane's 16 values per row cover one channel (32x32 form) or two (16x16 form: elements 0-3 / 8-11 vs 4-7 / 12-15)
+      const float bv0 = a.bias ? a.bias[cow + A_.chan(0, lane)] : 0.f, bv1 = a.bias ? a.bias[cow + A_.chan(4, lane)] : 0.f;
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float v = alpha * acc[m][i] + bv;
+          float v = alpha * A_.get(m, i) + ((i >> 2) & 1 ? bv1 : bv0);
           if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
           else if (a.act == SRGANFD_ACT_RELU) v = fmaxf(v, 0.f);
-          tile[((wr * MR + m) * 32 + mfma32_row(i, lane)) * C::NB + wn * 32 + r] = v * a.post_scale;
+          tile[((wr * MR + m) * 32 + A_.pixel(i, lane)) * C::NB + wn * 32 + A_.chan(i, lane)] = v * a.post_scale;
         }
     }
     __syncthreads();
@@ -347,21 +408,20 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   const T* __restrict__ r1g = (const T*)a.r1;
   const T* __restrict__ r2g = (const T*)a.r2;
   const T* __restrict__ mg = (const T*)a.mask;
-  const bool cok = co < a.cout_store;
-  const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int oy = oy0 + wr * MR + m;
-    if (!cok || oy >= a.Hout) continue;
+    if (oy >= a.Hout) continue;
     const size_t imgp = (size_t)n * a.HoutF * a.WoutF;                       // pixels before this image
     const int prow = (oy * a.osy + a.ooy) * a.WoutF + a.oox;                   // pixel inside the image
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int ox = ox0 + mfma32_row(i, lane);
-      if (ox < a.Wout) {
+      const int ox = ox0 + A_.pixel(i, lane);
+      const int co = cow + A_.chan(i, lane);
+      if (ox < a.Wout && co < a.cout_store) {
         const int p = prow + ox * a.osx;
         auto at = [&](int Cs, int c0, int ps, int gs) -> size_t { const int cc = c0 + co; return imgp * Cs + (size_t)(p * ps + (cc >> 5) * gs + (cc & 31)); };
-        float v = alpha * acc[m][i] + bv;
+        float v = alpha * A_.get(m, i) + (a.bias ? a.bias[co] : 0.f);
         if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
         else if (a.act == SRGANFD_ACT_RELU) v = v > 0.f ? v : 0.f;
         v *= a.post_scale;
@@ -376,11 +436,11 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   }
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN>;
-  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d>", dtype_name<T>(), KS, STRIDE, MR, WR, WN); return SRGANFD_OK; }
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16>;
+  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : ""); return SRGANFD_OK; }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
   if (!g_dry_run) {
     int dev = 0;
@@ -402,11 +462,24 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
 }
 
 int g_igemm_variant = 0;
+// default 1 (environment SRGANFD_MFMA16=0 turns it off at load): same-process A/B on the dense-block shapes, 32-channel tiles,
+// 35.4 / 43.3 / 50.6 / 59.5 / 74.2 us on 32x32x16 -> 31.5 / 38.9 / 47.4 / 52.7 / 68.4 us on 16x16x32 (profiles/r02_kbench_mfma16.txt)
+int g_mfma16 = [] { const char* e = getenv("SRGANFD_MFMA16"); return e ? atoi(e) : 1; }();   // 2: the 64-channel tiles too (experiment)
 
 template <typename T>
 static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t s) {
   const bool wide = (a->cout % 64) == 0;
   constexpr bool bf = sizeof(T) == 2;
+  if constexpr (bf) {
+    if (g_mfma16 && a->ksize == 3 && !wide) {      // 32-channel 3x3 operands are then packed in the 16x16x32 B-fragment order (ops.pack_job)
+      if (a->stride == 1) return launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
+      if (a->stride == 2) return launch_conv<T, 3, 2, 1, 4, 1, true>(k, a->cout, s);
+    }
+    if (g_mfma16 == 2 && a->ksize == 3 && wide) {
+      if (a->stride == 1) return launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s);
+      if (a->stride == 2) return launch_conv<T, 3, 2, 1, 4, 2, true>(k, a->cout, s);
+    }
+  }
   if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
     if constexpr (bf) {
       if (a->ksize == 3 && g_igemm_variant == 7)   // experiment: 4 rows per wave (0.75 fragment reads per MFMA), register staging
@@ -487,7 +560,7 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   {
     bool handled = false;
-    const int rc = conv3x3_ring_try(a, k, stream, &handled);   // 3x3 stride-1 16-bit launches large enough to fill the chip
+    const int rc = g_mfma16 == 2 ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);   // 64-channel tiles of large images (32x32x16-order weights)
     if (rc != SRGANFD_OK || handled) return rc;
   }
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);

@@ -21,14 +21,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const srganfd_pack_job* __res
     const int tap = (int)(blk % KT); blk /= KT;
     const int chunk = (int)(blk % nChunks);
     const int ntile = (int)(blk / nChunks);
-    if (J.dtype != SRGANFD_F32) {   // bf16 / f16: same fragment order
+    int n_in = -1;
+    if (J.dtype != SRGANFD_F32 && J.layout == 1) {   // 16x16x32 B fragments: [channel half s][lane][8], k = 8*(lane>>4) + j
+      const int j = within & 7; lane = (within >> 3) & 63; s = within >> 9;
+      k_in = 8 * (lane >> 4) + j;
+      n_in = 16 * s + (lane & 15);
+    } else if (J.dtype != SRGANFD_F32) {   // bf16 / f16, 32x32x16: [k-step s][lane][8]
       const int j = within & 7; lane = (within >> 3) & 63; s = within >> 9;
       k_in = 16 * s + 8 * (lane >> 5) + j;
     } else {
       lane = within & 63; s = within >> 6;
       k_in = 2 * s + (lane >> 5);
     }
-    const int k = chunk * 32 + k_in, n = ntile * 32 + (lane & 31);
+    const int k = chunk * 32 + k_in, n = ntile * 32 + (n_in >= 0 ? n_in : (lane & 31));
     float v = 0.f;
     for (int g = 0; g < J.nseg; ++g) {
       const srganfd_pack_seg& S = J.seg[g];

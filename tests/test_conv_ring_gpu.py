@@ -110,7 +110,7 @@ def test_ring_conv_matches_torch_and_igemm(dtype, mode, case):
         ref = ref + rt(rr)
     try:
         got_buf, got_y2 = run(FORCE | mode)
-        old_buf, old_y2 = run(0)
+        old_buf, old_y2 = run(0)              # conv_igemm tiles (16x16x32 form for the 32-channel cases: the library default)
     finally:
         A.lib().srganfd_set_ring_mode(-1)
     take = (lambda bf, c0: _from_planar(bf, c0, cout)) if planar else (lambda bf, c0: bf[..., c0:c0 + cout].permute(0, 3, 1, 2))

@@ -41,6 +41,15 @@ def _nhwc(t, dtype, cbuf=None, c0=0):
     return buf.to(dtype).cuda()
 
 
+@pytest.fixture(params=[0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
+def mfma16(request):
+    """both MFMA forms of the 3x3 16-bit kernels (srganfd_set_mfma16; weights are packed under the same setting)"""
+    from sr_gan_fd_amd import _abi as A
+    A.lib().srganfd_set_mfma16(request.param)
+    yield request.param
+    A.lib().srganfd_set_mfma16(1)          # the library default
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
     dict(n=2, h=16, w=16, cin=64, cout=32, act=1, bias=True),
@@ -54,7 +63,7 @@ def _nhwc(t, dtype, cbuf=None, c0=0):
     dict(n=1, h=8, w=8, cin=64, cout=32, k=1, p=0, bias=True),              # 1x1
     dict(n=1, h=16, w=16, cin=64, cout=32, mask=True),                      # LeakyReLU' mask epilogue
 ])
-def test_conv2d_forward(dtype, case):
+def test_conv2d_forward(dtype, case, mfma16):
     from sr_gan_fd_amd import _abi as A, ops
     torch.manual_seed(1)
     dt = ops.DT[dtype]
@@ -103,7 +112,7 @@ def test_conv2d_forward(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv2d_dgrad_orientation(dtype):
+def test_conv2d_dgrad_orientation(dtype, mfma16):
     """weights packed with transposed=1 turn the same kernel into the data-gradient pass"""
     from sr_gan_fd_amd import _abi as A, ops
     torch.manual_seed(2)

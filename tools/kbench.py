@@ -37,15 +37,20 @@ def _make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask, res, up):
     x = (torch.randn(n, h, w, xC, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.5)).to(DT)
     y = torch.empty(n, h << up, w << up, yC, device='cuda', dtype=DT)
     wt = torch.randn(cout, cin, 3, 3, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.05)
+    A.lib().srganfd_set_mfma16(0)
     wp = ops.pack_single(wt, dtc)
-    kw, keep = {}, [x, y, wp]
+    A.lib().srganfd_set_mfma16(1)
+    wp16 = ops.pack_single(wt, dtc)             # the same weights in the 16x16x32 B-fragment order where the kernel wants it (mode 8)
+    A.lib().srganfd_set_mfma16(0)
+    kw, keep = {}, [x, y, wp, wp16]
     if mask:
         m = torch.randn(n, h, w, yC, device='cuda').to(DT); keep.append(m)
         kw.update(mask=A.view(m, c0=y0, planar=PLANAR))
     if res:
         kw.update(r1=A.view(x, c0=0, planar=PLANAR), r1_scale=1.0, post_scale=0.2)
     a = ops.conv_args(dtc, A.view(x, c0=x0, planar=PLANAR), A.view(y, c0=y0, planar=PLANAR), wp, n, h, w, cin, cout, act=A.ACT_NONE if res else A.ACT_LRELU, up=up, **kw)
-    return name, a, keep, 2.0 * n * (h << up) * (w << up) * 9 * cin * cout
+    a16 = ops.conv_args(dtc, A.view(x, c0=x0, planar=PLANAR), A.view(y, c0=y0, planar=PLANAR), wp16, n, h, w, cin, cout, act=A.ACT_NONE if res else A.ACT_LRELU, up=up, **kw)
+    return name, (a, a16), keep, 2.0 * n * (h << up) * (w << up) * 9 * cin * cout
 
 
 def time_one(a, reps):
@@ -75,10 +80,12 @@ if __name__ == "__main__":
     shapes = [s for s in shapes if ONLY in s[0]]
     res = {}
     for rnd in range(ROUNDS + 1):                      # round 0 = warm-up
-        for name, a, keep, fl in shapes:
+        for name, (a32, a16), keep, fl in shapes:
             for m in MODES:
                 for d in DBGS:
-                    L.srganfd_set_ring_mode(m)
+                    a = a16 if m == 8 else a32           # mode 8: conv_igemm on v_mfma_f32_16x16x32
+                    L.srganfd_set_mfma16(1 if m == 8 else 0)
+                    L.srganfd_set_ring_mode(0 if m == 8 else m)
                     if d or len(DBGS) > 1:
                         L.srganfd_set_debug(d)
                     if hasattr(a, "_kernel_label"):
@@ -88,6 +95,7 @@ if __name__ == "__main__":
                     if rnd:
                         res.setdefault((name, m, d, lab, fl), []).append(us)
     L.srganfd_set_ring_mode(-1)
+    L.srganfd_set_mfma16(1)
     for (name, m, d, lab, fl), v in res.items():
         v.sort()
         med = v[len(v) // 2]
