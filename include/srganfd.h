@@ -130,17 +130,20 @@ typedef struct {
   int32_t dtype, ksize;
   int32_t k, n;           /* packed K and N, multiples of 32 */
   int32_t nseg;
-  int32_t layout;         /* 0: B fragments of v_mfma_f32_32x32x16; 1: of v_mfma_f32_16x16x32 -- what the 3x3 16-bit kernels with
-                             32-channel output tiles read while srganfd_get_mfma16() is 1 (ksize == 3, n % 64 != 0 operands only) */
+  int32_t layout;         /* 0: B fragments of v_mfma_f32_32x32x16; 1: of v_mfma_f32_16x16x32 -- srganfd_pack_layout(dtype, ksize, n) says
+                             which one the consuming kernel reads under the current srganfd_set_mfma16 level */
   srganfd_pack_seg seg[5];
 } srganfd_pack_job;
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n);
-/* MFMA form of the 3x3 16-bit convolutions with 32-channel output tiles: 1 = v_mfma_f32_16x16x32 (default; environment
- * SRGANFD_MFMA16=0 at load turns it off), 0 = v_mfma_f32_32x32x16.  Weights must be packed
+/* MFMA form of the 16-bit convolutions: level 0 = v_mfma_f32_32x32x16 everywhere, 1 = v_mfma_f32_16x16x32 for the 3x3 kernels with
+ * 32-channel output tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default; environment SRGANFD_MFMA16 at load).
+ * Weights must be packed
  * (layout field above) under the setting they are consumed with; switch before the first forward, or re-pack. */
-void srganfd_set_mfma16(int on);
+void srganfd_set_mfma16(int level);
 int srganfd_get_mfma16(void);
+/* the `layout` a pack job must carry for an operand of this dtype / kernel size / packed output width n under the current setting */
+int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n);
 /* max_elems = max over jobs of ksize*ksize*k*n (grid sizing; host knows it) */
 int srganfd_pack_weights(const srganfd_pack_job* jobs_dev, int32_t njobs, int64_t max_elems,
                          const float* params, const float* scalars, void* packed, void* stream);

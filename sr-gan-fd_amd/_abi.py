@@ -74,6 +74,7 @@ SYMBOLS = {
     "srganfd_set_ring_mode": (None, [C.c_int]),
     "srganfd_set_mfma16": (None, [C.c_int]),
     "srganfd_get_mfma16": (C.c_int, []),
+    "srganfd_pack_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_conv2d_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -61,6 +61,7 @@ template <> __device__ __forceinline__ f32x4_t mfma16<bf16_t>(bf16x8 a, bf16x8 b
 template <> __device__ __forceinline__ f32x4_t mfma16<f16_t>(f16x8 a, f16x8 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+bool conv_uses_m16(int dtype, int ksize, int cout);
 extern int g_mfma16;   // 1: the 3x3 16-bit convolutions run on the 16x16x32 form (weights packed in its B-fragment order: srganfd_pack_job.layout)
 
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous range

@@ -462,22 +462,32 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
 }
 
 int g_igemm_variant = 0;
-// default 1 (environment SRGANFD_MFMA16=0 turns it off at load): same-process A/B on the dense-block shapes, 32-channel tiles,
-// 35.4 / 43.3 / 50.6 / 59.5 / 74.2 us on 32x32x16 -> 31.5 / 38.9 / 47.4 / 52.7 / 68.4 us on 16x16x32 (profiles/r02_kbench_mfma16.txt)
-int g_mfma16 = [] { const char* e = getenv("SRGANFD_MFMA16"); return e ? atoi(e) : 1; }();   // 2: the 64-channel tiles too (experiment)
+// MFMA form of the 16-bit kernels (srganfd_set_mfma16 / environment SRGANFD_MFMA16 at load): 0 = v_mfma_f32_32x32x16 everywhere,
+// 1 = 16x16x32 for the 3x3 kernels with 32-channel tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default).
+// Same-box A/B of the training steps (profiles/r02_mfma16_ab.txt): generator-only 78.3 (0) -> 72.7 (1) -> 69.4 ms (2), GAN 179.6 (1)
+// -> 173.1 ms (2); the chip runs these steps power-limited (1.2 kW, clock at 2.06 of 2.4 GHz) and holds a higher clock on this form.
+int g_mfma16 = [] { const char* e = getenv("SRGANFD_MFMA16"); return e ? atoi(e) : 3; }();
+
+// does the kernel that consumes a packed operand of this kernel size / output width read 16x16x32 B fragments?  (pack.hip asks too)
+bool conv_uses_m16(int dtype, int ksize, int cout) {
+  if (dtype == SRGANFD_F32 || g_mfma16 <= 0) return false;
+  if (g_mfma16 >= 3) return true;
+  return ksize == 3 && (g_mfma16 == 2 || (cout % 64) != 0);
+}
 
 template <typename T>
 static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t s) {
   const bool wide = (a->cout % 64) == 0;
   constexpr bool bf = sizeof(T) == 2;
   if constexpr (bf) {
-    if (g_mfma16 && a->ksize == 3 && !wide) {      // 32-channel 3x3 operands are then packed in the 16x16x32 B-fragment order (ops.pack_job)
-      if (a->stride == 1) return launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
-      if (a->stride == 2) return launch_conv<T, 3, 2, 1, 4, 1, true>(k, a->cout, s);
-    }
-    if (g_mfma16 == 2 && a->ksize == 3 && wide) {
-      if (a->stride == 1) return launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s);
-      if (a->stride == 2) return launch_conv<T, 3, 2, 1, 4, 2, true>(k, a->cout, s);
+    if (conv_uses_m16(a->dtype, a->ksize, a->cout)) {
+      if (a->ksize == 3 && a->stride == 1) return wide ? launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
+      if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1, true>(k, a->cout, s);
+      if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1, true>(k, a->cout, s);
+      if (a->ksize == 4 && a->stride == 2) return wide ? launch_conv<T, 4, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 4, 2, 1, 4, 1, true>(k, a->cout, s);
+      if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1, true>(k, a->cout, s);
+      if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1, true>(k, a->cout, s);
+      return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
     }
   }
   if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
@@ -560,7 +570,8 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   {
     bool handled = false;
-    const int rc = g_mfma16 == 2 ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);   // 64-channel tiles of large images (32x32x16-order weights)
+    // the LDS-DMA ring kernel (64-channel tiles of large images) reads 32x32x16-order weights: used where that form is selected
+    const int rc = conv_uses_m16(a->dtype, a->ksize, a->cout) ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);
     if (rc != SRGANFD_OK || handled) return rc;
   }
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);

@@ -42,10 +42,8 @@ class PackTable:
 def pack_job(dst_off: int, dtype: int, ksize: int, k: int, n: int, segs: Sequence[dict]) -> A.PackJob:
     j = A.PackJob()
     j.dst_off, j.dtype, j.ksize, j.k, j.n, j.nseg = dst_off, dtype, ksize, k, n, len(segs)
-    # B-fragment order of the MFMA form the kernel that consumes the operand runs: the 3x3 16-bit convs with 32-channel output tiles
-    # (n not a multiple of 64: same test as the dispatch in conv_igemm.hip) use v_mfma_f32_16x16x32 while srganfd_get_mfma16() is 1
-    m16 = A.lib().srganfd_get_mfma16()
-    j.layout = 1 if (ksize == 3 and dtype != A.F32 and m16 and (n % 64 != 0 or m16 == 2)) else 0
+    # B-fragment order of the MFMA form the consuming kernel runs (the library knows its own dispatch: srganfd_set_mfma16)
+    j.layout = A.lib().srganfd_pack_layout(dtype, ksize, n)
     assert 1 <= len(segs) <= 5 and dst_off % 16 == 0
     for i, s in enumerate(segs):
         g = j.seg[i]

@@ -51,6 +51,7 @@ def test_ring_conv_matches_torch_and_igemm(dtype, mode, case):
         pytest.skip("ring configurations 2-5 exist in -DSRGANFD_EXPERIMENT builds only (SRGANFD_LIB=build_exp/libsrganfd_exp.so)")
     torch.manual_seed(3)
     dt = ops.DT[dtype]
+    A.lib().srganfd_set_mfma16(0)      # the ring kernels read 32x32x16-order weights: pack and run both kernels under that setting
     n, h, w, cin, cout = case["n"], case["h"], case["w"], case["cin"], case["cout"]
     up, planar = case.get("up", 0), case["planar"]
     x = torch.randn(n, cin, h, w)
@@ -113,6 +114,7 @@ def test_ring_conv_matches_torch_and_igemm(dtype, mode, case):
         old_buf, old_y2 = run(0)              # conv_igemm tiles (16x16x32 form for the 32-channel cases: the library default)
     finally:
         A.lib().srganfd_set_ring_mode(-1)
+        A.lib().srganfd_set_mfma16(3)
     take = (lambda bf, c0: _from_planar(bf, c0, cout)) if planar else (lambda bf, c0: bf[..., c0:c0 + cout].permute(0, 3, 1, 2))
     got, old = take(got_buf, 32).double().cpu(), take(old_buf, 32).double().cpu()
     scale = ref.abs().max().item()

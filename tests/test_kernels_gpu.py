@@ -41,13 +41,13 @@ def _nhwc(t, dtype, cbuf=None, c0=0):
     return buf.to(dtype).cuda()
 
 
-@pytest.fixture(params=[0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
+@pytest.fixture(params=[0, 3], ids=["mfma32x32x16", "mfma16x16x32"])
 def mfma16(request):
     """both MFMA forms of the 3x3 16-bit kernels (srganfd_set_mfma16; weights are packed under the same setting)"""
     from sr_gan_fd_amd import _abi as A
     A.lib().srganfd_set_mfma16(request.param)
     yield request.param
-    A.lib().srganfd_set_mfma16(1)          # the library default
+    A.lib().srganfd_set_mfma16(3)          # the library default
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -39,7 +39,7 @@ def _make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask, res, up):
     wt = torch.randn(cout, cin, 3, 3, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.05)
     A.lib().srganfd_set_mfma16(0)
     wp = ops.pack_single(wt, dtc)
-    A.lib().srganfd_set_mfma16(1)
+    A.lib().srganfd_set_mfma16(3)
     wp16 = ops.pack_single(wt, dtc)             # the same weights in the 16x16x32 B-fragment order where the kernel wants it (mode 8)
     A.lib().srganfd_set_mfma16(0)
     kw, keep = {}, [x, y, wp, wp16]
@@ -84,7 +84,7 @@ if __name__ == "__main__":
             for m in MODES:
                 for d in DBGS:
                     a = a16 if m == 8 else a32           # mode 8: conv_igemm on v_mfma_f32_16x16x32
-                    L.srganfd_set_mfma16(1 if m == 8 else 0)
+                    L.srganfd_set_mfma16(3 if m == 8 else 0)
                     L.srganfd_set_ring_mode(0 if m == 8 else m)
                     if d or len(DBGS) > 1:
                         L.srganfd_set_debug(d)
@@ -95,7 +95,7 @@ if __name__ == "__main__":
                     if rnd:
                         res.setdefault((name, m, d, lab, fl), []).append(us)
     L.srganfd_set_ring_mode(-1)
-    L.srganfd_set_mfma16(1)
+    L.srganfd_set_mfma16(3)
     for (name, m, d, lab, fl), v in res.items():
         v.sort()
         med = v[len(v) // 2]
