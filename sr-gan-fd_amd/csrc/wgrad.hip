@@ -93,7 +93,8 @@ static constexpr int kLoaderWaves = 4;
 // is applied to the per-lane SOURCE address); tile t+1 lands while tile t is in the MFMA phase, one barrier per tile,
 // no staging registers.  DMA = 0: global -> register -> LDS staging through one buffer.
 // VAR (3x3 stride-1 16-bit only; srganfd_set_ring_mode bits 9-10 pick it for A/B runs): 0 = six transposed x reads per half row
-// (one pair per kernel column); 1 = three reads + register shifts (see the loop); 2 = variant 1 software-pipelined one half row ahead.
+// (one pair per kernel column); 1 = three reads + register shifts (see the loop); 2 = variant 1 software-pipelined one half row ahead;
+// 3 = v_mfma_f32_16x16x32 with the shifted fragments.
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
 __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) void wgrad_kernel(const WgK a) {
   constexpr int TH = WgTile<KS, STRIDE>::TH;
@@ -140,6 +141,15 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
+  // VAR 3 (v_mfma_f32_16x16x32): [kernel column][input-channel half][output-channel half], 48 registers like acc[3] above
+  f32x4_t acc16[3][2][2];
+  float bsum16[2] = {0.f, 0.f};
+  if constexpr (VAR == 3) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc16[q / 4][(q >> 1) & 1][q & 1][i] = 0.f;
+  }
 
   const int xItems = (PR * PC * CPU) << xu_sh;
   const int yItems = (TH * 32 * CPU) << yu_sh;
@@ -319,7 +329,51 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       if (tile + a.S < a.ntiles) prefetch(tile + a.S);
     }
     if (W.active && !SRGANFD_DBG(a.dbg, 16)) {
-      if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 2) {
+      if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 3) {
+        // v_mfma_f32_16x16x32: K = the 32 pixels of one tile row.  A (16 input channels x 32 pixels) and B (32 pixels x 16 output
+        // channels): lane group g = lane>>4 supplies / receives pixels 8g..8g+7, so each 16-lane group of a transposed read takes its
+        // own 4-pixel x 16-channel block.  Per row: 2 channel halves x 3 reads of x (pixels p0..p0+11 -> the three kernel columns by
+        // register shifts, as in variant 1), 2 x 2 reads of dy, 12 MFMAs of 16 cycles (= the 6 of 32 cycles of the other variants).
+        using Fr = typename FragAB<T>::type;
+        const int Lp = 8 * g16 + lq;                                   // this lane's address row inside the 32-pixel run
+        const int tx0 = Lp * xRowB + ((W.ci_rel ^ swz(xp_sh, Lp)) * UB) + lp * 8;        // patch-row parity 0 (row start = 0 mod 4)
+        const int tx1 = Lp * xRowB + ((W.ci_rel ^ swz(xp_sh, 2 + Lp)) * UB) + lp * 8;    // parity 1 (row start = 2 mod 4)
+        const int ty0 = Lp * dyRowB + ((W.co_rel ^ swz(yp_sh, Lp)) * UB) + lp * 8;
+        for (int rr = 0; rr < rows_per; ++rr) {
+          const int ro = W.ks_idx * rows_per + rr, prow = ro + ky;
+          const char* xb = ldsX + ((prow & 1) ? tx1 : tx0) + prow * PC * xRowB;
+          const char* yb = ldsY + ty0 + ro * 32 * dyRowB;
+          Fr bq[2];
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            const u32x2 blo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + nh * 32)));
+            const u32x2 bhi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + nh * 32 + 4 * dyRowB)));
+            const u32x4 b4 = {blo.x, blo.y, bhi.x, bhi.y};
+            if (W.bias_slab >= 0) {
+              float f8[8];
+              unpack8<T>(b4, f8);
+              bsum16[nh] += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
+            }
+            bq[nh] = __builtin_bit_cast(Fr, b4);
+          }
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + ch * 32)));
+            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + ch * 32 + 4 * xRowB)));
+            const u32x2 nx = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + ch * 32 + 8 * xRowB)));
+            const u32x4 f0 = {lo.x, lo.y, hi.x, hi.y};
+            const u32x4 f1 = {__builtin_amdgcn_alignbit(lo.y, lo.x, 16), __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                              __builtin_amdgcn_alignbit(hi.y, hi.x, 16), __builtin_amdgcn_alignbit(nx.x, hi.y, 16)};
+            const u32x4 f2 = {lo.y, hi.x, hi.y, nx.x};
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              acc16[0][ch][nh] = mfma16<T>(__builtin_bit_cast(Fr, f0), bq[nh], acc16[0][ch][nh]);
+              acc16[1][ch][nh] = mfma16<T>(__builtin_bit_cast(Fr, f1), bq[nh], acc16[1][ch][nh]);
+              acc16[2][ch][nh] = mfma16<T>(__builtin_bit_cast(Fr, f2), bq[nh], acc16[2][ch][nh]);
+            }
+          }
+        }
+      } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 2) {
         // software-pipelined form of the shifted-fragment loop: the five transposed reads of half row i+1 are issued before the
         // three MFMAs of half row i (two named register sets, every index compile-time)
         using Fr = typename FragAB<T>::type;
@@ -435,11 +489,30 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   }
   if (W.active && !SRGANFD_DBG(a.dbg, 4)) {
     float* slab = a.slabs + (size_t)(W.slab_base + split * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
+    if constexpr (VAR == 3) {
+      // D of 16x16x32: column = lane & 15 (output channel inside its half), row = 4 * (lane >> 4) + register (input channel)
+#pragma unroll
+      for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slab[(tl * 32 + 16 * ch + 4 * (lane >> 4) + i) * 32 + 16 * nh + (lane & 15)] = acc16[tl][ch][nh][i];
+      if (W.bias_slab >= 0) {
+        // a lane summed 8 of the row's 32 pixels of channel 16 * nh + (lane & 15): add the four lane groups, slots 0..31 = channels
+        float t0 = bsum16[0], t1 = bsum16[1];
+        t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
+        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+        a.bslabs[(size_t)(W.bias_slab + split * W.ks_n + W.ks_idx) * 64 + lane] = lane < 16 ? t0 : (lane < 32 ? t1 : 0.f);
+      }
+    } else {
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
       for (int i = 0; i < 16; ++i) slab[(tl * 32 + mfma32_row(i, lane)) * 32 + r] = acc[tl][i];
     if (W.bias_slab >= 0) a.bslabs[(size_t)(W.bias_slab + split * W.ks_n + W.ks_idx) * 64 + lane] = bsum;
+    }
   }
 }
 
@@ -630,7 +703,7 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
   return SRGANFD_OK;
 }
 
-int g_wgrad_variant = 1;   // shifted fragments: same-box A/B 336.6 / 329.9 / 336.0 us for variants 0 / 1 / 2 (profiles/r02_wgrad_variants.txt)
+int g_wgrad_variant = 3;   // same-box A/B (profiles/r02_wgrad_variants.txt): 336.6 / 329.9 / 336.0 us for variants 0 / 1 / 2; 343.4 -> 314.9 us for 1 -> 3
 
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
 static int launch_wgrad4(const WgHeader& H, const WgK& k, hipStream_t stream) {
@@ -653,11 +726,12 @@ template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
 static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DMA) {
     if (g_wgrad_variant == 1) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
+    if (g_wgrad_variant == 3) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 3>(H, k, stream);
 #ifdef SRGANFD_EXPERIMENT
     if (g_wgrad_variant == 2) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 2>(H, k, stream);
     if (g_wgrad_variant == 0) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
 #endif
-    return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
+    return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 3>(H, k, stream);
   }
   return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
 }
