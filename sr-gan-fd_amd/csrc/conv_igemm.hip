@@ -137,6 +137,13 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   // 64-bit per-image base (block-uniform, scalar registers) + 32-bit offsets inside the image (host-checked)
   const T* __restrict__ xg = (const T*)a.x + (size_t)n * a.Hin * a.Win * a.xC;
 
+  // 16x16x32 form, stride 1: the slot swizzle is keyed on the patch COLUMN, 2*((px>>2)&1).  What keeps a 16-lane read group
+  // conflict free is that the four lanes whose pixels are 4 apart (same 64-byte position of the 256-byte bank row) alternate
+  // their slot bit, and 4 columns apart they do whatever the row start is.  The fragment address is then lane term (3 kernel
+  // columns) + wave-uniform row offset + immediate, instead of one precomputed VGPR per (row, column, pixel half) -- those 24
+  // registers pushed the 64-channel kernel over its 128 and spilled a prefetch pointer (scratch reload + vmcnt(0) inside the loop).
+  constexpr bool kColSwz = M16 && STRIDE == 1;
+  int ldsxo[kColSwz ? C::XI : 1];
   // per-thread source offsets (elements) of the X staging items; -1 = zero padding
   int xoff[C::XI];
 #pragma unroll
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     const int item = tid + i * NTHR;
     const int pix = item / C::CPP, c16 = item % C::CPP;
     const int py = pix / C::PC, px = pix % C::PC;
+    if constexpr (kColSwz) ldsxo[i] = pix * 64 + ((c16 ^ (((px >> 2) & 1) << 1)) << 4);
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
     xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
@@ -182,7 +190,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   auto store_x = [&](int i, u32x4 v) {
     const int item = tid + i * NTHR;
     if (item < C::NX) {
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (kColSwz) {
+        *(u32x4*)(ldsX + ldsxo[i]) = v;
+      } else if constexpr (sizeof(T) == 2) {
         *(u32x4*)(ldsX + ldsx0 + i * (C::PIX_PER_I * C::PIXB)) = v;
       } else {
         const int pix = item / C::CPP, c16 = item % C::CPP;
@@ -255,14 +265,19 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
       // one K step = the whole 32-channel chunk; per kernel column: (NROWS x 2 pixel halves) A fragments, (KS x 2 channel halves) B
       const int l15 = lane & 15, sl = lane >> 4;
       const int pixb = (wr * MR * STRIDE) * C::PC + l15 * STRIDE;
+      const char* ldsXw = ldsX + (wr * MR * STRIDE) * C::PC * 64;        // this wave's first patch row (wave-uniform)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
         Frag av[C::NROWS][2];
+        const int colterm = (l15 + kx) * 64 + ((sl ^ ((((l15 + kx) >> 2) & 1) << 1)) << 4);     // stride 1: lane term of column kx
 #pragma unroll
         for (int rr = 0; rr < C::NROWS; ++rr)
 #pragma unroll
-          for (int ph = 0; ph < 2; ++ph) av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + rr * C::PC + kx + 16 * ph * STRIDE, sl));
+          for (int ph = 0; ph < 2; ++ph) {
+            if constexpr (kColSwz) av[rr][ph] = *(const Frag*)(ldsXw + colterm + (rr * C::PC + 16 * ph) * 64);
+            else av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + rr * C::PC + kx + 16 * ph * STRIDE, sl));
+          }
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
