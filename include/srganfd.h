@@ -274,6 +274,23 @@ int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int3
                           const float* gamma, const float* save, float* dgamma, float* dbeta, float acc,
                           float* workspace, void* stream);
 
+/* Data-parallel SyncBatchNorm (the reference wraps its BatchNorm discriminator in DistributedDataParallel without converting it,
+ * A-ESRGAN/model.py:233, so each rank normalises with its own statistics; this is the optional whole-batch form).
+ * Two-phase calls around one all-reduce of the first srganfd_batchnorm_partial_floats(c) floats of the workspace:
+ *   phase 1: this rank's partial sums ((sum x, sum x^2) forward, (sum dy, sum dy*xhat) backward) into `workspace`;
+ *   caller:  sums that table over the ranks (forward in place; backward into `workspace_global`, `workspace` keeps its own);
+ *   phase 2: statistics / dx coefficients from the summed table with total_npix = pixels of the whole batch, then the apply pass.
+ * dgamma/dbeta are this rank's sums (the gradient all-reduce adds the ranks).  c <= 256, training mode; `act` may be empty
+ * (ptr NULL) or the LeakyReLU(act_slope) output whose derivative is folded into dy; phase 0 = the single-call form. */
+int64_t srganfd_batchnorm_partial_floats(int32_t c);
+int srganfd_batchnorm_fwd_sync(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* save,
+                               float* workspace, float act_slope, int32_t phase, int64_t total_npix, void* stream);
+int srganfd_batchnorm_bwd_sync(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c,
+                               const float* gamma, const float* save, float* dgamma, float* dbeta, float acc, float* workspace,
+                               const float* workspace_global, srganfd_view act, float act_slope, int32_t phase, int64_t total_npix,
+                               void* stream);
+
 /* BatchNorm2d followed by LeakyReLU(act_slope) in one pass (ESRGAN/model.py:98-126: conv -> BatchNorm2d -> LeakyReLU(0.2));
  * backward takes `act` = that LeakyReLU's output and folds its derivative into dy.  Any channel count that splits into
  * blocks of 256 (last block a power-of-two number of 16-byte chunks); workspace as above for 256 channels. */

@@ -129,6 +129,11 @@ SYMBOLS = {
                                         C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_batchnorm_bwd": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_void_p, C.c_void_p]),
+    "srganfd_batchnorm_partial_floats": (C.c_int64, [C.c_int32]),
+    "srganfd_batchnorm_fwd_sync": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                             C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int64, C.c_void_p]),
+    "srganfd_batchnorm_bwd_sync": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                             C.c_void_p, C.c_void_p, View, C.c_float, C.c_int32, C.c_int64, C.c_void_p]),
     "srganfd_batchnorm_act_fwd": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                             C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "srganfd_batchnorm_act_bwd": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,

@@ -74,9 +74,12 @@ int sigmoid_impl(float* x, size_t n, hipStream_t s);
 int sigmoid_bwd_impl(const float* ds, const float* sg, float* out, size_t n, hipStream_t s);
 int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, srganfd_view dx, float* dgate, int dtype, size_t npix, int c, hipStream_t s);
 int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
-                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s);
+                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s, int phase = 0,
+                       size_t total_npix = 0);
 int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
-                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s);
+                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s, int phase = 0,
+                       const float* ws_global = nullptr, size_t total_npix = 0);
+long long batchnorm_partial_floats_impl(int c);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -290,6 +293,19 @@ int srganfd_batchnorm_act_fwd(srganfd_view x, srganfd_view y, int32_t dtype, int
                               float* workspace, float act_slope, void* stream) {
   return batchnorm_fwd_impl(x, y, dtype, (size_t)npix, c, gamma, beta, running_mean, running_var, momentum, eps, training, save, workspace,
                             act_slope, (hipStream_t)stream);
+}
+int64_t srganfd_batchnorm_partial_floats(int32_t c) { return batchnorm_partial_floats_impl(c); }
+int srganfd_batchnorm_fwd_sync(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, int32_t c, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* save, float* workspace, float act_slope,
+                               int32_t phase, int64_t total_npix, void* stream) {
+  return batchnorm_fwd_impl(x, y, dtype, (size_t)npix, c, gamma, beta, running_mean, running_var, momentum, eps, 1, save, workspace, act_slope,
+                            (hipStream_t)stream, phase, (size_t)total_npix);
+}
+int srganfd_batchnorm_bwd_sync(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
+                               const float* save, float* dgamma, float* dbeta, float acc, float* workspace, const float* workspace_global,
+                               srganfd_view act, float act_slope, int32_t phase, int64_t total_npix, void* stream) {
+  return batchnorm_bwd_impl(x, dy, dx, dtype, (size_t)npix, c, gamma, save, dgamma, dbeta, acc, workspace, act, act_slope, (hipStream_t)stream, phase,
+                            workspace_global, (size_t)total_npix);
 }
 int srganfd_batchnorm_bwd(srganfd_view x, srganfd_view dy, srganfd_view dx, int32_t dtype, int64_t npix, int32_t c, const float* gamma,
                           const float* save, float* dgamma, float* dbeta, float acc, float* workspace, void* stream) {

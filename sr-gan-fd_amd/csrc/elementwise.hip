@@ -889,15 +889,26 @@ __global__ __launch_bounds__(1024) void bn_fwd_finish_kernel(const float* __rest
   save[ch] = mean; save[c + ch] = invstd; save[2 * c + ch] = sc; save[3 * c + ch] = beta[ch] - mean * sc;
 }
 // dx = dy*A + x*B + C0 per channel; coefficient triple + parameter gradients from the partial sums
+// partial_global (data-parallel SyncBN, else NULL): the same table summed over the ranks.  The parameter gradients are this rank's
+// sums (the flat-gradient all-reduce adds the ranks later); the dx coefficients use the sums and the pixel count of the whole batch.
 __global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int c, float npix, const float* __restrict__ gamma,
-                                                             const float* __restrict__ save, float* dgamma, float* dbeta, float acc, float* __restrict__ coef) {
+                                                             const float* __restrict__ save, float* dgamma, float* dbeta, float acc, float* __restrict__ coef,
+                                                             const float* __restrict__ partial_global) {
   __shared__ float tot[2][256];
   bn_reduce_partials(partial, nblk, c, tot);
   const int ch = threadIdx.x;
+  float db = 0.f, dg = 0.f;
+  if (ch < c) {
+    db = tot[0][ch]; dg = tot[1][ch];
+    dgamma[ch] = dg + (acc != 0.f ? acc * dgamma[ch] : 0.f);
+    dbeta[ch] = db + (acc != 0.f ? acc * dbeta[ch] : 0.f);
+  }
+  if (partial_global) {
+    __syncthreads();
+    bn_reduce_partials(partial_global, nblk, c, tot);
+    if (ch < c) { db = tot[0][ch]; dg = tot[1][ch]; }
+  }
   if (ch >= c) return;
-  const float db = tot[0][ch], dg = tot[1][ch];
-  dgamma[ch] = dg + (acc != 0.f ? acc * dgamma[ch] : 0.f);
-  dbeta[ch] = db + (acc != 0.f ? acc * dbeta[ch] : 0.f);
   const float mean = save[ch], invstd = save[c + ch], gi = gamma[ch] * invstd;
   coef[ch] = gi;                                              // A
   coef[c + ch] = -gi * invstd * dg / npix;                    // B
@@ -1419,25 +1430,32 @@ int gate_mul_impl(int bwd, srganfd_view x, const float* gate, srganfd_view y, sr
   return SRGANFD_OK;
 }
 static constexpr int kBnBlocks = 1024;  // workspace: kBnBlocks * 2 * c floats (+ 3c for the backward coefficients)
+long long batchnorm_partial_floats_impl(int c) { return (long long)kBnBlocks * 2 * c; }
 static inline bool bn_chunks_ok(int dtype, int c) { const int cv = c / (dtype == SRGANFD_F32 ? 4 : 8); return cv > 0 && 256 % cv == 0; }
 static inline unsigned bn_grid(size_t npix, int dtype, int c) { const int lanes = 256 / (c / (dtype == SRGANFD_F32 ? 4 : 8)); return grid_for((npix + lanes - 1) / lanes, 1, 16384); }
 // Channels are processed in blocks of <= 256 (the statistics kernels map one thread to one channel); `save` is
 // [block][mean | invstd | scale | shift] and is only read back by batchnorm_bwd_impl with the same blocking.
 static inline srganfd_view sub_view(srganfd_view v, int cb) { if (v.ptr) v.c0 += cb; return v; }
+// phase (data-parallel SyncBN): 0 = statistics, finish and apply in one call; 1 = this rank's partial sums into ws only (the caller
+// all-reduces the first batchnorm_partial_floats(c) floats of ws over the ranks); 2 = finish + apply from ws with total_npix pixels.
 int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, const float* gamma, const float* beta, float* rm, float* rv,
-                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s) {
+                       float momentum, float eps, int training, float* save, float* ws, float act_slope, hipStream_t s, int phase = 0,
+                       size_t total_npix = 0) {
   if (!x.ptr || !y.ptr || !gamma || !beta || !rm || !rv || !save || !ws || c <= 0 || !vec_ok(dtype, c, {x, y}))
     return set_err(SRGANFD_EINVAL, "batchnorm_fwd: bad args (16-byte aligned views)");
+  if (phase && (c > 256 || !training)) return set_err(SRGANFD_EINVAL, "batchnorm_fwd: the two-phase form takes training mode and at most 256 channels");
+  const float count = (float)(phase == 2 ? total_npix : npix);
   for (int cb = 0; cb < c; cb += 256) {
     const int cc = c - cb < 256 ? c - cb : 256;
     if (!bn_chunks_ok(dtype, cc)) return set_err(SRGANFD_EINVAL, "batchnorm_fwd: channel block of %d is not a power-of-two number of 16-byte chunks", cc);
     const srganfd_view xs = sub_view(x, cb), ys = sub_view(y, cb);
     float* sv = save + 4 * cb;
-    if (training) {
+    if (training && phase != 2) {
       DISPATCH_T(dtype,
                  SRGANFD_LAUNCH(bn_partial_kernel<TT>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0, (const float*)nullptr, npix, cc, ws, (const void*)nullptr, 0, 0, 1.f));
     }
-    SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, beta + cb, rm + cb, rv + cb, momentum, eps, training, sv);
+    if (phase == 1) continue;
+    SRGANFD_LAUNCH(bn_fwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, count, gamma + cb, beta + cb, rm + cb, rv + cb, momentum, eps, training, sv);
     DISPATCH_T(dtype,
                SRGANFD_LAUNCH(chan_affine_kernel<TT>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)nullptr, 0, 0,
                               ys.ptr, ys.cstride, ys.c0, (const float*)(sv + 2 * cc), (const float*)nullptr, (const float*)(sv + 3 * cc), npix, cc, act_slope, (const void*)nullptr, 0, 0, 1.f));
@@ -1445,19 +1463,28 @@ int batchnorm_fwd_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, i
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
+// phase as in batchnorm_fwd_impl; phase 2 takes ws_global = the partial table summed over the ranks (ws keeps this rank's own)
 int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, size_t npix, int c, const float* gamma, const float* save,
-                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s) {
+                       float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s, int phase = 0,
+                       const float* ws_global = nullptr, size_t total_npix = 0) {
   if (!x.ptr || !dy.ptr || !dx.ptr || !gamma || !save || !dgamma || !dbeta || !ws || c <= 0 || !vec_ok(dtype, c, {x, dy, dx, act}))
     return set_err(SRGANFD_EINVAL, "batchnorm_bwd: bad args");
+  if (phase && c > 256) return set_err(SRGANFD_EINVAL, "batchnorm_bwd: the two-phase form takes at most 256 channels");
+  if (phase == 2 && !ws_global) return set_err(SRGANFD_EINVAL, "batchnorm_bwd: phase 2 needs the all-reduced table");
+  const float count = (float)(phase == 2 ? total_npix : npix);
   for (int cb = 0; cb < c; cb += 256) {
     const int cc = c - cb < 256 ? c - cb : 256;
     if (!bn_chunks_ok(dtype, cc)) return set_err(SRGANFD_EINVAL, "batchnorm_bwd: channel block of %d is not a power-of-two number of 16-byte chunks", cc);
     const srganfd_view xs = sub_view(x, cb), dys = sub_view(dy, cb), dxs = sub_view(dx, cb), as = sub_view(act, cb);
     const float* sv = save + 4 * cb;
     float* coef = ws + (size_t)kBnBlocks * 2 * cc;
-    DISPATCH_T(dtype,
-               SRGANFD_LAUNCH(bn_partial_kernel<TT>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope));
-    SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, (float)npix, gamma + cb, sv, dgamma + cb, dbeta + cb, acc, coef);
+    if (phase != 2) {
+      DISPATCH_T(dtype,
+                 SRGANFD_LAUNCH(bn_partial_kernel<TT>, dim3(kBnBlocks), dim3(256), 0, s, xs.ptr, xs.cstride, xs.c0, (const void*)dys.ptr, dys.cstride, dys.c0, sv, npix, cc, ws, (const void*)as.ptr, as.cstride, as.c0, act_slope));
+    }
+    if (phase == 1) continue;
+    SRGANFD_LAUNCH(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, kBnBlocks, cc, count, gamma + cb, sv, dgamma + cb, dbeta + cb, acc, coef,
+                   phase == 2 ? ws_global : (const float*)nullptr);
     DISPATCH_T(dtype,
                SRGANFD_LAUNCH(chan_affine_kernel<TT>, dim3(bn_grid(npix, dtype, cc)), dim3(256), 0, s, dys.ptr, dys.cstride, dys.c0, (const void*)xs.ptr, xs.cstride, xs.c0,
                               dxs.ptr, dxs.cstride, dxs.c0, (const float*)coef, (const float*)(coef + cc), (const float*)(coef + 2 * cc), npix, cc, 1.f, (const void*)as.ptr, as.cstride, as.c0, act_slope));

@@ -52,6 +52,7 @@ class AesrganDiscriminatorEngine:
         self.shapes = PlanCache()
         self.packed: Dict[int, dict] = {}
         self.token = 0
+        self.sync_bn = None   # data parallel: SyncBatchNormReduce -- batch statistics over all ranks (set by GanTrainer(sync_batchnorm=True))
 
     def _poff(self, n):
         return self.fp.off(n)
@@ -155,6 +156,7 @@ class AesrganDiscriminatorEngine:
         B["b3"], B["x4"], B["b4"], B["x5"], B["b5"] = new(*R[2], 8 * nf), new(*R[2], 4 * nf), new(*R[1], 4 * nf), new(*R[1], 2 * nf), new(*R[0], 2 * nf)
         B["x6"], B["c7"], B["c8"] = new(*R[0], nf), new(*R[0], nf), new(*R[0], nf)
         sp.bn_ws = torch.empty(2048 * 256 + 3 * 256, dtype=torch.float32, device=device)
+        sp.bn_ws_global = None
         lre = dict(act=A.ACT_LRELU, slope=0.2)
         cv = lambda *a, **k: ("conv", ops.conv_args(dtc, *a, **k))
         call = lambda fn: ("call", fn)
@@ -391,8 +393,17 @@ class AesrganDiscriminatorEngine:
                 k, xv, yv, npix, Ck, gamma, beta, bn, save = item
                 if bn.running_mean.device != dev:
                     raise A.SrganfdError("BatchNorm buffers must live on the module's GPU")
-                A.check(L.srganfd_batchnorm_fwd(xv, yv, dtc, npix, Ck, gamma, beta, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                                bn.momentum, bn.eps, 1 if training else 0, save.data_ptr(), sp.bn_ws.data_ptr(), st), "batchnorm_fwd")
+                if training and self.sync_bn is not None:
+                    # (sum x, sum x^2) of this rank's pixels -> summed over the ranks -> statistics of the whole batch (pixel count = ranks * npix)
+                    sb, ws = self.sync_bn, sp.bn_ws
+                    args = (xv, yv, dtc, npix, Ck, gamma, beta, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.momentum, bn.eps,
+                            save.data_ptr(), ws.data_ptr(), 1.0)
+                    A.check(L.srganfd_batchnorm_fwd_sync(*args, 1, 0, st), "batchnorm_fwd_sync")
+                    sb.all_reduce(ws[:L.srganfd_batchnorm_partial_floats(Ck)])
+                    A.check(L.srganfd_batchnorm_fwd_sync(*args, 2, npix * sb.world, st), "batchnorm_fwd_sync")
+                else:
+                    A.check(L.srganfd_batchnorm_fwd(xv, yv, dtc, npix, Ck, gamma, beta, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                    bn.momentum, bn.eps, 1 if training else 0, save.data_ptr(), sp.bn_ws.data_ptr(), st), "batchnorm_fwd")
                 if training:
                     bn.num_batches_tracked += 1
             else:
@@ -443,9 +454,24 @@ class AesrganDiscriminatorEngine:
                                                          0.0, sp.sn_ws.data_ptr(), st), "spectral_norm_grad")
             elif kind == "bn_bwd":
                 xv, dyv, dxv, npix, Ck, pre, save = item[1]
-                A.check(L.srganfd_batchnorm_bwd(xv, dyv, dxv, dtc, npix, Ck, flat.data_ptr() + 4 * self._poff(pre + ".W.1.weight"), save.data_ptr(),
-                                                flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.weight"),
-                                                flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.bias"), 0.0, sp.bn_ws.data_ptr(), st), "batchnorm_bwd")
+                if self.sync_bn is not None:
+                    # dgamma/dbeta stay this rank's sums (the flat-gradient all-reduce averages them with everything else); the
+                    # dx coefficients need (sum dy, sum dy*xhat) over the whole batch
+                    sb, ws = self.sync_bn, sp.bn_ws
+                    nfl = L.srganfd_batchnorm_partial_floats(Ck)
+                    if sp.bn_ws_global is None:
+                        sp.bn_ws_global = torch.empty(L.srganfd_batchnorm_partial_floats(256), dtype=torch.float32, device=ws.device)
+                    args = (xv, dyv, dxv, dtc, npix, Ck, flat.data_ptr() + 4 * self._poff(pre + ".W.1.weight"), save.data_ptr(),
+                            flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.weight"), flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.bias"),
+                            0.0, ws.data_ptr(), sp.bn_ws_global.data_ptr(), A.NULL_VIEW, 1.0)
+                    A.check(L.srganfd_batchnorm_bwd_sync(*args, 1, 0, st), "batchnorm_bwd_sync")
+                    sp.bn_ws_global[:nfl].copy_(ws[:nfl])
+                    sb.all_reduce(sp.bn_ws_global[:nfl])
+                    A.check(L.srganfd_batchnorm_bwd_sync(*args, 2, npix * sb.world, st), "batchnorm_bwd_sync")
+                else:
+                    A.check(L.srganfd_batchnorm_bwd(xv, dyv, dxv, dtc, npix, Ck, flat.data_ptr() + 4 * self._poff(pre + ".W.1.weight"), save.data_ptr(),
+                                                    flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.weight"),
+                                                    flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.bias"), 0.0, sp.bn_ws.data_ptr(), st), "batchnorm_bwd")
             else:
                 item[1]()
         dx = None

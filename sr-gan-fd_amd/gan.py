@@ -20,7 +20,7 @@ from . import _abi as A
 from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
-from .parallel import SideStreamReducer, allreduce_sum_
+from .parallel import SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
 from .trainer import FlatAdamEMA, LossScaler, needs_loss_scaling
 
 
@@ -28,7 +28,7 @@ class GanTrainer:
     def __init__(self, g_model, d_model, content_criterion=None, *, g_lr: float = 8e-5, d_lr: float = 2e-4, betas=(0.9, 0.999),
                  eps: float = 1e-4, weight_decay: float = 0.0, ema_decay: float = 0.999, pixel_weight: float = 20.0,
                  content_weight=1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None,
-                 generator_first: bool = False):
+                 generator_first: bool = False, sync_batchnorm: bool = False):
         # defaults = BSRGAN/bsrgan_config.py:137-159
         self.g, self.d, self.content = g_model, d_model, content_criterion
         # either discriminator of the reference: DiscriminatorUNet (BSRGAN / Real-ESRGAN) or the A-ESRGAN attention U-Net
@@ -48,6 +48,11 @@ class GanTrainer:
         self.generator_first = generator_first
         self.pg = process_group
         self.d_reducer = SideStreamReducer(dev, process_group)      # D's gradient exchange + Adam beside the generator-side losses
+        if sync_batchnorm:
+            # A-ESRGAN's attention blocks carry BatchNorm2d (A-ESRGAN/model.py:233): whole-batch statistics across the ranks
+            if not hasattr(self.de, "sync_bn"):
+                raise ValueError("sync_batchnorm: this discriminator has no BatchNorm layers served by the two-phase kernels")
+            self.de.sync_bn = SyncBatchNormReduce(process_group)
         # [d_loss_hr, d_loss_sr, pixel, adversarial, D(gt) prob, D(sr) prob]
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)
         self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)

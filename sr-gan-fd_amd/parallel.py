@@ -1,8 +1,11 @@
 """Data parallelism: one process per GPU (torchrun), RCCL over xGMI (backend "nccl" on ROCm).
 
 The reference has no distributed code; the step is data-parallel by construction: every
-loss is a mean over independent images and no layer mixes samples (no BatchNorm; spectral-norm u/v
-depend on the weights only), so equal shards + one gradient all-reduce(sum) x 1/world is exact.
+loss is a mean over independent images and no layer of the benchmarked networks mixes samples (spectral-norm
+u/v depend on the weights only), so equal shards + one gradient all-reduce(sum) x 1/world is exact.  The
+BatchNorm discriminators (A-ESRGAN/model.py:233, ESRGAN/model.py:98-126) are the exception: per-rank batch
+statistics are what DistributedDataParallel would give the unconverted reference; SyncBatchNormReduce below
+is the opt-in whole-batch form (statistics identical to one process holding the full batch).
 Exchange steps per iteration: D's flat gradient (17.5 MB fp32) after its second backward, G's flat
 gradient (66.8 MB fp32) after its backward -- two large collectives, sized for per-link-bound xGMI
 rings, instead of per-tensor buckets.  The 1/world factor is folded into the Adam kernel.
@@ -44,6 +47,20 @@ def allreduce_sum_(flat_grad: torch.Tensor, pg) -> float:
     return 1.0 / dist.get_world_size(pg)
 
 
+class SyncBatchNormReduce:
+    """Sums a BatchNorm partial-sum table over the ranks between the two phases of srganfd_batchnorm_{fwd,bwd}_sync
+    (include/srganfd.h): (sum x, sum x^2) forward, (sum dy, sum dy*xhat) backward, 2 * 1024 * C floats each (2 MB at 256 channels).
+    Every rank holds the same number of pixels (equal shards), so the whole-batch pixel count is world * npix."""
+
+    def __init__(self, pg):
+        self.pg = pg
+        self.world = dist.get_world_size(pg) if pg is not None else 1
+
+    def all_reduce(self, table: torch.Tensor) -> None:
+        if self.pg is not None:
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.pg)
+
+
 class SideStreamReducer:
     """All-reduce + optimizer step of one network on a side HIP stream, so that it overlaps whatever the main stream does next
     that does not read that network's parameters (GAN iteration: the discriminator's 17.5 MB reduce + Adam run beside the
@@ -58,7 +75,8 @@ class SideStreamReducer:
 
     def __init__(self, device, pg):
         self.pg = pg
-        self.stream = torch.cuda.Stream(device=device) if pg is not None else None
+        # the dry-run host tests drive the trainers with CPU tensors over gloo: no stream there, the exchange runs inline
+        self.stream = torch.cuda.Stream(device=device) if pg is not None and torch.device(device).type == "cuda" else None
         self.event = None
 
     def launch(self, fn, tensors=()) -> None:

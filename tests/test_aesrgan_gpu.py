@@ -91,6 +91,100 @@ def test_batchnorm_and_gate():
     assert _rel(dgate.view(n, 1, h, w), g.grad) < 1e-5
 
 
+def test_sync_batchnorm_two_rank_emulation():
+    """Two ranks holding half the batch each, the all-reduce emulated by adding their partial tables: the two-phase kernels
+    (srganfd_batchnorm_{fwd,bwd}_sync) reproduce the full-batch output, running statistics and dx on both halves, and the
+    two ranks' dgamma/dbeta add up to the full-batch parameter gradients (what the gradient all-reduce then sums)."""
+    from sr_gan_fd_amd import _abi as A
+    torch.manual_seed(3)
+    n, c, h, w = 4, 64, 12, 20
+    L, st = A.lib(), A.stream_ptr()
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(n, c, h, w) * 2 + 0.7).requires_grad_(True)
+    y = bn(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    nfl = L.srganfd_batchnorm_partial_floats(c)
+    assert nfl == 2 * 1024 * c
+    gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    half = n // 2
+    npix = half * h * w
+    ranks = []
+    for r in range(2):
+        xa = x.detach()[r * half:(r + 1) * half].permute(0, 2, 3, 1).contiguous().cuda()
+        dya = dy[r * half:(r + 1) * half].permute(0, 2, 3, 1).contiguous().cuda()
+        ranks.append(dict(x=xa, dy=dya, y=torch.empty_like(xa), dx=torch.empty_like(xa), rm=torch.zeros(c, device="cuda"), rv=torch.ones(c, device="cuda"),
+                          save=torch.empty(4 * c, device="cuda"), ws=torch.empty(2048 * 256 + 768, device="cuda"), wsg=torch.empty(nfl, device="cuda"),
+                          dg=torch.empty(c, device="cuda"), db=torch.empty(c, device="cuda")))
+
+    def fwd(R, phase, total):
+        A.check(L.srganfd_batchnorm_fwd_sync(A.view(R["x"]), A.view(R["y"]), A.F32, npix, c, gam.data_ptr(), bet.data_ptr(), R["rm"].data_ptr(), R["rv"].data_ptr(),
+                                             0.1, 1e-5, R["save"].data_ptr(), R["ws"].data_ptr(), 1.0, phase, total, st))
+
+    def bwd(R, phase, total):
+        A.check(L.srganfd_batchnorm_bwd_sync(A.view(R["x"]), A.view(R["dy"]), A.view(R["dx"]), A.F32, npix, c, gam.data_ptr(), R["save"].data_ptr(), R["dg"].data_ptr(),
+                                             R["db"].data_ptr(), 0.0, R["ws"].data_ptr(), R["wsg"].data_ptr(), A.NULL_VIEW, 1.0, phase, total, st))
+
+    for R in ranks:
+        fwd(R, 1, 0)
+    tot = ranks[0]["ws"][:nfl] + ranks[1]["ws"][:nfl]          # the all-reduce
+    for R in ranks:
+        R["ws"][:nfl] = tot
+        fwd(R, 2, 2 * npix)
+    for R in ranks:
+        bwd(R, 1, 0)
+    tot = ranks[0]["ws"][:nfl] + ranks[1]["ws"][:nfl]
+    for R in ranks:
+        R["wsg"].copy_(tot)
+        bwd(R, 2, 2 * npix)
+    torch.cuda.synchronize()
+    yy = torch.cat([R["y"] for R in ranks]).permute(0, 3, 1, 2)
+    dxx = torch.cat([R["dx"] for R in ranks]).permute(0, 3, 1, 2)
+    assert _rel(yy, y) < 1e-5
+    assert _rel(dxx, x.grad) < 1e-4
+    for R in ranks:
+        assert _rel(R["rm"], bn.running_mean) < 1e-5 and _rel(R["rv"], bn.running_var) < 1e-5
+    assert _rel(ranks[0]["dg"] + ranks[1]["dg"], bn.weight.grad) < 1e-4
+    assert _rel(ranks[0]["db"] + ranks[1]["db"], bn.bias.grad) < 1e-4
+    # and the statistics differ from what each half alone would give (the test would pass vacuously otherwise)
+    own = x.detach()[:half].mean(dim=(0, 2, 3))
+    assert (own - x.detach().mean(dim=(0, 2, 3))).abs().max() > 1e-3
+    # single-rank group: the two-phase path of the engine equals the single-call path
+    with pytest.raises(A.SrganfdError):
+        A.check(L.srganfd_batchnorm_bwd_sync(A.view(ranks[0]["x"]), A.view(ranks[0]["dy"]), A.view(ranks[0]["dx"]), A.F32, npix, c, gam.data_ptr(),
+                                             ranks[0]["save"].data_ptr(), ranks[0]["dg"].data_ptr(), ranks[0]["db"].data_ptr(), 0.0, ranks[0]["ws"].data_ptr(),
+                                             None, A.NULL_VIEW, 1.0, 2, 2 * npix, st))
+
+
+def test_sync_batchnorm_engine_path_world_one():
+    """The discriminator engine with the two-phase BatchNorm path on a one-rank group gives the single-call results"""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.engine_a import aesrgan_engine
+    from sr_gan_fd_amd.parallel import SyncBatchNormReduce
+    torch.manual_seed(0)
+    d = M.UNetDiscriminatorAesrgan(3).cuda().train()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    e = aesrgan_engine(d)
+    import copy
+    sd = copy.deepcopy(d.state_dict())      # spectral-norm u/v and the running statistics move with every training forward
+    outs = []
+    for sync in (None, SyncBatchNormReduce(None)):
+        e.sync_bn = sync
+        d.load_state_dict(sd)
+        for p in d.parameters():
+            p.grad = None
+        y = d(x)
+        y.mean().backward()
+        outs.append((y.detach().clone(), torch.cat([p.grad.flatten() for p in d.parameters()]).clone(),
+                     torch.cat([m.running_var for m in d.modules() if isinstance(m, torch.nn.BatchNorm2d)]).clone()))
+    e.sync_bn = None
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_aesrgan_discriminator(golden_dir, dtype):
     from sr_gan_fd_amd import model as M

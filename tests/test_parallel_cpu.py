@@ -119,7 +119,15 @@ def test_trainers_exchange_one_flat_gradient_per_network():
     procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = []
+    import queue, time
+    t0 = time.time()
+    while len(res) < len(procs) and time.time() - t0 < 300:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: " + str([p.exitcode for p in procs])
+    assert len(res) == len(procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
