@@ -33,7 +33,10 @@ class LossScaler:
     Differences in mechanics, not in arithmetic: the loss is never materialised scaled -- the factor multiplies the gradient
     seeds that the loss kernels emit; the unscale is the Adam kernel's ``grad_scale``; found_inf is one reduction over the flat
     (already all-reduced: every rank sees the same value) gradient; the skip happens on the device (``skip_flag``), so the host
-    never waits for the flag -- it reads it back asynchronously and applies backoff / growth one or two optimizer steps late."""
+    never waits for a fresh flag -- it reads it back asynchronously and applies backoff / growth exactly ``LAG`` optimizer steps
+    late.  The lag is a fixed count, not "whatever has arrived": under data parallelism every rank must fold the same flags in
+    before the same backward pass, or for one iteration the ranks would seed their gradients with different scales."""
+    LAG = 2
 
     def __init__(self, device, enabled: bool = True, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
                  growth_interval: int = 2000):
@@ -50,11 +53,12 @@ class LossScaler:
     def current(self) -> float:
         """Scale for the backward pass that starts now (finished found_inf flags are folded in first, without blocking)."""
         if self.enabled:
-            self._drain(block=False)
+            self._drain(self.LAG)
         return self.scale
 
-    def _drain(self, block: bool) -> None:
-        while self.pending and (block or self.pending[0][0].query()):
+    def _drain(self, keep: int) -> None:
+        """Fold in every flag but the newest ``keep`` (blocking on steps that old costs nothing: they finished long ago)."""
+        while len(self.pending) > keep:
             ev, host = self.pending.pop(0)
             ev.synchronize()
             self.n_steps += 1
@@ -74,7 +78,7 @@ class LossScaler:
             opt.step(grad, grad_scale, update_ema)
             return
         if len(self.pending) >= 6:
-            self._drain(block=True)
+            raise RuntimeError("LossScaler: step() without current() -- the scale must be read before every backward pass")
         flag = self.flags[self.slot:self.slot + 1]
         self.slot = (self.slot + 1) % 8
         A.check(A.lib().srganfd_nonfinite_flag(grad.data_ptr(), grad.numel(), flag.data_ptr(), 0, A.stream_ptr()), "nonfinite_flag")
@@ -87,7 +91,7 @@ class LossScaler:
 
     def report(self) -> dict:
         if self.enabled:
-            self._drain(block=True)
+            self._drain(0)
         return {"enabled": self.enabled, "scale": self.scale, "optimizer_steps": self.n_steps, "skipped": self.n_skipped}
 
     def state_dict(self) -> dict:

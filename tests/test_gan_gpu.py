@@ -323,6 +323,15 @@ def test_loss_scaler_skips_nonfinite_step():
     nan[7] = float("nan")
     sc.step(opt, nan, 1.0, sc.current())
     assert sc.report()["scale"] == 256.0 and torch.equal(p, p1)
+    # the scale moves a FIXED number of optimizer steps after the overflow (every data-parallel rank folds the same flags in before
+    # the same backward pass), not whenever the asynchronous read-back happens to have landed
+    sc = LossScaler(p.device, enabled=True, init_scale=1024.0)
+    sc.step(opt, bad, 1.0, sc.current())
+    torch.cuda.synchronize()                          # the flag has certainly arrived ...
+    for k in range(LossScaler.LAG):
+        assert sc.current() == 1024.0                 # ... and is still not applied
+        sc.step(opt, g * 1024.0, 1.0, 1024.0)
+    assert sc.current() == 512.0
 
 
 def test_gan_step_bf16_runs_close():
