@@ -19,6 +19,10 @@ class GraphedStep:
         first-call copy), then captures one more call without executing it."""
         if getattr(trainer, "pg", None) is not None:
             raise ValueError("GraphedStep: data-parallel trainers are not captured (the all-reduce stays eager)")
+        if getattr(getattr(trainer, "scaler", None), "enabled", False):
+            # the dynamic loss scale is a host-side decision on flags read back from the device (trainer.LossScaler): a replayed
+            # graph would neither read them nor change the by-value scale arguments.  bf16 / f32 trainers have no scaler.
+            raise ValueError("GraphedStep: f16 trainers (dynamic loss scaling) run eagerly; capture a bf16 or f32 trainer")
         self.trainer = trainer
         self.lr, self.gt = lr_example.clone(), gt_example.clone()      # static input buffers
         for opt in (getattr(trainer, "opt", None), getattr(trainer, "g_opt", None), getattr(trainer, "d_opt", None)):
