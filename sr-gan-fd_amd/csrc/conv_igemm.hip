@@ -35,8 +35,23 @@ template <int I> struct IC { static constexpr int v = I; };
 template <class Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
 template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // last fragment load issued before MFMA i: the fragment it needs (7 loads / 6 MFMAs per column body) plus kD of read-ahead
+// 16x16x32 form, 3x3 stride 1, two rows per wave: fixed issue order of one kernel column's 14 fragment reads and 24 MFMAs.
+// reads:  B00 A00 A01 A10 A11 | B01 | B10 A20 A21 | B11 | B20 A30 A31 | B21      (B[ky][channel half], A[patch row][pixel half])
+// MFMAs:  group (ky, nh) = 4 MFMAs (row m, pixel half ph): acc[m][ph][nh] += A[m + ky][ph] x B[ky][nh]  -- eight independent
+//         accumulators between two uses of the same one.
+__host__ __device__ constexpr int m16_bidx(int ky, int nh) { return ky == 0 ? (nh ? 5 : 0) : ky == 1 ? (nh ? 9 : 6) : (nh ? 13 : 10); }
+__host__ __device__ constexpr int m16_aidx(int rr, int ph) { return (rr == 0 ? 1 : rr == 1 ? 3 : rr == 2 ? 7 : 11) + ph; }
+__host__ __device__ constexpr int m16_need(int j) {
+  const int gq = j / 4, t = j % 4, a = m16_aidx((t >> 1) + (gq >> 1), t & 1), b = m16_bidx(gq >> 1, gq & 1);
+  return a > b ? a : b;
+}
+__host__ __device__ constexpr int m16_pipe_hi(int i, int d, int nl) { const int need = 14 * (i / 24) + m16_need(i % 24); return need + d < nl - 1 ? need + d : nl - 1; }
 __host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need = 7 * (i / 6) + (i % 6) + 1; return need + d < nl - 1 ? need + d : nl - 1; }
 }
+
+#ifndef SRGANFD_M16_PIPE
+#define SRGANFD_M16_PIPE 3
+#endif
 
 namespace srganfd {
 
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   // columns) + wave-uniform row offset + immediate, instead of one precomputed VGPR per (row, column, pixel half) -- those 24
   // registers pushed the 64-channel kernel over its 128 and spilled a prefetch pointer (scratch reload + vmcnt(0) inside the loop).
   constexpr bool kColSwz = M16 && STRIDE == 1;
+  constexpr int kM16Pipe = WN == 2 ? SRGANFD_M16_PIPE : SRGANFD_M16_PIPE - 1;     // fragment read-ahead (what fits 128 VGPRs) of the 3x3 stride-1 16x16x32 loop (0 = the compiler's own schedule)
   int ldsxo[kColSwz ? C::XI : 1];
   // per-thread source offsets (elements) of the X staging items; -1 = zero padding
   int xoff[C::XI];
@@ -237,6 +253,11 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
   const char* ldsWn = ldsW + wn * C::WN_BYTES + lane * C::FRAGB;
 
+  // 16x16x32 form, stride 1: lane term of the fragment address per kernel column (chunk-invariant)
+  int colt[KS];
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx) colt[kx] = ((lane & 15) + kx) * 64 + (((lane >> 4) ^ (((((lane & 15) + kx) >> 2) & 1) << 1)) << 4);
+
   prefetch(0);
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
@@ -267,6 +288,32 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
       const int pixb = (wr * MR * STRIDE) * C::PC + l15 * STRIDE;
       const char* ldsXw = ldsX + (wr * MR * STRIDE) * C::PC * 64;        // this wave's first patch row (wave-uniform)
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (kColSwz && KS == 3 && MR == 2 && kM16Pipe > 0) {
+        // software-pipelined fragment reads (see m16_need): every ds_read_b128 is issued kM16Pipe fragments ahead of the MFMA that
+        // needs it, across the three kernel columns of the chunk; same accumulation order per accumulator as the plain loop below
+        constexpr int NL = 14 * KS, NM = 24 * KS;
+        Frag F[NL];
+        static_for<NM>([&](auto ic) {
+          constexpr int i = decltype(ic)::v;
+          constexpr int c = i / 24, j = i % 24, gq = j / 4, t = j % 4;
+          constexpr int hi = m16_pipe_hi(i, kM16Pipe, NL), lo = i == 0 ? 0 : m16_pipe_hi(i - 1, kM16Pipe, NL) + 1;
+          static_for<hi - lo + 1>([&](auto jc) {
+            constexpr int n = lo + decltype(jc)::v;
+            constexpr int kx = n / 14, l = n % 14;
+            constexpr bool isB = l == 0 || l == 5 || l == 6 || l == 9 || l == 10 || l == 13;
+            if constexpr (isB) {
+              constexpr int ky = l < 6 ? 0 : (l < 10 ? 1 : 2), nh = (l == 5 || l == 9 || l == 13) ? 1 : 0;
+              F[n] = *(const Frag*)(ldsWn + ((ky * KS + kx) * 2 + nh) * 64 * C::FRAGB);
+            } else {
+              constexpr int q = l < 5 ? l - 1 : (l < 9 ? l - 3 : l - 5), rr = q >> 1, ph = q & 1;
+              F[n] = *(const Frag*)(ldsXw + colt[kx] + (rr * C::PC + 16 * ph) * 64);
+            }
+          });
+          constexpr int ky = gq >> 1, nh = gq & 1, m = t >> 1, ph = t & 1;
+          acc[m][ph][nh] = mfma16<T>(F[14 * c + m16_aidx(m + ky, ph)], F[14 * c + m16_bidx(ky, nh)], acc[m][ph][nh]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
         Frag av[C::NROWS][2];

@@ -6,9 +6,13 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 FORCE = 0x100
+# configurations 2-5 exist in -DSRGANFD_EXPERIMENT builds only: run them when such a library is selected with SRGANFD_LIB
+MODES = [1, 2, 3, 4, 5] if os.environ.get("SRGANFD_LIB") else [1]
 
 
 def _planar(t_nchw, dtype, cbuf, c0):
@@ -43,7 +47,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", CASES)
 def test_ring_conv_matches_torch_and_igemm(dtype, mode, case):
     from sr_gan_fd_amd import _abi as A, ops
