@@ -186,7 +186,7 @@ def main():
     results = [run_workload(args, wl, rank, world, dev, pg) for wl in workloads]
     out = results[0]
     if len(results) > 1 and rank == 0:
-        out["gan"] = {k: results[1][k] for k in ("value", "unit", "ms_per_step", "config", "step_tflops_per_gpu", "roofline", "kernel_classes")
+        out["gan"] = {k: results[1][k] for k in ("value", "unit", "ms_per_step", "config", "step_tflops_per_gpu", "loss_scale", "last_step_scalars", "roofline", "kernel_classes")
                       if k in results[1]}
     if rank == 0:
         h = args.lr_size or BASE_LR_SIZE[workloads[0]]
@@ -277,8 +277,9 @@ def run_workload(args, workload, rank, world, dev, pg):
     barrier()
     rec = None if args.no_kernel_events else profiling.enable()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step_fn(lr_img, gt)
+        last = step_fn(lr_img, gt)
     barrier()
     dt = time.perf_counter() - t0
     profiling.disable()
@@ -309,6 +310,13 @@ def run_workload(args, workload, rank, world, dev, pg):
     scaler = getattr(trainer, "scaler", None)
     if scaler is not None:
         out["loss_scale"] = scaler.report()
+    if torch.is_tensor(last):
+        # the step's own scalars after the timed region (read once, outside it): a step that overflowed its 16-bit range or was
+        # skipped by the loss scaler every time would show here, not as a fast number
+        vals = [float(v) for v in last.detach().float().reshape(-1)[:6].cpu()]
+        out["last_step_scalars"] = [round(v, 6) for v in vals]
+        if not all(v == v and abs(v) != float("inf") for v in vals):
+            raise SystemExit("bench.py: non-finite training scalars %r" % (vals,))
     if rank == 0 and rec is not None:
         out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS, PEAK_HBM_GBPS)
         out["roofline"].update(pmc_fields(workload, out["roofline"]["kernel"], B, h))

@@ -1,5 +1,5 @@
 """Parity through size-independent properties at BASELINE.json's full configuration (configs[1]: 23 RRDB, batch 32,
-128x128 -> 512x512, bf16), where the CPU oracle would need minutes per case: run-to-run determinism of a training
+128x128 -> 512x512, f16 = the benchmarked dtype), where the CPU oracle would need minutes per case: run-to-run determinism of a training
 iteration (the reductions are ordered, no float atomics), data-parallel shard equivalence of the full-batch gradient,
 linearity of the fused convolution, and spot checks of full-size kernel outputs against direct dot products."""
 import numpy as np
@@ -11,6 +11,7 @@ from tests.util import scaled_init
 
 pytestmark = pytest.mark.gpu
 B, H = 32, 128
+DT = torch.float16          # bench.py's default dtype (the reference's autocast dtype); trainers then carry the loss scaler
 
 
 def _gen(seed=0):
@@ -18,7 +19,7 @@ def _gen(seed=0):
     torch.manual_seed(seed)
     g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
     scaled_init(g, 3.0, 0.5)
-    g.compute_dtype = torch.bfloat16
+    g.compute_dtype = DT
     return g.cuda().train()
 
 
@@ -43,15 +44,17 @@ def test_full_size_iteration_is_bitwise_reproducible():
 
 
 def test_full_size_shards_equal_full_batch():
-    """(e): mean of the two 16-image shard gradients == the 32-image gradient (bf16 activations: L2 bound)"""
+    """(e): mean of the two 16-image shard gradients == the 32-image gradient (16-bit activations: L2 bound)"""
     from sr_gan_fd_amd.engine import generator_engine
     g = _gen()
     lr, gt = _batch()
 
+    S = 65536.0      # the reference's GradScaler (train_bsrnet.py: scaler.scale(loss).backward()): an unscaled L1 seed, 1 / (32 * 3 * 512^2) = 4e-8, is below f16's range
+
     def flat_grad(x, y):
         g.zero_grad(set_to_none=True)
-        F.l1_loss(g(x), y).backward()
-        return torch.cat([p.grad.reshape(-1) for p in g.parameters()]).double()
+        (F.l1_loss(g(x), y) * S).backward()
+        return torch.cat([p.grad.reshape(-1) for p in g.parameters()]).double() / S
     full = flat_grad(lr, gt)
     halves = 0.5 * (flat_grad(lr[:16], gt[:16]) + flat_grad(lr[16:], gt[16:]))
     e = ((halves - full).norm() / full.norm()).item()
@@ -78,9 +81,9 @@ def test_full_size_conv_linearity_and_spot_values():
     lin = conv(x1 + x2, torch.float32) - (conv(x1, torch.float32) + conv(x2, torch.float32))
     ref_scale = conv(x1, torch.float32).abs().max().item()
     assert lin.abs().max().item() < 1e-4 * ref_scale
-    # spot values of the bf16 launch against direct dot products of the bf16-rounded operands (fp64 on the host)
-    y = conv(x1, torch.bfloat16)
-    xb, wb = x1.bfloat16().double().cpu(), wt.bfloat16().double().cpu()
+    # spot values of the 16-bit launch against direct dot products of the rounded operands (fp64 on the host)
+    y = conv(x1, DT)
+    xb, wb = x1.to(DT).double().cpu(), wt.to(DT).double().cpu()
     rng = np.random.default_rng(0)
     worst = 0.0
     for _ in range(40):
@@ -93,11 +96,11 @@ def test_full_size_conv_linearity_and_spot_values():
                     acc += float((xb[i, yy, xx_] * wb[co, :, ky, kx]).sum())
         worst = max(worst, abs(y[i, oy, ox, co].item() - acc) / ref_scale)
     print(f"full-size conv spot check: worst error {worst:.2e} of the output scale")
-    assert worst < 4e-3       # the stored result is rounded to bf16 (2^-9 relative)
+    assert worst < 1e-3       # the stored result is rounded to f16 (2^-11 relative)
 
 
 def test_full_size_gan_iteration_is_bitwise_reproducible():
-    """configs[2]: RRDBNet + U-Net discriminator + VGG-19 content loss, batch 32, 128 -> 512, bf16"""
+    """configs[2]: RRDBNet + U-Net discriminator + VGG-19 content loss, batch 32, 128 -> 512, f16"""
     from sr_gan_fd_amd import model as M
     from sr_gan_fd_amd.gan import GanTrainer
     nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
@@ -108,7 +111,7 @@ def test_full_size_gan_iteration_is_bitwise_reproducible():
         torch.manual_seed(1)
         d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
         cl = M.ContentLoss(nodes, mean, std)
-        d.compute_dtype = cl.compute_dtype = torch.bfloat16
+        d.compute_dtype = cl.compute_dtype = DT
         tr = GanTrainer(g, d.cuda().train(), cl.cuda())
         s = tr.step(lr, gt).clone()
         out.append((s, tr.g_opt.flat.clone(), tr.d_opt.flat.clone(), tr.content_vals.clone()))
@@ -136,7 +139,7 @@ def test_full_size_images_are_independent():
 
 def test_config5_iteration_is_bitwise_reproducible():
     """configs[4] per GPU: RRDBNet + A-ESRGAN attention U-Net discriminator (BatchNorm, spectral norm, bilinear resizes) + VGG-19,
-    batch 32, 192 -> 768, bf16: two runs from the same state agree bit for bit (ordered reductions everywhere)"""
+    batch 32, 192 -> 768, f16: two runs from the same state agree bit for bit (ordered reductions everywhere)"""
     from sr_gan_fd_amd import model as M
     from sr_gan_fd_amd.gan import GanTrainer
     nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
@@ -149,7 +152,7 @@ def test_config5_iteration_is_bitwise_reproducible():
         torch.manual_seed(1)
         d = M.uNetDiscriminatorAesrgan()
         cl = M.ContentLoss(nodes, mean, std)
-        d.compute_dtype = cl.compute_dtype = torch.bfloat16
+        d.compute_dtype = cl.compute_dtype = DT
         tr = GanTrainer(g, d.cuda().train(), cl.cuda(), g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1)
         s = tr.step(lr, gt).clone()
         out.append((s, tr.g_opt.flat.clone(), tr.d_opt.flat.clone(), d.attn_3.W[1].running_var.clone()))
@@ -167,6 +170,9 @@ def test_config5_discriminator_addresses_beyond_2_31_elements():
     from sr_gan_fd_amd import model as M
     torch.manual_seed(1)
     d = M.uNetDiscriminatorAesrgan()
+    # bf16 here: an eval-mode forward of a never-trained module divides by sigma = u^T W v of the RANDOM initial u, v (no power
+    # iteration in eval mode), which inflates the activations past f16's 65504 -- in the reference's fp16 autocast as well; the
+    # test is about addressing, not about the element type
     d.compute_dtype = torch.bfloat16
     d.cuda().eval()
     gen = torch.Generator(device="cuda").manual_seed(13)
@@ -186,26 +192,26 @@ def test_kernels_beyond_2_31_elements():
     torch.manual_seed(5)
     n, h, w, cin, cout = B, 768, 768, 128, 64
     dtc = A.BF16
-    x = torch.zeros(n, h, w, cin, device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros(n, h, w, cin, device="cuda", dtype=DT)
     assert x.numel() > 2 ** 31
     k = n - 1
-    x[k] = torch.randn(h, w, cin, device="cuda").bfloat16()
-    r1 = torch.zeros(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
-    r1[k] = torch.randn(h, w, cout, device="cuda").bfloat16()
-    m = torch.randn(n, h, w, cout, device="cuda").bfloat16()
+    x[k] = torch.randn(h, w, cin, device="cuda").to(DT)
+    r1 = torch.zeros(n, h, w, cout, device="cuda", dtype=DT)
+    r1[k] = torch.randn(h, w, cout, device="cuda").to(DT)
+    m = torch.randn(n, h, w, cout, device="cuda").to(DT)
     wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
     wp = ops.pack_single(wt, dtc)
-    y = torch.empty(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(n, h, w, cout, device="cuda", dtype=DT)
     ops.conv2d(ops.conv_args(dtc, A.view(x), A.view(y), wp, n, h, w, cin, cout, r1=A.view(r1), r1_scale=0.5, mask=A.view(m), mask_slope=0.2))
-    y1 = torch.empty(1, h, w, cout, device="cuda", dtype=torch.bfloat16)
+    y1 = torch.empty(1, h, w, cout, device="cuda", dtype=DT)
     xk, rk, mk = x[k:k + 1].contiguous(), r1[k:k + 1].contiguous(), m[k:k + 1].contiguous()
     ops.conv2d(ops.conv_args(dtc, A.view(xk), A.view(y1), wp, 1, h, w, cin, cout, r1=A.view(rk), r1_scale=0.5, mask=A.view(mk), mask_slope=0.2))
     torch.cuda.synchronize()
     assert torch.equal(y[k], y1[0]) and float(y1.float().abs().sum()) > 0
     assert float(y[:k].float().abs().sum()) == 0.0                    # zero input, zero residual -> zero output everywhere else
     # weight gradient: only image k is non-zero on both sides, so the 32-image reduction must equal the single-image one
-    dy = torch.zeros(n, h, w, cout, device="cuda", dtype=torch.bfloat16)
-    dy[k] = torch.randn(h, w, cout, device="cuda").bfloat16()
+    dy = torch.zeros(n, h, w, cout, device="cuda", dtype=DT)
+    dy[k] = torch.randn(h, w, cout, device="cuda").to(DT)
     conv = [dict(cin=cin, cout=cout, dw_off=0, co_dst=cout, ci_dst=cin, db_off=cout * cin * 9)]
     g_all, g_one = torch.zeros(cout * cin * 9 + cout, device="cuda"), torch.zeros(cout * cin * 9 + cout, device="cuda")
     for nn_, xx, dd, gg in ((n, x, dy, g_all), (1, xk, dy[k:k + 1].contiguous(), g_one)):
@@ -223,16 +229,22 @@ def test_full_size_unet_discriminator_and_content_loss_are_per_image():
     from sr_gan_fd_amd import model as M
     torch.manual_seed(1)
     d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
-    d.compute_dtype = torch.bfloat16
-    d.cuda().eval()
+    d.compute_dtype = DT
+    d.cuda().train()
     _, gt = _batch()
     with torch.no_grad():
+        # a never-trained module's u, v are random: sigma = u^T W v then underestimates the spectral norm several-fold per layer and the
+        # eval forward leaves f16's range (as the reference's fp16 autocast would); a few training-mode forwards iterate them first
+        for _ in range(8):
+            d(gt[:1, :, :64, :64].contiguous())
+        d.eval()
         full = d(gt)
+        assert torch.isfinite(full).all()
         for k in (0, 31):
             assert torch.equal(full[k], d(gt[k:k + 1].contiguous())[0]), f"image {k}"
     nodes, mean, std = ["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     cl = M.ContentLoss(nodes, mean, std)
-    cl.compute_dtype = torch.bfloat16
+    cl.compute_dtype = DT
     cl.cuda()
     gen = torch.Generator(device="cuda").manual_seed(14)
     sr = torch.rand(8, 3, 512, 512, device="cuda", generator=gen)
