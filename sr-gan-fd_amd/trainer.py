@@ -103,6 +103,46 @@ class LossScaler:
         self.scale, self.good_steps = float(sd["scale"]), int(sd.get("_growth_tracker", 0))
 
 
+class MultiStepLR:
+    """``torch.optim.lr_scheduler.MultiStepLR`` for the fused optimizers (torch's class insists on a ``torch.optim.Optimizer``).
+    The reference builds one per network from ``lr_scheduler_milestones`` / ``lr_scheduler_gamma`` (bsrgan_config.py:153-155,
+    train_bsrgan.py:314-323) and steps it once per epoch (:193-195).  ``state_dict()`` carries torch's keys, so a checkpoint written
+    by the reference's script resumes here and the other way round (utils.load_state_dict passes ``ckpt["scheduler"]`` through)."""
+
+    def __init__(self, optimizer: "FlatAdamEMA", milestones, gamma: float = 0.1, last_epoch: int = -1):
+        from collections import Counter
+        self.optimizer = optimizer
+        self.milestones = Counter(int(m) for m in milestones)
+        self.gamma = gamma
+        self.base_lrs = [optimizer.lr]
+        self.last_epoch = last_epoch
+        self._step_count = 0
+        self._last_lr = [optimizer.lr]
+        self.step()                                   # torch's constructor performs the initial step (last_epoch -> 0)
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def step(self) -> None:
+        self._step_count += 1
+        self.last_epoch += 1
+        if self.last_epoch in self.milestones:        # torch's chained form: multiply the CURRENT rate (a rate set by hand is kept)
+            self.optimizer.lr = self.optimizer.lr * self.gamma ** self.milestones[self.last_epoch]
+        self._last_lr = [self.optimizer.lr]
+
+    def state_dict(self) -> dict:
+        return {"milestones": self.milestones, "gamma": self.gamma, "base_lrs": list(self.base_lrs), "last_epoch": self.last_epoch,
+                "verbose": False, "_step_count": self._step_count, "_get_lr_called_within_step": False, "_last_lr": list(self._last_lr)}
+
+    def load_state_dict(self, sd: dict) -> None:
+        from collections import Counter
+        self.milestones = Counter({int(k): int(v) for k, v in dict(sd["milestones"]).items()})
+        self.gamma, self.base_lrs = sd["gamma"], list(sd["base_lrs"])
+        self.last_epoch, self._step_count = int(sd["last_epoch"]), int(sd["_step_count"])
+        self._last_lr = list(sd["_last_lr"])
+        self.optimizer.lr = self._last_lr[0]
+
+
 def needs_loss_scaling(*modules) -> bool:
     return any(getattr(m, "compute_dtype", None) == torch.float16 for m in modules if m is not None)
 

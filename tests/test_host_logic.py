@@ -360,3 +360,35 @@ def test_plan_cache_keeps_training_plan():
     assert c.get("train") == "T" and len(c) == 4 and c.get(("eval", 9)) == 9 and c.get(("eval", 0)) is None
     c.put("train2", "T2", pinned=True); c.put("train3", "T3", pinned=True)
     assert c.get("train") is None and c.get("train3") == "T3"
+
+
+def test_multistep_lr_mirror_follows_torch_and_exchanges_state():
+    """trainer.MultiStepLR == torch.optim.lr_scheduler.MultiStepLR (bsrgan_config.py:153-155 milestones / gamma, one step per
+    epoch: train_bsrgan.py:193-195) on the fused optimizer, and the two load each other's state_dict (checkpoint key "scheduler")."""
+    from sr_gan_fd_amd.trainer import FlatAdamEMA, MultiStepLR
+    flat = torch.zeros(8)
+    fused = FlatAdamEMA(flat, 8e-5, (0.9, 0.999), 1e-4)
+    ref_p = torch.nn.Parameter(torch.zeros(8))
+    ref_opt = torch.optim.Adam([ref_p], 8e-5)
+    milestones, gamma = [2, 5, 5, 9], 0.5          # a repeated milestone applies gamma twice (torch keeps a Counter)
+    mine, ref = MultiStepLR(fused, milestones, gamma), torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones, gamma)
+    for epoch in range(12):
+        assert abs(fused.lr - ref_opt.param_groups[0]["lr"]) < 1e-18 and mine.get_last_lr() == ref.get_last_lr(), epoch
+        if epoch == 6:
+            # resume in the middle: each implementation continues from the other's state
+            fused2 = FlatAdamEMA(torch.zeros(8), 1.0, (0.9, 0.999), 1e-4)
+            mine2 = MultiStepLR(fused2, [1], 0.1)
+            mine2.load_state_dict(ref.state_dict())
+            ref_opt2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(8))], 1.0)
+            ref2 = torch.optim.lr_scheduler.MultiStepLR(ref_opt2, [1], 0.1)
+            ref2.load_state_dict(mine.state_dict())
+            ref_opt2.param_groups[0]["lr"] = ref2.get_last_lr()[0]      # torch restores the rate with the optimizer's own state
+            assert fused2.lr == fused.lr and mine2.last_epoch == ref.last_epoch
+        ref_opt.step()
+        mine.step()
+        ref.step()
+        if epoch >= 6:
+            ref_opt2.step()
+            mine2.step()
+            ref2.step()
+            assert abs(fused2.lr - fused.lr) < 1e-18 and abs(ref_opt2.param_groups[0]["lr"] - fused.lr) < 1e-18, epoch
