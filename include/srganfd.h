@@ -40,11 +40,13 @@ void srganfd_set_dry_run(int on);
 /* kernel timing experiments (tools/build_variant.sh builds only; the product library does not export it): bit 0 skip
  * activation loads, bit 1 skip weight loads, bit 2 skip the epilogue of the conv kernels -- results are wrong when non-zero. */
 void srganfd_set_debug(int flags);
-#endif
-/* Which kernel serves the 3x3 stride-1 16-bit convolutions: 0 = conv_igemm tiles only, 1 = the LDS-DMA ring kernel with its
- * default tile per shape (library default; also the environment variable SRGANFD_RING, read once), 2.. = other ring
- * configurations (same results; tools/kbench.py times them against each other in one process).  -1 = back to the default. */
+/* A/B switches of the kernel experiments (tools/kbench.py, tools/wgbench.py): which kernel serves the 3x3 stride-1 16-bit
+ * convolutions (0 = conv_igemm tiles only, 1.. = LDS-DMA ring / stream configurations; bit 0x1000 selects a weight-gradient loop
+ * variant instead), and the MFMA form of the 16-bit convolutions (0 = v_mfma_f32_32x32x16 everywhere ... 3 = v_mfma_f32_16x16x32
+ * everywhere; weights must be packed under the level they are consumed with). */
 void srganfd_set_ring_mode(int mode);
+void srganfd_set_mfma16(int level);
+#endif
 
 /* A channel-slice view of an NHWC activation buffer: element (n,y,x,c) lives at
  * ptr[((n*H + y)*W + x)*cstride + c0 + c]. */
@@ -136,11 +138,7 @@ typedef struct {
 } srganfd_pack_job;
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n);
-/* MFMA form of the 16-bit convolutions: level 0 = v_mfma_f32_32x32x16 everywhere, 1 = v_mfma_f32_16x16x32 for the 3x3 kernels with
- * 32-channel output tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default; environment SRGANFD_MFMA16 at load).
- * Weights must be packed
- * (layout field above) under the setting they are consumed with; switch before the first forward, or re-pack. */
-void srganfd_set_mfma16(int level);
+/* MFMA form of the 16-bit convolutions: 3 = v_mfma_f32_16x16x32 for every kernel shape (the product library's only level). */
 int srganfd_get_mfma16(void);
 /* the `layout` a pack job must carry for an operand of this dtype / kernel size / packed output width n under the current setting */
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n);

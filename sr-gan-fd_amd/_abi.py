@@ -71,8 +71,6 @@ SYMBOLS = {
     "srganfd_last_error": (C.c_char_p, []),
     "srganfd_abi_version": (C.c_int, []),
     "srganfd_set_dry_run": (None, [C.c_int]),
-    "srganfd_set_ring_mode": (None, [C.c_int]),
-    "srganfd_set_mfma16": (None, [C.c_int]),
     "srganfd_get_mfma16": (C.c_int, []),
     "srganfd_pack_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
@@ -163,8 +161,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if hasattr(l, "srganfd_set_debug"):        # -DSRGANFD_EXPERIMENT builds only (tools/build_variant.sh)
-            l.srganfd_set_debug.restype, l.srganfd_set_debug.argtypes = None, [C.c_int]
+        for name in ("srganfd_set_debug", "srganfd_set_ring_mode", "srganfd_set_mfma16"):
+            if hasattr(l, name):                   # -DSRGANFD_EXPERIMENT builds only (tools/build_variant.sh; select with SRGANFD_LIB)
+                getattr(l, name).restype, getattr(l, name).argtypes = None, [C.c_int]
         _lib = l
     return _lib
 

@@ -89,10 +89,10 @@ extern "C" {
 const char* srganfd_last_error(void) { return g_err; }
 int srganfd_abi_version(void) { return 2; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
-void srganfd_set_mfma16(int on) { srganfd::g_mfma16 = on; }
 int srganfd_get_mfma16(void) { return srganfd::g_mfma16; }
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganfd::conv_uses_m16(dtype, ksize, n) ? 1 : 0; }
 #ifdef SRGANFD_EXPERIMENT
+void srganfd_set_mfma16(int on) { srganfd::g_mfma16 = on; }
 void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
 void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
 #endif

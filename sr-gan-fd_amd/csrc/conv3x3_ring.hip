@@ -18,6 +18,7 @@
 //   * one workgroup of 8 waves per CU (2 per SIMD, up to 256 VGPRs each) or two of 4.
 // Everything else (weights packed by pack.hip, epilogue formula, planar / NHWC operand addressing, nearest x2 gather) is the
 // contract of srganfd_conv2d (include/srganfd.h); conv_igemm.hip keeps every other kernel shape and the f32 parity mode.
+#ifdef SRGANFD_EXPERIMENT   // LDS-DMA ring / persistent stream kernels: measured and rejected; kept for the A/B tools
 #include "conv_common.hpp"
 
 namespace srganfd {
@@ -598,3 +599,5 @@ int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t str
 }
 
 }  // namespace srganfd
+
+#endif  // SRGANFD_EXPERIMENT

@@ -528,7 +528,13 @@ int g_igemm_variant = 0;
 // 1 = 16x16x32 for the 3x3 kernels with 32-channel tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default).
 // Same-box A/B of the training steps (profiles/r02_mfma16_ab.txt): generator-only 78.3 (0) -> 72.7 (1) -> 69.4 ms (2), GAN 179.6 (1)
 // -> 173.1 ms (2); the chip runs these steps power-limited (1.2 kW, clock at 2.06 of 2.4 GHz) and holds a higher clock on this form.
+// The product library runs level 3 only: the 32x32x16 instantiations of the 16-bit kernels, the level switch and the LDS-DMA ring /
+// stream kernels (conv3x3_ring.hip) exist in -DSRGANFD_EXPERIMENT builds, where the A/B tools select them at run time.
+#ifdef SRGANFD_EXPERIMENT
 int g_mfma16 = [] { const char* e = getenv("SRGANFD_MFMA16"); return e ? atoi(e) : 3; }();
+#else
+int g_mfma16 = 3;
+#endif
 
 // does the kernel that consumes a packed operand of this kernel size / output width read 16x16x32 B fragments?  (pack.hip asks too)
 bool conv_uses_m16(int dtype, int ksize, int cout) {
@@ -552,6 +558,11 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
       return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
     }
   }
+#ifndef SRGANFD_EXPERIMENT
+  if constexpr (bf) return set_err(SRGANFD_EINVAL, "conv2d: the 16-bit kernels run on v_mfma_f32_16x16x32 (ksize %d stride %d has no kernel)", a->ksize, a->stride);
+  else
+#endif
+  {
   if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
     if constexpr (bf) {
       if (a->ksize == 3 && g_igemm_variant == 7)   // experiment: 4 rows per wave (0.75 fragment reads per MFMA), register staging
@@ -569,6 +580,7 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
   if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1>(k, a->cout, s);
   if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1>(k, a->cout, s);
   return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
+  }
 }
 
 int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
@@ -630,12 +642,14 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.dbg = 0; k.stamps = nullptr;
 #endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
+#ifdef SRGANFD_EXPERIMENT
   {
     bool handled = false;
     // the LDS-DMA ring kernel (64-channel tiles of large images) reads 32x32x16-order weights: used where that form is selected
     const int rc = conv_uses_m16(a->dtype, a->ksize, a->cout) ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);
     if (rc != SRGANFD_OK || handled) return rc;
   }
+#endif
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F16) return dispatch_conv<f16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F32) return dispatch_conv<float>(a, k, stream);

@@ -676,6 +676,9 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.lds_bytes = PR * PC * H.x_upad * UB + kTH * 32 * H.dy_upad * UB;
   if (H.lds_bytes > 160 * 1024) return set_err(SRGANFD_EINVAL, "wgrad: LDS tile %d B too large", H.lds_bytes);
   H.dma_ok = (s->dtype != SRGANFD_F32 && 2 * H.lds_bytes <= 160 * 1024) ? 1 : 0;
+  // 3x3 stride 2 (A-ESRGAN's encoder): with the four loader waves the workgroup has 1024 threads = 128 VGPRs per lane, and this shape's
+  // addressing does not fit them (10-13 spilled registers, scratch inside the loop); 12 waves with register staging have 168
+  if (s->ksize == 3 && s->stride == 2) H.dma_ok = 0;
   for (auto& g : pb.groups) if (g.x_units != H.x_upad || g.dy_units != H.dy_upad) H.dma_ok = 0;
   H.groups_off = (sizeof(WgHeader) + 15) & ~15LL;
   H.tasks_off = (H.groups_off + (long long)sizeof(WgGroup) * H.ngroups + 15) & ~15LL;
@@ -725,20 +728,21 @@ static int launch_wgrad4(const WgHeader& H, const WgK& k, hipStream_t stream) {
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
 static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DMA) {
-    if (g_wgrad_variant == 1) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
-    if (g_wgrad_variant == 3) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 3>(H, k, stream);
 #ifdef SRGANFD_EXPERIMENT
+    if (g_wgrad_variant == 1) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
     if (g_wgrad_variant == 2) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 2>(H, k, stream);
     if (g_wgrad_variant == 0) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
 #endif
     return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 3>(H, k, stream);
+  } else {
+    return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
   }
-  return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
 }
 template <typename T, int KS, int STRIDE, int XP, int YP>
 static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
-    if (H.dma_ok && !SRGANFD_DBG(g_debug, 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
+    if constexpr (!(KS == 3 && STRIDE == 2))
+      if (H.dma_ok && !SRGANFD_DBG(g_debug, 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
   }
   return launch_wgrad3<T, KS, STRIDE, XP, YP, false>(H, k, stream);
 }

@@ -11,8 +11,11 @@ import os
 pytestmark = pytest.mark.gpu
 
 FORCE = 0x100
-# configurations 2-5 exist in -DSRGANFD_EXPERIMENT builds only: run them when such a library is selected with SRGANFD_LIB
-MODES = [1, 2, 3, 4, 5] if os.environ.get("SRGANFD_LIB") else [1]
+# The ring / stream kernels were measured and rejected; they are compiled in -DSRGANFD_EXPERIMENT builds only
+# (tools/build_variant.sh, selected with SRGANFD_LIB), and so is this module's subject.
+MODES = [1, 2, 3, 4, 5]
+if not os.environ.get("SRGANFD_LIB"):
+    pytest.skip("ring / stream conv kernels exist in experiment builds only (SRGANFD_LIB=...)", allow_module_level=True)
 
 
 def _planar(t_nchw, dtype, cbuf, c0):
@@ -51,8 +54,8 @@ CASES = [
 @pytest.mark.parametrize("case", CASES)
 def test_ring_conv_matches_torch_and_igemm(dtype, mode, case):
     from sr_gan_fd_amd import _abi as A, ops
-    if mode > 1 and not hasattr(A.lib(), "srganfd_set_debug"):
-        pytest.skip("ring configurations 2-5 exist in -DSRGANFD_EXPERIMENT builds only (SRGANFD_LIB=build_exp/libsrganfd_exp.so)")
+    if not hasattr(A.lib(), "srganfd_set_ring_mode"):
+        pytest.skip("SRGANFD_LIB does not point at an experiment build")
     torch.manual_seed(3)
     dt = ops.DT[dtype]
     A.lib().srganfd_set_mfma16(0)      # the ring kernels read 32x32x16-order weights: pack and run both kernels under that setting

@@ -25,6 +25,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, name), f"{name} declared in include/srganfd.h but not exported"
     assert declared == set(A.SYMBOLS), f"binding/header mismatch: {declared ^ set(A.SYMBOLS)}"
     assert A.lib().srganfd_abi_version() == 2
+    assert A.lib().srganfd_get_mfma16() == 3
 
 
 def test_product_path_fails_loudly_without_gpu():

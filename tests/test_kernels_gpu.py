@@ -5,6 +5,8 @@ bf16 / f16 modes (v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulate): the oracle 
 inputs/weights, so only accumulation order and the final 16-bit store differ: tolerance 1e-2 of the
 output scale for bf16 (8 bits of mantissa -> 3.9e-3 per rounding), 1.5e-3 for f16 (11 bits -> 4.9e-4).
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -41,13 +43,21 @@ def _nhwc(t, dtype, cbuf=None, c0=0):
     return buf.to(dtype).cuda()
 
 
-@pytest.fixture(params=[0, 3], ids=["mfma32x32x16", "mfma16x16x32"])
+# The product library runs the 16-bit kernels on v_mfma_f32_16x16x32 only (level 3).  An experiment build selected with SRGANFD_LIB
+# (-DSRGANFD_EXPERIMENT: tools/build_variant.sh) also carries the 32x32x16 instantiations and the level switch: test both there.
+_LEVELS = [0, 3] if os.environ.get("SRGANFD_LIB") else [3]
+
+
+@pytest.fixture(params=_LEVELS, ids=["mfma32x32x16", "mfma16x16x32"][-len(_LEVELS):])
 def mfma16(request):
-    """both MFMA forms of the 3x3 16-bit kernels (srganfd_set_mfma16; weights are packed under the same setting)"""
+    """MFMA form of the 16-bit kernels (weights are packed under the same setting)"""
     from sr_gan_fd_amd import _abi as A
-    A.lib().srganfd_set_mfma16(request.param)
+    if hasattr(A.lib(), "srganfd_set_mfma16"):
+        A.lib().srganfd_set_mfma16(request.param)
+    assert A.lib().srganfd_get_mfma16() == request.param
     yield request.param
-    A.lib().srganfd_set_mfma16(3)          # the library default
+    if hasattr(A.lib(), "srganfd_set_mfma16"):
+        A.lib().srganfd_set_mfma16(3)          # the library default
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

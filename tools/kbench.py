@@ -9,6 +9,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sr_gan_fd_amd import _abi as A, ops, profiling
 
 
+def _switch(name, v):
+    """A/B switches exist in -DSRGANFD_EXPERIMENT builds (tools/build_variant.sh + SRGANFD_LIB); the product library runs mode 8 only"""
+    f = getattr(A.lib(), name, None)
+    if f is not None:
+        f(v)
+    elif (name, v) not in (("srganfd_set_mfma16", 3), ("srganfd_set_ring_mode", 0), ("srganfd_set_ring_mode", -1)):
+        raise SystemExit("kbench: this library has no %s (product build): use --modes 8, or SRGANFD_LIB=<experiment build>" % name)
+
+
 def arg(name, default):
     return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
 
@@ -37,11 +46,14 @@ def _make(name, n, h, w, cin, cout, xC, x0, yC, y0, mask, res, up):
     x = (torch.randn(n, h, w, xC, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.5)).to(DT)
     y = torch.empty(n, h << up, w << up, yC, device='cuda', dtype=DT)
     wt = torch.randn(cout, cin, 3, 3, device='cuda') * (0.0 if "--zeros" in sys.argv else 0.05)
-    A.lib().srganfd_set_mfma16(0)
+    EXP = hasattr(A.lib(), "srganfd_set_mfma16")
+    if EXP:
+        A.lib().srganfd_set_mfma16(0)
     wp = ops.pack_single(wt, dtc)
-    A.lib().srganfd_set_mfma16(3)
+    _switch("srganfd_set_mfma16", 3)
     wp16 = ops.pack_single(wt, dtc)             # the same weights in the 16x16x32 B-fragment order where the kernel wants it (mode 8)
-    A.lib().srganfd_set_mfma16(0)
+    if EXP:
+        A.lib().srganfd_set_mfma16(0)
     kw, keep = {}, [x, y, wp, wp16]
     if mask:
         m = torch.randn(n, h, w, yC, device='cuda').to(DT); keep.append(m)
@@ -84,8 +96,8 @@ if __name__ == "__main__":
             for m in MODES:
                 for d in DBGS:
                     a = a16 if m == 8 else a32           # mode 8: conv_igemm on v_mfma_f32_16x16x32
-                    L.srganfd_set_mfma16(3 if m == 8 else 0)
-                    L.srganfd_set_ring_mode(0 if m == 8 else m)
+                    _switch("srganfd_set_mfma16", 3 if m == 8 else 0)
+                    _switch("srganfd_set_ring_mode", 0 if m == 8 else m)
                     if d or len(DBGS) > 1:
                         L.srganfd_set_debug(d)
                     if hasattr(a, "_kernel_label"):
@@ -94,8 +106,8 @@ if __name__ == "__main__":
                     us = time_one(a, 3 if rnd == 0 else REPS)
                     if rnd:
                         res.setdefault((name, m, d, lab, fl), []).append(us)
-    L.srganfd_set_ring_mode(-1)
-    L.srganfd_set_mfma16(3)
+    _switch("srganfd_set_ring_mode", -1)
+    _switch("srganfd_set_mfma16", 3)
     for (name, m, d, lab, fl), v in res.items():
         v.sort()
         med = v[len(v) // 2]
