@@ -409,6 +409,9 @@ class TrunkEngine:
             # conv2: f0 = out1 + conv2(trunk_out)
             bw.append(("wgrad", wplan(N, H, W, Cc, Cc, one("conv2", Cc, Cc)), VC(sp.catb(R)), V(d_f0), 0))
             bw.append(("conv", ops.conv_args(dtc, V(d_f0), VD(dyb(R - 1)), wptr + pk["offs"][("b", "conv2")], N, H, W, Cc, Cc)))
+            # gradient buckets for the data-parallel exchange (parallel.BucketReducer): parameters sit in named_parameters() order --
+            # conv1, the dense blocks, conv2 and the tail -- so "everything from conv2 on" is one contiguous range, final here
+            bw.append(("ready", self._poff("conv2.weight"), self.fp.total))
         # dense blocks, last to first
         rdb_names = ["conv%d" % k for k in range(1, 6)]
         plans = {}
@@ -433,6 +436,8 @@ class TrunkEngine:
                 bw.append(("conv", ops.conv_args(dtc, VD(di), VD(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
                                                  mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
             bw.append(("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight")))
+            if self.full and R >= 4 and i == R // 2:      # upper half of the trunk is final: second bucket
+                bw.append(("ready", self._poff(pre + "conv1.weight"), self._poff("conv2.weight")))
             dst = VD(dyb(i - 1)) if i > 0 else V(sp.dx0)
             kw = dict(r1=VD(di), r1_scale=s_out)
             if first:
@@ -443,6 +448,9 @@ class TrunkEngine:
                 A.lib().srganfd_axpby(x, y, dtc, N * H * W, Cc, 1.0, 1.0, A.stream_ptr()), "axpby"))))
             convs = [dict(cin=32, cout=Cc, dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), co_dst=Cc, ci_dst=self.in_ch)]
             bw.append(("wgrad", wplan(N, H, W, 32, Cc, convs), V(sp.xin), V(sp.dx0), 0))
+        # last bucket: whatever the earlier markers did not cover
+        covered = min([it[1] for it in bw if it[0] == "ready"], default=self.fp.total)
+        bw.append(("ready", 0, covered))
         sp.bw = bw
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
 
@@ -482,8 +490,10 @@ class TrunkEngine:
         self._last = sp
         return out
 
-    def backward(self, sp: _Shape, token: int, dout: Tensor, need_dx: bool) -> Tuple[Tensor, Optional[Tensor]]:
-        """dout: NCHW fp32 gradient of forward()'s result.  Returns (flat parameter gradient, dx or None)."""
+    def backward(self, sp: _Shape, token: int, dout: Tensor, need_dx: bool, on_ready=None) -> Tuple[Tensor, Optional[Tensor]]:
+        """dout: NCHW fp32 gradient of forward()'s result.  Returns (flat parameter gradient, dx or None).
+        ``on_ready(flat_grad, lo, hi)`` (data parallelism, parallel.BucketReducer.bucket) is called when every launch that writes
+        elements [lo, hi) of the flat gradient has been enqueued; the ranges are disjoint and cover the whole buffer."""
         if getattr(sp, "token", None) != token:
             raise A.SrganfdError("generator activations were overwritten by a later training-mode forward before backward ran")
         L, st = A.lib(), A.stream_ptr()
@@ -514,6 +524,9 @@ class TrunkEngine:
                     run()
                 else:
                     rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
+            elif kind == "ready":
+                if on_ready is not None:
+                    on_ready(flat_grad, item[1], item[2])
             else:
                 item[1]()
         dx = None

@@ -20,7 +20,7 @@ from . import _abi as A
 from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
-from .parallel import SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
+from .parallel import BucketReducer, SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
 from .trainer import FlatAdamEMA, LossScaler, needs_loss_scaling
 
 
@@ -48,6 +48,7 @@ class GanTrainer:
         self.generator_first = generator_first
         self.pg = process_group
         self.d_reducer = SideStreamReducer(dev, process_group)      # D's gradient exchange + Adam beside the generator-side losses
+        self.g_reducer = BucketReducer(dev, process_group)          # G's gradient exchange in buckets behind its own backward pass
         if sync_batchnorm:
             # A-ESRGAN's attention blocks carry BatchNorm2d (A-ESRGAN/model.py:233): whole-batch statistics across the ranks
             if not hasattr(self.de, "sync_bn"):
@@ -126,8 +127,9 @@ class GanTrainer:
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
-            gg, _ = ge.backward(g_sp, g_tok, dsr, False)
-            self.scaler.step(self.g_opt, gg, self._allreduce(gg), Sg)
+            self.g_reducer.begin()
+            gg, _ = ge.backward(g_sp, g_tok, dsr, False, on_ready=self.g_reducer.bucket)
+            self.scaler.step(self.g_opt, gg, self.g_reducer.finish(), Sg)
             ge.fp.touch()
         s = self.scalars.data_ptr()
         Sd = self.scaler.current()
@@ -182,8 +184,9 @@ class GanTrainer:
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
-            gg, _ = ge.backward(g_sp, g_tok, dsr, False)
-            self.scaler.step(self.g_opt, gg, self._allreduce(gg), Sg)    # scaler.step(g_optimizer); scaler.update(); EMA  (:466-470)
+            self.g_reducer.begin()
+            gg, _ = ge.backward(g_sp, g_tok, dsr, False, on_ready=self.g_reducer.bucket)
+            self.scaler.step(self.g_opt, gg, self.g_reducer.finish(), Sg)    # scaler.step(g_optimizer); scaler.update(); EMA  (:466-470)
             ge.fp.touch()
         self.sr = sr
         return self.scalars

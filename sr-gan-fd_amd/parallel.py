@@ -61,6 +61,45 @@ class SyncBatchNormReduce:
             dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.pg)
 
 
+class BucketReducer:
+    """The generator's gradient exchange in buckets that follow its backward pass: the engine reports a contiguous range of the
+    flat gradient as final (tail convs first, then the upper half of the trunk, then the rest -- three ranges of 2 / 32 / 33 MB for
+    the 23-block RRDBNet) and the all-reduce of that range starts on a side HIP stream while the data- and weight-gradient kernels
+    of the earlier layers still run; ``finish()`` makes the main stream wait for the last one before the Adam kernel.  A ring over
+    xGMI is per-link bound and needs few CUs, so the exchange costs the backward pass next to nothing and only the last bucket's
+    tail is exposed.  No process group (or CPU tensors: the dry-run host tests): ``bucket`` reduces inline / does nothing.
+
+        flat_grad, _ = engine.backward(sp, token, dout, False, on_ready=reducer.bucket)
+        scale = reducer.finish()          # 1 / world for the optimizer"""
+
+    def __init__(self, device, pg):
+        self.pg = pg
+        self.world = dist.get_world_size(pg) if pg is not None else 1
+        self.stream = torch.cuda.Stream(device=device) if pg is not None and torch.device(device).type == "cuda" else None
+        self.sizes = []                   # elements per bucket of the last backward pass (tests look at it)
+
+    def begin(self) -> None:
+        self.sizes = []
+
+    def bucket(self, flat_grad: torch.Tensor, lo: int, hi: int) -> None:
+        if self.pg is None or hi <= lo:
+            return
+        part = flat_grad[lo:hi]
+        self.sizes.append(hi - lo)
+        if self.stream is None:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())      # the kernels that produced [lo, hi) are enqueued before this point
+        flat_grad.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def finish(self) -> float:
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return 1.0 / self.world
+
+
 class SideStreamReducer:
     """All-reduce + optimizer step of one network on a side HIP stream, so that it overlaps whatever the main stream does next
     that does not read that network's parameters (GAN iteration: the discriminator's 17.5 MB reduce + Adam run beside the

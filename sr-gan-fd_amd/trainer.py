@@ -22,7 +22,7 @@ from torch import Tensor
 
 from . import _abi as A
 from .engine import generator_engine
-from .parallel import allreduce_sum_
+from .parallel import BucketReducer, allreduce_sum_
 
 
 class LossScaler:
@@ -277,6 +277,7 @@ class GeneratorTrainer:
         self.loss_weight = loss_weight
         self.scaler = LossScaler(dev, enabled=needs_loss_scaling(g_model))      # train_rrdbnet.py:94 / train_bsrnet.py:94
         self.pg = process_group
+        self.g_reducer = BucketReducer(dev, process_group)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
         self.dsr: Optional[Tensor] = None
@@ -313,8 +314,10 @@ class GeneratorTrainer:
         S = self.scaler.current()                       # scaler.scale(loss): the factor rides on the gradient seed
         A.check(A.lib().srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.loss_weight, self.loss_buf.data_ptr(), 0,
                                         self.dsr.data_ptr(), self.loss_weight * S, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
-        grad, _ = eng.backward(sp, token, self.dsr, False)
-        scale = allreduce_sum_(grad, self.pg)          # RCCL over xGMI: ONE flat 67 MB buffer per step
+        # RCCL over xGMI: the flat gradient goes out in three buckets as the backward pass finishes them (parallel.BucketReducer)
+        self.g_reducer.begin()
+        grad, _ = eng.backward(sp, token, self.dsr, False, on_ready=self.g_reducer.bucket)
+        scale = self.g_reducer.finish()
         self.scaler.step(self.opt, grad, scale, S)     # scaler.step(optimizer); scaler.update(); ema update
         eng.fp.touch()                             # parameters changed behind autograd's back -> re-pack
         self.sr = sr

@@ -468,7 +468,22 @@ def test_two_rank_gan_iteration_equals_full_batch_iteration():
     for r in range(2):
         g_r, d_r = _build_gan(torch.float32)
         t = GanTrainer(g_r, d_r, None)
-        t._allreduce = (lambda grad, r=r: ex.allreduce(r, grad))
+        t._allreduce = (lambda grad, r=r: ex.allreduce(r, grad))          # the discriminator's exchange
+
+        class Buckets:                                                      # the generator's: buckets during backward, sum at finish()
+            def __init__(self, r):
+                self.r, self.flat, self.covered = r, None, 0
+
+            def begin(self):
+                self.covered = 0
+
+            def bucket(self, flat, lo, hi):
+                self.flat, self.covered = flat, self.covered + hi - lo
+
+            def finish(self):
+                assert self.covered == self.flat.numel()
+                return ex.allreduce(self.r, self.flat)
+        t.g_reducer = Buckets(r)
         trainers.append(t)
 
     def run(r):
@@ -531,3 +546,59 @@ def test_side_stream_discriminator_update_equals_inline():
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(a, b)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
+def test_bucketed_generator_exchange_equals_inline(monkeypatch):
+    """Data-parallel runs send the generator's flat gradient in three buckets on a side stream while its backward pass is still
+    running (parallel.BucketReducer; the engine marks contiguous ranges final: tail, upper half of the trunk, the rest).  With the
+    collective replaced by a kernel that rewrites the range in place on that stream (one rank: the sum is the value), two
+    generator-only iterations and two GAN iterations must not change by a bit, and the buckets must cover the buffer exactly once."""
+    from sr_gan_fd_amd import model as M, parallel as P
+    from sr_gan_fd_amd.gan import GanTrainer
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    seen = []
+
+    def fake_all_reduce(t, op=None, group=None):
+        seen.append((t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+        t.mul_(1.0)                                   # a kernel on the reducer's stream that reads and rewrites the whole range
+    monkeypatch.setattr(P.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(P.dist, "get_world_size", lambda pg=None: 1)
+    torch.manual_seed(12)
+    batches = [(torch.rand(2, 3, 16, 16).cuda(), torch.rand(2, 3, 64, 64).cuda()) for _ in range(2)]
+
+    def gen5():
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)     # 6 dense blocks: all three buckets
+        scaled_init(g, 3.0, 0.5)
+        g.compute_dtype = torch.float32
+        return g.cuda().train()
+    outs = []
+    for bucketed in (False, True):
+        tr = GeneratorTrainer(gen5(), lr=1e-4)
+        if bucketed:
+            tr.g_reducer = P.BucketReducer(torch.device("cuda"), pg="one-rank stand-in")
+            assert tr.g_reducer.stream is not None
+        losses = [tr.step(x, y).item() for x, y in batches]
+        torch.cuda.synchronize()
+        outs.append((losses, tr.flat.clone(), tr.opt.ema.clone()))
+        if bucketed:
+            main = torch.cuda.current_stream().cuda_stream
+            per_step = seen[:len(seen) // 2]
+            assert len(per_step) == 3 and sum(n for _, n, _ in per_step) == tr.flat.numel() and tr.g_reducer.sizes == [n for _, n, _ in per_step]
+            assert all(s != main for _, _, s in seen)
+            # disjoint, contiguous, tail first
+            spans = sorted((p, p + 4 * n) for p, n, _ in per_step)
+            assert spans[0][1] == spans[1][0] and spans[1][1] == spans[2][0] and per_step[0][0] == spans[2][0]
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    seen.clear()
+    gouts = []
+    for bucketed in (False, True):
+        gen, d = _build_gan(torch.float32)
+        tr = GanTrainer(gen, d, None)
+        if bucketed:
+            tr.g_reducer = P.BucketReducer(torch.device("cuda"), pg="one-rank stand-in")
+        sc = [tr.step(x, y).cpu().numpy().copy() for x, y in batches]
+        torch.cuda.synchronize()
+        gouts.append((sc, tr.g_opt.flat.clone(), tr.d_opt.flat.clone()))
+    assert all(np.array_equal(a, b) for a, b in zip(gouts[0][0], gouts[1][0]))
+    assert torch.equal(gouts[0][1], gouts[1][1]) and torch.equal(gouts[0][2], gouts[1][2]) and len(seen) > 0

@@ -102,11 +102,12 @@ def _trainer_worker(rank, world, port, q):
     tr = GeneratorTrainer(g, lr=1e-4, process_group=pg)
     lr_img, gt = torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)
     tr.step(lr_img, gt)
-    ok1 = calls == [tr.flat.numel()]
+    # the generator's gradient goes out in contiguous buckets that follow its backward pass (tail first); they cover the buffer once
+    ok1 = sum(calls) == tr.flat.numel() and calls == tr.g_reducer.sizes and 1 <= len(calls) <= 3
     calls.clear()
     gan = GanTrainer(M.bsrgan_x4(num_rrdb=1), M.discriminator_unet(in_channels=3, out_channels=1, channels=64), None, process_group=pg)
     gan.step(lr_img, gt)
-    ok2 = calls == [gan.de.fp.total, gan.ge.fp.total]            # D after its second backward, then G (gan.py)
+    ok2 = calls[0] == gan.de.fp.total and sum(calls[1:]) == gan.ge.fp.total and calls[1:] == gan.g_reducer.sizes   # D after its second backward, then G's buckets (gan.py)
     dist.barrier()
     q.put((rank, ok1, ok2, calls))
     dist.destroy_process_group()
