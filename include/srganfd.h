@@ -196,6 +196,11 @@ int srganfd_clamp_grad_to_nhwc(const float* dsr_nchw, srganfd_view pre_f32, int3
  * a = source view, b = destination view. */
 int srganfd_resample(int32_t op, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t h,
                      int32_t w, int32_t c, void* stream);
+/* Backward of `lrelu(conv(bilinear_x2(u))) + skip` chains (the U-Net decoder, model.py:150-161) in one pass: dx_raw = adjoint of the
+ * bilinear x2 upsampling applied to dy ((h, w) = LOW-resolution dims), dx_masked = dx_raw * (act > 0 ? 1 : slope) with act = the
+ * LeakyReLU output of the upsampled layer.  dx_raw.ptr may be NULL; dx_masked may alias nothing it reads. */
+int srganfd_resample_bwd_lrelu(srganfd_view dy, srganfd_view dx_raw, srganfd_view act, srganfd_view dx_masked,
+                               int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, float slope, void* stream);
 /* out = dy * (act - skip > 0 ? 1 : slope): LeakyReLU backward where only act = lrelu(z) + skip was
  * stored (U-Net skip adds, model.py:153,157,161); skip.ptr may be NULL (plain LeakyReLU backward). */
 int srganfd_lrelu_bwd(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd_view out, int32_t dtype,

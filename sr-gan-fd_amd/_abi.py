@@ -86,6 +86,7 @@ SYMBOLS = {
     "srganfd_lrelu_bwd": (C.c_int, [View, View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_nhwc_to_nchw": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "srganfd_clamp_grad_to_nhwc": (C.c_int, [C.c_void_p, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, View, C.c_int32, C.c_int32, C.c_void_p]),
+    "srganfd_resample_bwd_lrelu": (C.c_int, [View, View, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_resample": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_axpby": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "srganfd_l1_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),

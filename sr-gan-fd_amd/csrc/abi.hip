@@ -30,6 +30,8 @@ int lrelu_bwd_impl(srganfd_view dy, srganfd_view act, srganfd_view skip, srganfd
 int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, float* dst, int clamp01, hipStream_t s);
 int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s);
 int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int h, int w, int c, hipStream_t s);
+int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view act, srganfd_view dx_masked, int dtype, int n, int h, int w, int c, float slope,
+                            hipStream_t s);
 int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s);
 int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s);
 int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStream_t s);
@@ -142,6 +144,10 @@ int srganfd_nhwc_to_nchw(srganfd_view src, int32_t dtype, int32_t n, int32_t c, 
 int srganfd_clamp_grad_to_nhwc(const float* dsr_nchw, srganfd_view pre_f32, int32_t n, int32_t c, int32_t h, int32_t w, srganfd_view dst,
                                int32_t dtype, int32_t cpad, void* stream) {
   return clamp_grad_impl(dsr_nchw, pre_f32, n, c, h, w, dst, dtype, cpad, (hipStream_t)stream);
+}
+int srganfd_resample_bwd_lrelu(srganfd_view dy, srganfd_view dx_raw, srganfd_view act, srganfd_view dx_masked, int32_t dtype, int32_t n, int32_t h, int32_t w,
+                               int32_t c, float slope, void* stream) {
+  return resample_bwd_lrelu_impl(dy, dx_raw, act, dx_masked, dtype, n, h, w, c, slope, (hipStream_t)stream);
 }
 int srganfd_resample(int32_t op, srganfd_view a, srganfd_view b, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   return resample_impl(op, a, b, dtype, n, h, w, c, (hipStream_t)stream);

@@ -49,8 +49,12 @@ template <typename T> __device__ __forceinline__ void stv(void* p, size_t i, con
 __device__ __forceinline__ void bil_taps(int d, int n, int& i0, int& i1, float& w0, float& w1);
 __device__ __forceinline__ int bil_bwd_taps(int k, int n, int* d, float* wt);
 
+// OP 2 only: act != NULL also writes b2 = result * (act > 0 ? 1 : slope) (LeakyReLU' of the layer whose output was upsampled: the
+// raw gradient b is the U-Net skip's share, model.py:153,157,161; b may be NULL when only the masked one is wanted)
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int n, int h, int w, int c) {
+__global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int n, int h, int w, int c,
+                                                           const void* __restrict__ act = nullptr, int actC = 0, int act0 = 0, void* b2 = nullptr, int b2C = 0,
+                                                           int b20 = 0, float slope = 0.f) {
   constexpr int N = VecN<T>::N;
   const int cv = c / N;
   // output extents: op0/2 -> (h, w) low-res ; op1 -> (2h, 2w) ; op3 -> (h/2, w/2) ; op4 -> (h, w)
@@ -121,7 +125,18 @@ __global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restric
 #pragma unroll
       for (int q = 0; q < N; ++q) acc[q] = fmaxf(acc[q], 0.f);
     }
-    stv<T>(b, ((img * oh + oy) * ow + ox) * (size_t)bC + b0 + ch, acc);
+    if constexpr (OP == 2) {
+      const size_t op_ = (img * oh + oy) * ow + ox;
+      if (b) stv<T>(b, op_ * (size_t)bC + b0 + ch, acc);
+      if (act) {
+        ldv<T>(act, op_ * (size_t)actC + act0 + ch, t);
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] *= t[q] > 0.f ? 1.f : slope;
+        stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
+      }
+    } else {
+      stv<T>(b, ((img * oh + oy) * ow + ox) * (size_t)bC + b0 + ch, acc);
+    }
   }
 }
 
@@ -1224,6 +1239,20 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
   else return set_err(SRGANFD_EINVAL, "resample: bad op %d", op);
 #undef RS
 #undef RSV
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+// bilinear-x2 backward fused with the LeakyReLU' of the upsampled layer: dx_raw (optional) = adjoint of the upsampling applied to dy,
+// dx_masked = dx_raw * (act > 0 ? 1 : slope).  16-byte-vectorised views only (the discriminators' channel counts).
+int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view act, srganfd_view dx_masked, int dtype, int n, int h, int w, int c, float slope,
+                            hipStream_t s) {
+  if (!dy.ptr || !act.ptr || !dx_masked.ptr) return set_err(SRGANFD_EINVAL, "resample_bwd_lrelu: null view");
+  const int vn = dtype == SRGANFD_F32 ? 4 : 8;
+  auto ok = [&](const srganfd_view& v) { return !v.ptr || (v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0 && v.c0 + c <= v.cstride && !v.planar); };
+  if (c % vn || !ok(dy) || !ok(dx_raw) || !ok(act) || !ok(dx_masked)) return set_err(SRGANFD_EINVAL, "resample_bwd_lrelu: views must be 16-byte aligned NHWC slices");
+  const size_t lo = (size_t)n * h * w * c;
+  DISPATCH_T(dtype, SRGANFD_LAUNCH((resample_vec_kernel<TT, 2>), dim3(grid_for(lo / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride,
+                                   dx_raw.c0, n, h, w, c, (const void*)act.ptr, act.cstride, act.c0, dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -185,8 +185,9 @@ class DiscriminatorEngine:
 
         cv = lambda *a, **k: ("conv", ops.conv_args(dtc, *a, **k))
         rs = lambda op, a, b, h, w, c: ("call", lambda: A.check(L.srganfd_resample(op, a, b, dtc, N, h, w, c, A.stream_ptr()), "resample"))
-        lb = lambda dy, act, skip, out, npix, c: ("call", lambda: A.check(
-            L.srganfd_lrelu_bwd(dy, act, skip, out, dtc, npix, c, 0.2, A.stream_ptr()), "lrelu_bwd"))
+        # bilinear-x2 backward + LeakyReLU' of the upsampled layer in one pass: raw gradient (the skip connection's share) and masked one
+        rsl = lambda dy, raw, act, masked, h, w, c: ("call", lambda: A.check(
+            L.srganfd_resample_bwd_lrelu(dy, raw, act, masked, dtc, N, h, w, c, 0.2, A.stream_ptr()), "resample_bwd_lrelu"))
 
         def s2_dgrad(name, dy, dx, hd, wd, cout, cin, r1, mask):
             """data gradient of a 4x4 stride-2 conv: 4 output-parity classes (2x2-tap convs over dy)"""
@@ -210,20 +211,18 @@ class DiscriminatorEngine:
             wg("conv3", sp.c2, gA, H, W, 64, 64, sn_index=7),
             cv(V(gA), V(gB), wptr + O[("b", "conv3")], N, H, W, 64, 64, mask=V(sp.c2), mask_slope=0.2),
             wg("conv2", sp.u3, gB, H, W, 64, 64, sn_index=6),
-            cv(V(gB), V(gA), wptr + O[("b", "conv2")], N, H, W, 64, 64),                 # gA = d u3
-            lb(V(gA), V(sp.a3), A.NULL_VIEW, V(gB), P, 64),                              # gB = d z3
-            wg("up_block3", sp.b1, gB, H, W, 128, 64, sn_index=5),
-            cv(V(gB), V(gC), wptr + O[("b", "up_block3")], N, H, W, 64, 128),            # gC = d b1
-            rs(2, V(gC), V(h1), H // 2, W // 2, 128),                                    # h1 = d u2
-            lb(V(h1), V(sp.a2), A.NULL_VIEW, V(h2), P // 4, 128),                          # h2 = d z2
+            # u3 = lrelu(z3) + out1: the conv's two outputs are d u3 (y2: the skip's share, added into d out1 below) and
+            # d z3 = d u3 * lrelu'(a3) (y, after the mask) -- no separate LeakyReLU-backward pass over the 512^2 tensor
+            cv(V(gB), V(gD), wptr + O[("b", "conv2")], N, H, W, 64, 64, y2=V(gA), mask=V(sp.a3), mask_slope=0.2),   # gA = d u3, gD = d z3
+            wg("up_block3", sp.b1, gD, H, W, 128, 64, sn_index=5),
+            cv(V(gD), V(gC), wptr + O[("b", "up_block3")], N, H, W, 64, 128),            # gC = d b1
+            rsl(V(gC), V(h1), V(sp.a2), V(h2), H // 2, W // 2, 128),                     # h1 = d u2, h2 = d z2
             wg("up_block2", sp.b2, h2, H // 2, W // 2, 256, 128, sn_index=4),
             cv(V(h2), V(h3), wptr + O[("b", "up_block2")], N, H // 2, W // 2, 128, 256),  # h3 = d b2
-            rs(2, V(h3), V(q1), H // 4, W // 4, 256),                                    # q1 = d u1
-            lb(V(q1), V(sp.a1), A.NULL_VIEW, V(q2), P // 16, 256),                         # q2 = d z1
+            rsl(V(h3), V(q1), V(sp.a1), V(q2), H // 4, W // 4, 256),                     # q1 = d u1, q2 = d z1
             wg("up_block1", sp.b3, q2, H // 4, W // 4, 512, 256, sn_index=3),
             cv(V(q2), V(q3), wptr + O[("b", "up_block1")], N, H // 4, W // 4, 256, 512),  # q3 = d b3
-            rs(2, V(q3), V(e1), H // 8, W // 8, 512),                                    # e1 = d d3 (post-act)
-            lb(V(e1), V(sp.d3), A.NULL_VIEW, V(e1), P // 64, 512),                      # e1 = d d3 (pre-act)
+            rsl(V(q3), A.NULL_VIEW, V(sp.d3), V(e1), H // 8, W // 8, 512),               # e1 = d d3 (pre-activation)
             wg("down_block3", sp.d2, e1, H // 4, W // 4, 256, 512, sn_index=2, k=4, s=2),
         ]
         bw += s2_dgrad("down_block3", e1, q4, H // 8, W // 8, 512, 256, q1, sp.d2)       # q4 = (d d2 + d u1) * lrelu'(d2)

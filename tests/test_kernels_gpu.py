@@ -241,3 +241,37 @@ def test_clamp_grad_rgb_fast_path_matches_definition():
     dst16 = torch.full((n, h, w, 16), 7.0, device="cuda", dtype=torch.bfloat16)
     A.check(A.lib().srganfd_clamp_grad_to_nhwc(dsr.data_ptr(), A.view(pre), n, c, h, w, A.view(dst16), A.BF16, 16, A.stream_ptr()), "clamp_grad")
     assert torch.equal(dst16[..., :3], want) and float(dst16[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resample_bwd_lrelu_equals_two_passes(dtype):
+    """srganfd_resample_bwd_lrelu (adjoint of bilinear x2 + LeakyReLU' of the upsampled layer, U-Net decoder backward,
+    model.py:150-161): the raw output equals srganfd_resample(op 2) bit for bit; the masked output equals raw * mask in f32 and is one
+    16-bit rounding away from the two-pass result otherwise (the fused kernel masks the fp32 value before rounding)."""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(4)
+    n, h, w, c = 2, 9, 13, 64
+    dtc = ops.DT[dtype]
+    dy = torch.randn(n, 2 * h, 2 * w, c, device="cuda").to(dtype)
+    act = torch.randn(n, h, w, c, device="cuda").to(dtype)
+    raw, masked, two = (torch.empty(n, h, w, c, device="cuda", dtype=dtype) for _ in range(3))
+    ref_raw = torch.empty_like(raw)
+    L, st = A.lib(), A.stream_ptr()
+    A.check(L.srganfd_resample(2, A.view(dy), A.view(ref_raw), dtc, n, h, w, c, st))
+    A.check(L.srganfd_lrelu_bwd(A.view(ref_raw), A.view(act), A.NULL_VIEW, A.view(two), dtc, n * h * w, c, 0.2, st))
+    A.check(L.srganfd_resample_bwd_lrelu(A.view(dy), A.view(raw), A.view(act), A.view(masked), dtc, n, h, w, c, 0.2, st))
+    only = torch.empty_like(masked)
+    A.check(L.srganfd_resample_bwd_lrelu(A.view(dy), A.NULL_VIEW, A.view(act), A.view(only), dtc, n, h, w, c, 0.2, st))
+    torch.cuda.synchronize()
+    assert torch.equal(raw, ref_raw) and torch.equal(only, masked)
+    # against torch: the adjoint of F.interpolate(scale_factor=2, mode="bilinear")
+    u = torch.zeros(n, c, h, w, device="cuda", requires_grad=True)
+    F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False).backward(dy.float().permute(0, 3, 1, 2))
+    want = u.grad.permute(0, 2, 3, 1) * torch.where(act.float() > 0, 1.0, 0.2)
+    tol = 1e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 1.5e-3)
+    scale = want.abs().max().item()
+    assert (masked.float() - want).abs().max().item() < tol * scale
+    if dtype == torch.float32:
+        assert torch.equal(masked, two)
+    else:
+        assert (masked.float() - two.float()).abs().max().item() < tol * scale
