@@ -55,7 +55,9 @@ __host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need
 
 namespace srganfd {
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN>
+// TS = tap split: the weight slab of a 32-channel chunk is staged in TS pieces of KS/TS kernel rows (the 4x4 stride-2 kernel: 64 KiB of
+// weights per chunk next to a 42 KiB patch would leave room for ONE workgroup per CU; in halves two fit)
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, int TS = 1>
 struct ConvCfg {
   static constexpr int NWAVES = WR * WN, NTHR = 64 * NWAVES;
   static constexpr int KT = KS * KS;
@@ -72,9 +74,11 @@ struct ConvCfg {
   static constexpr int WN_BYTES = KT * KSTEPS * 64 * FRAGB;  // one 32-channel n-tile, one chunk
   static constexpr int NX = PR * PC * CPP;
   static constexpr int XI = (NX + NTHR - 1) / NTHR;
-  static constexpr int NW16 = WN * WN_BYTES / 16;
+  static_assert(KS % TS == 0, "tap split by kernel rows");
+  static constexpr int WS_BYTES = WN_BYTES / TS;              // one n-tile's slab piece of one stage
+  static constexpr int NW16 = WN * WS_BYTES / 16;
   static constexpr int WI = (NW16 + NTHR - 1) / NTHR;
-  static constexpr int STAGE_BYTES = XBYTES + WN * WN_BYTES;
+  static constexpr int STAGE_BYTES = XBYTES + WN * WS_BYTES;
   static constexpr int NB = 32 * WN;                           // output channels per workgroup
   static constexpr int EPI_BYTES = TH * TW * NB * 4;           // fp32 tile for the vectorised epilogue
   static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
@@ -123,10 +127,11 @@ template <int MR> struct AccSet<true, MR> {
   static __device__ __forceinline__ int chan(int e, int lane) { return 16 * ((e >> 2) & 1) + (lane & 15); }
 };
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false>
-__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1>
+__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
+  static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
   using Frag = typename FragAB<T>::type;
   constexpr int NTHR = C::NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,13 +198,13 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * a.x_cs);
     return v;
   };
-  auto load_w = [&](int i, int chunk) -> u32x4 {
+  auto load_w = [&](int i, int chunk, int th = 0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (item < C::NW16 && !SRGANFD_DBG(a.dbg, 2)) {
-      // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]
-      const int nn = item / (C::WN_BYTES / 16), rem = item % (C::WN_BYTES / 16);
-      v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + rem];
+      // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]; piece th = taps [th, th+1) * KT/TS
+      const int nn = item / (C::WS_BYTES / 16), rem = item % (C::WS_BYTES / 16);
+      v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16) + rem];
     }
     return v;
   };
@@ -251,13 +256,69 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
 
   // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
   const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
-  const char* ldsWn = ldsW + wn * C::WN_BYTES + lane * C::FRAGB;
+  const char* ldsWn = ldsW + wn * C::WS_BYTES + lane * C::FRAGB;
 
   // 16x16x32 form, stride 1: lane term of the fragment address per kernel column (chunk-invariant)
   int colt[KS];
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) colt[kx] = ((lane & 15) + kx) * 64 + (((lane >> 4) ^ (((((lane & 15) + kx) >> 2) & 1) << 1)) << 4);
 
+  if constexpr (TS > 1) {
+    // Tap-split main loop (16x16x32 form): stage (chunk, th) holds the chunk's patch and kernel rows [th*KYS, (th+1)*KYS) of its
+    // weights; the patch is committed with th == 0 and stays for the chunk's TS weight pieces.  Same issue-early / write-late
+    // staging as below, one barrier pair per stage.
+    constexpr int KYS = KS / TS, NR_ = (MR - 1) * STRIDE + KYS;
+    const int l15 = lane & 15, sl = lane >> 4;
+    const int pixb = (wr * MR * STRIDE) * C::PC + l15 * STRIDE;
+#pragma unroll
+    for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, 0);
+#pragma unroll
+    for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, 0, 0);
+    for (int chunk = 0; chunk < a.nChunks; ++chunk) {
+      static_for<TS>([&](auto thc) {
+        constexpr int th = decltype(thc)::v;
+        __syncthreads();
+        if constexpr (th == 0) {
+#pragma unroll
+          for (int i = 0; i < C::XI; ++i) store_x(i, xr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < C::WI; ++i) store_w(i, wrg[i]);
+        __syncthreads();
+        if constexpr (th + 1 < TS) {
+#pragma unroll
+          for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, chunk, th + 1);
+        } else if (chunk + 1 < a.nChunks) {
+#pragma unroll
+          for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, chunk + 1);
+#pragma unroll
+          for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, chunk + 1, 0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          Frag av[NR_][2];
+#pragma unroll
+          for (int rr = 0; rr < NR_; ++rr)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+              av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + (th * KYS + rr) * C::PC + kx + 16 * ph * STRIDE, sl));
+#pragma unroll
+          for (int kyl = 0; kyl < KYS; ++kyl) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              const Frag bq = *(const Frag*)(ldsWn + ((kyl * KS + kx) * 2 + nh) * 64 * C::FRAGB);
+#pragma unroll
+              for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) acc[m][ph][nh] = mfma16<T>(av[m * STRIDE + kyl][ph], bq, acc[m][ph][nh]);
+            }
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      });
+    }
+  } else {
   prefetch(0);
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
@@ -380,6 +441,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
     }
   }
 
+  }
+
   // ---- epilogue (see srganfd.h for the formula) ----
   if (SRGANFD_DBG(a.dbg, 4)) { if (A_.get(0, 0) == 123.456f) ((float*)a.y)[0] = 1.f; return; }
   float alpha = a.alpha;
@@ -498,11 +561,11 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN>::
   }
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16>;
-  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : ""); return SRGANFD_OK; }
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS>;
+  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : ""); return SRGANFD_OK; }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
   if (!g_dry_run) {
     int dev = 0;
@@ -552,7 +615,8 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
       if (a->ksize == 3 && a->stride == 1) return wide ? launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
       if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1, true>(k, a->cout, s);
       if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1, true>(k, a->cout, s);
-      if (a->ksize == 4 && a->stride == 2) return wide ? launch_conv<T, 4, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 4, 2, 1, 4, 1, true>(k, a->cout, s);
+      // 4x4 stride 2, 64-channel tiles: weights staged in two halves of two kernel rows -> 73 KiB of LDS, two workgroups per CU
+      if (a->ksize == 4 && a->stride == 2) return wide ? launch_conv<T, 4, 2, 1, 4, 2, true, 2>(k, a->cout, s) : launch_conv<T, 4, 2, 1, 4, 1, true>(k, a->cout, s);
       if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1, true>(k, a->cout, s);
       if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1, true>(k, a->cout, s);
       return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
