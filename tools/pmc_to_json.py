@@ -34,9 +34,10 @@ def demangle(kernel: str) -> str:
 def label(kernel: str):
     """rocprof kernel name -> bench.py class label (profiling.conv_label / WgradPlan.label)"""
     kernel = demangle(kernel)
-    m = re.search(r"conv_igemm_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?>", kernel)
+    m = re.search(r"conv_igemm_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?(?:, (\d+))?>", kernel)
     if m:
-        return "conv_igemm_kernel<%s,KS=%s,S=%s,MR=%s,WR=%s,WN=%s%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:6], ",M16" if m.group(7) == "true" else "")
+        return "conv_igemm_kernel<%s,KS=%s,S=%s,MR=%s,WR=%s,WN=%s%s%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:6], ",M16" if m.group(7) == "true" else "",
+                                                                         ",TS=%s" % m.group(8) if m.group(8) and int(m.group(8)) > 1 else "")
     m = re.search(r"conv3x3_ring_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
     if m:
         return "conv3x3_ring_kernel<%s,MR=%s,WR=%s,NR=%s,SCH=%s,NBUF=%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:])
