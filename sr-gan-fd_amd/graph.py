@@ -5,7 +5,9 @@ cost, at small batches (BASELINE configs[0]: 4 x 32x32) the step is launch-bound
 ``trainer.step`` (GeneratorTrainer or GanTrainer) into a hipGraph through ``torch.cuda.CUDAGraph`` and replays it:
 the engines only launch kernels on torch's current stream (no host synchronisation, no host-side scalars that change
 between iterations once the Adam step count lives in device memory), so the capture is exact.
-Single-process only: the RCCL all-reduce of the data-parallel path is not captured here.
+Single-process only: the RCCL all-reduce of the data-parallel path is not captured here.  f16 trainers (dynamic loss scaling,
+trainer.LossScaler) are supported: the scale is a captured by-value argument, the found_inf flags the captured step writes are
+copied out after every replay and folded in at the scaler's fixed lag, and a changed scale captures the graph again.
 """
 from __future__ import annotations
 
@@ -19,11 +21,9 @@ class GraphedStep:
         first-call copy), then captures one more call without executing it."""
         if getattr(trainer, "pg", None) is not None:
             raise ValueError("GraphedStep: data-parallel trainers are not captured (the all-reduce stays eager)")
-        if getattr(getattr(trainer, "scaler", None), "enabled", False):
-            # the dynamic loss scale is a host-side decision on flags read back from the device (trainer.LossScaler): a replayed
-            # graph would neither read them nor change the by-value scale arguments.  bf16 / f32 trainers have no scaler.
-            raise ValueError("GraphedStep: f16 trainers (dynamic loss scaling) run eagerly; capture a bf16 or f32 trainer")
         self.trainer = trainer
+        sc = getattr(trainer, "scaler", None)
+        self.scaler = sc if getattr(sc, "enabled", False) else None      # f16 trainers: dynamic loss scaling (trainer.LossScaler)
         self.lr, self.gt = lr_example.clone(), gt_example.clone()      # static input buffers
         for opt in (getattr(trainer, "opt", None), getattr(trainer, "g_opt", None), getattr(trainer, "d_opt", None)):
             if opt is not None:
@@ -46,9 +46,16 @@ class GraphedStep:
         a change (the reference steps MultiStepLR every epoch, train_bsrgan.py:193-195) re-captures the graph."""
         opts = self._opts()
         before = [(o.t, o.n_averaged) for o in opts]
+        if self.scaler is not None:
+            # the scale is a by-value argument of the loss-seed and Adam kernels: the captured step runs with the scale of this
+            # moment; the found_inf flags it writes are copied out after every replay, folded in at the scaler's fixed lag by
+            # current() before the next one, and a changed scale re-captures (it is part of _hyper())
+            self.scaler.current()
+            self.scaler.captured_flags = []
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self.trainer.step(self.lr, self.gt)
+        self._flags = list(self.scaler.captured_flags) if self.scaler is not None else []
         # the host-side counters advanced during capture although nothing ran: undo exactly what moved (an optimizer that
         # did not step -- train_generator=False -- keeps its counters)
         self._delta = []
@@ -63,11 +70,15 @@ class GraphedStep:
                 tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")) + (getattr(getattr(tr, "scaler", None), "scale", 1.0),))
 
     def __call__(self, lr_img: Tensor, gt: Tensor) -> Tensor:
+        if self.scaler is not None:
+            self.scaler.current()                       # folds finished found_inf flags in (backoff / growth), as trainer.step does
         if self._hyper() != self._frozen:
             self._capture()
         self.lr.copy_(lr_img)
         self.gt.copy_(gt)
         self.graph.replay()
+        for f in self._flags:                           # one per optimizer step of the iteration, in order
+            self.scaler.read_back(f)
         for o, (dt, dn) in zip(self._opts(), self._delta):
             o.t += dt
             o.n_averaged += dn

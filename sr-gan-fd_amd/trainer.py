@@ -46,6 +46,7 @@ class LossScaler:
         self.good_steps = 0
         self.n_steps = self.n_skipped = 0
         self.pending = []           # (event, pinned host flag) of optimizer steps whose found_inf has not been read yet
+        self.captured_flags = []    # flag slots written by a step that was captured into a hipGraph
         if enabled:
             self.flags = torch.zeros(8, dtype=torch.float32, device=device)      # ring: one slot per optimizer step in flight
             self.slot = 0
@@ -83,6 +84,13 @@ class LossScaler:
         self.slot = (self.slot + 1) % 8
         A.check(A.lib().srganfd_nonfinite_flag(grad.data_ptr(), grad.numel(), flag.data_ptr(), 0, A.stream_ptr()), "nonfinite_flag")
         opt.step(grad, grad_scale / scale_used, update_ema, skip_flag=flag)
+        if torch.cuda.is_current_stream_capturing():
+            self.captured_flags.append(flag)          # graph.GraphedStep reads these back after every replay (read_back)
+        else:
+            self.read_back(flag)
+
+    def read_back(self, flag: Tensor) -> None:
+        """Queue one optimizer step's found_inf flag for the scale update: asynchronous copy to pinned memory + an event."""
         host = torch.empty(1, dtype=torch.float32, pin_memory=True)
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()

@@ -24,7 +24,7 @@ def _batches(n, b=4, h=32):
     return [(torch.rand(b, 3, h, h, device="cuda", generator=gen), torch.rand(b, 3, 4 * h, 4 * h, device="cuda", generator=gen)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_graphed_generator_step_equals_eager(dtype):
     from sr_gan_fd_amd.graph import GraphedStep
     from sr_gan_fd_amd.trainer import GeneratorTrainer
@@ -82,3 +82,37 @@ def test_graphed_gan_step_equals_eager():
     torch.cuda.synchronize()
     t_g = (time.perf_counter() - t0) / 5
     print(f"GAN step B=2 16->64: eager {t_e * 1e3:.2f} ms, graph replay {t_g * 1e3:.2f} ms")
+
+
+def test_graphed_f16_step_handles_overflow_like_eager():
+    """f16 trainers carry the dynamic loss scale (trainer.LossScaler): a replayed graph writes the same found_inf flags, GraphedStep
+    reads them back after every replay, the scale halves at the scaler's fixed lag and the graph is captured again with the new
+    scale.  With the scale forced far too high (2^34: the gradient seeds overflow f16) both runs skip the same steps, back off the
+    same way and end with the same parameters."""
+    from sr_gan_fd_amd.graph import GraphedStep
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    data = _batches(9)
+    te = GeneratorTrainer(_gen(torch.float16), lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999)
+    tg = GeneratorTrainer(_gen(torch.float16), lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999)
+    for _ in range(2):
+        te.step(*data[0])
+    step = GraphedStep(tg, *data[0], warmup=2)
+    te.step(*data[1])
+    step(*data[1])                                       # one clean replayed step first
+    te.scaler.report(), tg.scaler.report()               # fold everything in, then force the overflow
+    te.scaler.scale = tg.scaler.scale = 2.0 ** 34
+    w_before = tg.flat.clone()
+    scales = []
+    for lr, gt in data[2:]:
+        te.step(lr, gt)
+        step(lr, gt)
+        scales.append((te.scaler.scale, tg.scaler.scale))
+    torch.cuda.synchronize()
+    re, rg = te.scaler.report(), tg.scaler.report()
+    print("eager", re, "graphed", rg, scales)
+    assert re == rg and re["skipped"] >= 3 and re["scale"] < 2.0 ** 34
+    assert all(a == b for a, b in scales)
+    assert torch.isfinite(tg.flat).all()
+    assert ((te.flat - tg.flat).abs().max() / te.flat.abs().max()).item() < 1e-6
+    if re["skipped"] == len(data) - 2:
+        assert torch.equal(tg.flat, w_before)            # every forced step overflowed: the parameters never moved
