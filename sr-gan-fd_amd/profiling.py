@@ -108,6 +108,9 @@ def summary(rec: Recorder) -> Dict[str, dict]:
     return agg
 
 
+MEASURED_READ_GBPS = 5600.0      # midpoint of the read-only probe runs in profiles/r02_hbm_bw_probe.txt
+
+
 def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> dict:
     """Dominant kernel class (largest total time) against the roof that bounds it: its arithmetic intensity (algorithmic
     FLOP / algorithmic bytes) below the ridge peak_tflops / peak_gbps means HBM-bound, else MFMA-bound.  Both fractions
@@ -125,5 +128,8 @@ def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> di
     out.update(traffic=None, avg_launch_us=d["avg_us"], launches=d["launches"],
                flop_per_launch=float(f"{d['flop'] / d['launches']:.6g}"),
                bytes_per_launch=float(f"{d['bytes'] / d['launches']:.6g}"), flop_per_byte=ai, ridge_flop_per_byte=round(ridge, 1),
-               mfma_frac=round(d["tflops"] / peak_tflops, 4), hbm_frac=round(d["gbps"] / peak_gbps, 4))
+               mfma_frac=round(d["tflops"] / peak_tflops, 4), hbm_frac=round(d["gbps"] / peak_gbps, 4),
+               # what a pure streaming kernel reaches on this part (tools/probes/bw_probe.hip, profiles/r02_hbm_bw_probe.txt: reads
+               # 5.3-6.2 TB/s, copies 4.3-5.1): context for hbm_frac, which the contract prices against the 8 TB/s datasheet figure
+               hbm_measured_read_gbps=MEASURED_READ_GBPS, hbm_frac_of_measured=round(d["gbps"] / MEASURED_READ_GBPS, 4))
     return out
