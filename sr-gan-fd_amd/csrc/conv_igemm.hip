@@ -457,13 +457,16 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     {
       // a lane's 16 values per row cover one channel (32x32 form) or two (16x16 form: elements 0-3 / 8-11 vs 4-7 / 12-15)
       const float bv0 = a.bias ? a.bias[cow + A_.chan(0, lane)] : 0.f, bv1 = a.bias ? a.bias[cow + A_.chan(4, lane)] : 0.f;
+      // the activation as ONE select per element: factor of the negative side = slope (LeakyReLU), 0 (ReLU), 1 (none).  Written
+      // as `if (act == ...)` inside the loop the compiler emitted two scalar compares and branches per element (630 branches in this
+      // epilogue's ISA), and every wave walked them.
+      const float neg = a.act == SRGANFD_ACT_LRELU ? a.slope : (a.act == SRGANFD_ACT_RELU ? 0.f : 1.f);
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           float v = alpha * A_.get(m, i) + ((i >> 2) & 1 ? bv1 : bv0);
-          if (a.act == SRGANFD_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-          else if (a.act == SRGANFD_ACT_RELU) v = fmaxf(v, 0.f);
+          v = v > 0.f ? v : v * neg;
           tile[((wr * MR + m) * 32 + A_.pixel(i, lane)) * C::NB + wn * 32 + A_.chan(i, lane)] = v * a.post_scale;
         }
     }
@@ -585,6 +588,7 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
+
 
 int g_igemm_variant = 0;
 // MFMA form of the 16-bit kernels (srganfd_set_mfma16 / environment SRGANFD_MFMA16 at load): 0 = v_mfma_f32_32x32x16 everywhere,
