@@ -193,20 +193,46 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   constexpr int XR = kPrefetch ? C::XI : 1, WRG = kPrefetch ? C::WI : 1;
   u32x4 xr[XR];
   u32x4 wrg[WRG];
-  auto load_x = [&](int i, int chunk) -> u32x4 {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * a.x_cs);
-    return v;
+  // 16-bit staging loads go through buffer descriptors: padding pixels / idle lanes carry an offset beyond the descriptor's range and
+  // the hardware range check returns zeros -- no zero-initialised destination registers (32 v_mov per chunk), no exec-mask branches
+  // around the loads.  Descriptors are built from wave-uniform values (image base, weight base of this output-channel block).
+  constexpr bool kBuf = sizeof(T) == 2;
+  constexpr int kOob = 0x7fffffff;
+  // (the base pointers are block-uniform, but 64-bit products are computed in VGPRs: without the explicit readfirstlane the backend
+  // wraps every buffer load in a waterfall loop over "divergent" descriptors)
+  auto uniform_ptr = [](const void* p) -> void* {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
   };
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(xg), (short)0, kBuf ? (int)((unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.xC * (unsigned)sizeof(T)) : 0, 0x00020000);
+  auto load_x = [&](int i, int chunk) -> u32x4 {
+    if constexpr (kBuf) {
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned v4u;
+      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[i] >= 0 ? xoff[i] * (int)sizeof(T) : kOob, chunk * a.x_cs * (int)sizeof(T), 0);
+      return __builtin_bit_cast(u32x4, r);
+    } else {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (xoff[i] >= 0) v = *(const u32x4*)(xg + xoff[i] + chunk * a.x_cs);
+      return v;
+    }
+  };
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wgp), (short)0, kBuf ? (int)((unsigned)WN * (unsigned)a.nChunks * (unsigned)C::WN_BYTES) : 0, 0x00020000);
   auto load_w = [&](int i, int chunk, int th = 0) -> u32x4 {
     const int item = tid + i * NTHR;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < C::NW16 && !SRGANFD_DBG(a.dbg, 2)) {
-      // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]; piece th = taps [th, th+1) * KT/TS
-      const int nn = item / (C::WS_BYTES / 16), rem = item % (C::WS_BYTES / 16);
-      v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16) + rem];
+    // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]; piece th = taps [th, th+1) * KT/TS
+    const int nn = item / (C::WS_BYTES / 16), rem = item % (C::WS_BYTES / 16);
+    if constexpr (kBuf) {
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned v4u;
+      const bool ok = item < C::NW16 && !SRGANFD_DBG(a.dbg, 2);
+      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? (nn * a.nChunks * (C::WN_BYTES / 16) + rem) * 16 : kOob,
+                                                          (chunk * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16)) * 16, 0);
+      return __builtin_bit_cast(u32x4, r);
+    } else {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (item < C::NW16 && !SRGANFD_DBG(a.dbg, 2)) v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16) + rem];
+      return v;
     }
-    return v;
   };
   auto store_x = [&](int i, u32x4 v) {
     const int item = tid + i * NTHR;
