@@ -145,12 +145,14 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   const int r = lane & 31, h = lane >> 5;
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (L2), give each XCD a contiguous range
+  // (block-uniform by construction; the readfirstlane tells the compiler so: the divisions go through v_rcp, and without it every
+  // address product downstream -- image bases of five tensors, tile origins -- stays in quarter-rate vector multiplies)
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int nb = bid % a.nNb;
+  const int nb = __builtin_amdgcn_readfirstlane(bid % a.nNb);
   int t = bid / a.nNb;
-  const int tx = t % a.tiles_x; t /= a.tiles_x;
-  const int ty = t % a.tiles_y;
-  const int n = t / a.tiles_y;
+  const int tx = __builtin_amdgcn_readfirstlane(t % a.tiles_x); t /= a.tiles_x;
+  const int ty = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
+  const int n = __builtin_amdgcn_readfirstlane(t / a.tiles_y);
   const int oy0 = ty * C::TH, ox0 = tx * C::TW;
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
