@@ -26,6 +26,7 @@ struct ConvK {
   int nNb;            // cout / (output channels per workgroup)
   int cout_store;
   int tiles_x, tiles_y;
+  unsigned m_nNb, m_tx, m_ty;   // ceil(2^32 / d) for the block-index decode (0: divide), see fast_div
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
   int act, y_f32, fast_epi;
   int dbg;            // SRGANFD_EXPERIMENT builds only: 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
@@ -60,6 +61,13 @@ template <> __device__ __forceinline__ f32x4_t mfma16<bf16_t>(bf16x8 a, bf16x8 b
 }
 template <> __device__ __forceinline__ f32x4_t mfma16<f16_t>(f16x8 a, f16x8 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// n / d for block-uniform n with the host's magic number m = ceil(2^32 / d): exact while n * d < 2^32 (the host passes 0 otherwise, and
+// for d == 1).  A runtime 32-bit division is a v_rcp_iflag + fix-up sequence of ~20 instructions on the vector pipe.
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m) { return m ? __umulhi(n, m) : n / d; }
+inline unsigned div_magic(unsigned d, unsigned long long n_max) {
+  if (d <= 1 || n_max * d >= (1ull << 32)) return 0u;
+  return (unsigned)(((1ull << 32) + d - 1) / d);
 }
 bool conv_uses_m16(int dtype, int ksize, int cout);
 extern int g_mfma16;   // 1: the 3x3 16-bit convolutions run on the 16x16x32 form (weights packed in its B-fragment order: srganfd_pack_job.layout)

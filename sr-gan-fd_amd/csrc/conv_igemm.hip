@@ -148,11 +148,13 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   // (block-uniform by construction; the readfirstlane tells the compiler so: the divisions go through v_rcp, and without it every
   // address product downstream -- image bases of five tensors, tile origins -- stays in quarter-rate vector multiplies)
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int nb = __builtin_amdgcn_readfirstlane(bid % a.nNb);
-  int t = bid / a.nNb;
-  const int tx = __builtin_amdgcn_readfirstlane(t % a.tiles_x); t /= a.tiles_x;
-  const int ty = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
-  const int n = __builtin_amdgcn_readfirstlane(t / a.tiles_y);
+  const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
+  const int nb = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
+  const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
+  const int tx = __builtin_amdgcn_readfirstlane(t0 - t1 * a.tiles_x);
+  const int t2 = (int)fast_div((unsigned)t1, (unsigned)a.tiles_y, a.m_ty);
+  const int ty = __builtin_amdgcn_readfirstlane(t1 - t2 * a.tiles_y);
+  const int n = __builtin_amdgcn_readfirstlane(t2);
   const int oy0 = ty * C::TH, ox0 = tx * C::TW;
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
@@ -489,13 +491,14 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       // as `if (act == ...)` inside the loop the compiler emitted two scalar compares and branches per element (630 branches in this
       // epilogue's ISA), and every wave walked them.
       const float neg = a.act == SRGANFD_ACT_LRELU ? a.slope : (a.act == SRGANFD_ACT_RELU ? 0.f : 1.f);
+      // post_scale * act(v) = v * (v > 0 ? post_scale : neg * post_scale): one multiply per element instead of two
+      const float ps_pos = a.post_scale, ps_neg = neg * a.post_scale;
 #pragma unroll
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float v = alpha * A_.get(m, i) + ((i >> 2) & 1 ? bv1 : bv0);
-          v = v > 0.f ? v : v * neg;
-          tile[((wr * MR + m) * 32 + A_.pixel(i, lane)) * C::NB + wn * 32 + A_.chan(i, lane)] = v * a.post_scale;
+          const float v = alpha * A_.get(m, i) + ((i >> 2) & 1 ? bv1 : bv0);
+          tile[((wr * MR + m) * 32 + A_.pixel(i, lane)) * C::NB + wn * 32 + A_.chan(i, lane)] = v * (v > 0.f ? ps_pos : ps_neg);
         }
     }
     __syncthreads();
@@ -612,6 +615,9 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   kk.tiles_y = ceil_div(k.Hout, C::TH);
   const long long nblk = (long long)k.N * kk.tiles_x * kk.tiles_y * kk.nNb;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d: bad grid %lld", nblk);
+  kk.m_nNb = div_magic((unsigned)kk.nNb, (unsigned long long)nblk);
+  kk.m_tx = div_magic((unsigned)kk.tiles_x, (unsigned long long)nblk);
+  kk.m_ty = div_magic((unsigned)kk.tiles_y, (unsigned long long)nblk);
   SRGANFD_LAUNCH(kern, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS_BYTES, stream, kk);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
