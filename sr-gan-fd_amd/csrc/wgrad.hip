@@ -144,6 +144,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   // VAR 3 (v_mfma_f32_16x16x32): [kernel column][input-channel half][output-channel half], 48 registers like acc[3] above
   f32x4_t acc16[3][2][2];
   float bsum16[2] = {0.f, 0.f};
+  f32x4_t bacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // VAR 3: bias sums as MFMA results (all rows equal)
   if constexpr (VAR == 3) {
 #pragma unroll
     for (int q = 0; q < 12; ++q)
@@ -339,6 +340,8 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
         const int tx0 = Lp * xRowB + ((W.ci_rel ^ swz(xp_sh, Lp)) * UB) + lp * 8;        // patch-row parity 0 (row start = 0 mod 4)
         const int tx1 = Lp * xRowB + ((W.ci_rel ^ swz(xp_sh, 2 + Lp)) * UB) + lp * 8;    // parity 1 (row start = 2 mod 4)
         const int ty0 = Lp * dyRowB + ((W.co_rel ^ swz(yp_sh, Lp)) * UB) + lp * 8;
+        const unsigned one2 = sizeof(T) == 2 && Elem<T>::kDtype == SRGANFD_F16 ? 0x3C003C00u : 0x3F803F80u;      // two 1.0 in f16 / bf16
+        const Fr ones = __builtin_bit_cast(Fr, u32x4{one2, one2, one2, one2});
         for (int rr = 0; rr < rows_per; ++rr) {
           const int ro = W.ks_idx * rows_per + rr, prow = ro + ky;
           const char* xb = ldsX + ((prow & 1) ? tx1 : tx0) + prow * PC * xRowB;
@@ -349,12 +352,11 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
             const u32x2 blo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + nh * 32)));
             const u32x2 bhi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + nh * 32 + 4 * dyRowB)));
             const u32x4 b4 = {blo.x, blo.y, bhi.x, bhi.y};
-            if (W.bias_slab >= 0) {
-              float f8[8];
-              unpack8<T>(b4, f8);
-              bsum16[nh] += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
-            }
             bq[nh] = __builtin_bit_cast(Fr, b4);
+            // bias gradient = sum over the row's 32 pixels of dy: one MFMA against a fragment of ones (every row of the result is
+            // that sum) instead of 8 conversions + 7 adds per lane -- 16 matrix-pipe cycles for ~90 VALU cycles in the one wave of
+            // three that carries it
+            if (W.bias_slab >= 0) bacc[nh] = mfma16<T>(ones, bq[nh], bacc[nh]);
           }
 #pragma unroll
           for (int ch = 0; ch < 2; ++ch) {
@@ -500,8 +502,9 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) slab[(tl * 32 + 16 * ch + 4 * (lane >> 4) + i) * 32 + 16 * nh + (lane & 15)] = acc16[tl][ch][nh][i];
       if (W.bias_slab >= 0) {
-        // a lane summed 8 of the row's 32 pixels of channel 16 * nh + (lane & 15): add the four lane groups, slots 0..31 = channels
-        float t0 = bsum16[0], t1 = bsum16[1];
+        // every row of bacc holds the 32-pixel sums of channels 16 * nh + (lane & 15): take row 0 (lane group 0), slots 0..31 = channels
+        float t0 = (lane >> 4) == 0 ? bacc[0][0] : 0.f, t1 = (lane >> 4) == 0 ? bacc[1][0] : 0.f;
+        (void)bsum16;
         t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
         t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
         a.bslabs[(size_t)(W.bias_slab + split * W.ks_n + W.ks_idx) * 64 + lane] = lane < 16 ? t0 : (lane < 32 ? t1 : 0.f);
