@@ -236,42 +236,59 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   constexpr int XITEMS = PR * PC * (CPU << xp_sh), YITEMS = TH * 32 * (CPU << yp_sh);
   constexpr int XPIECES = (XITEMS + 63) / 64, NPIECE = XPIECES + (YITEMS + 63) / 64;
   constexpr int NSLOT = (NPIECE + kLoaderWaves - 1) / kLoaderWaves;   // pieces per loader wave and tile
-  auto dma_piece = [&](int n, int oy0, int ox0, int buf, int piece) __attribute__((always_inline)) {
-    char* bx = smem + buf * kBufBytes;
-    char* by = bx + PR * PC * xRowB;
+  // Per piece and tile the loader needs: patch pixel (py, px) of the lane's chunk, its (swizzled) source unit and 16-byte slot.  All
+  // of it is tile-invariant, so it is decoded ONCE per kernel into one packed register per slot (the full decode -- pixel / unit,
+  // swizzle, division by the patch width -- is ~100 instructions per piece; 19 pieces per tile and loader wave, issued at raised
+  // priority on the SIMDs of the MFMA waves).  Per tile a piece is then: unpack, two coordinate adds, bounds, one address.
+  int spk[DMA ? NSLOT : 1];      // py | px << 8 | unit << 16 | w16 << 20 ; -1 = idle lane
+  auto slots_setup = [&]() __attribute__((always_inline)) {
     constexpr int XSH = CPU_SH + xp_sh, YSH = CPU_SH + yp_sh;
-    if (piece < XPIECES) {
-      const int item = piece * 64 + lane;
-      if (item < XITEMS) {
-        const int pix = item >> XSH, c16 = item & ((CPU << xp_sh) - 1);
-        const int unit = (c16 >> CPU_SH) ^ swz(xp_sh, pix), w16 = c16 & (CPU - 1);
-        const int py = pix / PC, px = pix - py * PC;
-        const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
-        if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl) {
-          const T* src = xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16);
-          glds16(src, lds_addr(bx) + (unsigned)(piece * 1024));
-        } else {
-          *(u32x4*)(bx + item * 16) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int piece = (wave - WgWaves<KS>::NW) + kLoaderWaves * k;
+      spk[k] = -1;
+      if (piece < XPIECES) {
+        const int item = piece * 64 + lane;
+        if (item < XITEMS) {
+          const int pix = item >> XSH, c16 = item & ((CPU << xp_sh) - 1);
+          const int unit = (c16 >> CPU_SH) ^ swz(xp_sh, pix), w16 = c16 & (CPU - 1);
+          const int py = pix / PC, px = pix - py * PC;
+          spk[k] = py | (px << 8) | (unit << 16) | (w16 << 20);
         }
-      }
-    } else if (piece < NPIECE) {
-      const int item = (piece - XPIECES) * 64 + lane;
-      if (item < YITEMS) {
-        const int pix = item >> YSH, c16 = item & ((CPU << yp_sh) - 1);
-        const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
-        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-        if (oy < a.Hout && ox < a.Wout) {
-          const T* src = dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + unit * a.dy_gs + w16 * E16);
-          glds16(src, lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
-        } else {
-          *(u32x4*)(by + item * 16) = u32x4{0u, 0u, 0u, 0u};
+      } else if (piece < NPIECE) {
+        const int item = (piece - XPIECES) * 64 + lane;
+        if (item < YITEMS) {
+          const int pix = item >> YSH, c16 = item & ((CPU << yp_sh) - 1);
+          const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
+          spk[k] = (pix >> 5) | ((pix & 31) << 8) | (unit << 16) | (w16 << 20);
         }
       }
     }
   };
   auto dma_slots = [&](int n, int oy0, int ox0, int buf) __attribute__((always_inline)) {
+    char* bx = smem + buf * kBufBytes;
+    char* by = bx + PR * PC * xRowB;
+    const int gy0 = oy0 * STRIDE - a.pad, gx0 = ox0 * STRIDE - a.pad;
+    const T* xi = xg + (size_t)n * a.Hin * a.Win * a.xC;            // image bases (wave-uniform)
+    const T* yi = dyg + (size_t)n * a.Hout * a.Wout * a.dyC;
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k) dma_piece(n, oy0, ox0, buf, (wave - WgWaves<KS>::NW) + kLoaderWaves * k);   // unrolled: the address arithmetic of all pieces overlaps
+    for (int k = 0; k < NSLOT; ++k) {
+      const int piece = (wave - WgWaves<KS>::NW) + kLoaderWaves * k;       // wave-uniform
+      const int q = spk[k];
+      if (piece >= NPIECE || q < 0) continue;
+      const int py = q & 255, px = (q >> 8) & 255, unit = (q >> 16) & 15, w16 = q >> 20;
+      if (piece < XPIECES) {
+        const int gy = gy0 + py, gx = gx0 + px;
+        if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
+          glds16(xi + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16), lds_addr(bx) + (unsigned)(piece * 1024));
+        else *(u32x4*)(bx + (piece * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+      } else {
+        const int oy = oy0 + py, ox = ox0 + px;
+        if (oy < a.Hout && ox < a.Wout)
+          glds16(yi + ((oy * a.Wout + ox) * a.dy_ps + unit * a.dy_gs + w16 * E16), lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
+        else *(u32x4*)(by + ((piece - XPIECES) * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
   };
 
   // ---- lane-constant LDS address tables (keeps the MFMA loop almost free of address VALU work) ----
@@ -304,14 +321,19 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
     if (wave >= WgWaves<KS>::NW) {
       // ---- loader wavefronts: tile t+1 -> buffer cur^1 while the compute waves run tile t out of buffer cur ----
       int n, oy0, ox0;
+      slots_setup();
+      auto fill = [&](int t, int buf) __attribute__((always_inline)) {
+        tile_origin(t, n, oy0, ox0);
+        dma_slots(n, oy0, ox0, buf);
+      };
       __builtin_amdgcn_s_setprio(3);   // the copy must not wait behind the compute waves' issue slots (334 -> 317 us)
-      if (tile < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) { tile_origin(tile, n, oy0, ox0); dma_slots(n, oy0, ox0, 0); }
+      if (tile < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) fill(tile, 0);
       for (; tile < a.ntiles; tile += a.S) {
         // own DMAs landed (vmcnt) and zero fills written (lgkmcnt in the barrier's fence); past the barrier the buffer
         // is published and nobody reads buffer cur^1 any more (its MFMA phase precedes this barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + a.S < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) { tile_origin(tile + a.S, n, oy0, ox0); dma_slots(n, oy0, ox0, cur ^ 1); }
+        if (tile + a.S < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) fill(tile + a.S, cur ^ 1);
         cur ^= 1;
       }
       return;
