@@ -67,12 +67,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst));   // no "memory" clobber: it pins every by-reference lambda capture to scratch,
-                                                        // and scratch loads share vmcnt with the copies; ordering comes from the
-                                                        // explicit vmcnt(0) + barrier that publish a buffer
+  // m0 is declared clobbered instead of saved and restored around every piece (nothing else in these kernels lives in m0: LDS
+  // instructions do not need it on gfx9+)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               : : "v"(gsrc), "s"(dst) : "m0");   // no "memory" clobber: it pins every by-reference lambda capture to scratch,
+                                                   // and scratch loads share vmcnt with the copies; ordering comes from the
+                                                   // explicit vmcnt(0) + barrier that publish a buffer
 }
 
 template <int KS, int STRIDE> struct WgTile { static constexpr int TH = (STRIDE == 1) ? 8 : 4; };
@@ -241,12 +242,13 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   // swizzle, division by the patch width -- is ~100 instructions per piece; 19 pieces per tile and loader wave, issued at raised
   // priority on the SIMDs of the MFMA waves).  Per tile a piece is then: unpack, two coordinate adds, bounds, one address.
   int spk[DMA ? NSLOT : 1];      // py | px << 8 | unit << 16 | w16 << 20 ; -1 = idle lane
+  int soff[DMA ? NSLOT : 1];     // the lane's element offset from the tile's first patch / gradient pixel (valid for up == 0)
   auto slots_setup = [&]() __attribute__((always_inline)) {
     constexpr int XSH = CPU_SH + xp_sh, YSH = CPU_SH + yp_sh;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
       const int piece = (wave - WgWaves<KS>::NW) + kLoaderWaves * k;
-      spk[k] = -1;
+      spk[k] = -1; soff[k] = 0;
       if (piece < XPIECES) {
         const int item = piece * 64 + lane;
         if (item < XITEMS) {
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
           const int unit = (c16 >> CPU_SH) ^ swz(xp_sh, pix), w16 = c16 & (CPU - 1);
           const int py = pix / PC, px = pix - py * PC;
           spk[k] = py | (px << 8) | (unit << 16) | (w16 << 20);
+          soff[k] = (py * a.Win + px) * a.x_ps + unit * a.x_gs + w16 * E16;
         }
       } else if (piece < NPIECE) {
         const int item = (piece - XPIECES) * 64 + lane;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
           const int pix = item >> YSH, c16 = item & ((CPU << yp_sh) - 1);
           const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
           spk[k] = (pix >> 5) | ((pix & 31) << 8) | (unit << 16) | (w16 << 20);
+          soff[k] = ((pix >> 5) * a.Wout + (pix & 31)) * a.dy_ps + unit * a.dy_gs + w16 * E16;
         }
       }
     }
@@ -271,6 +275,10 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
     const int gy0 = oy0 * STRIDE - a.pad, gx0 = ox0 * STRIDE - a.pad;
     const T* xi = xg + (size_t)n * a.Hin * a.Win * a.xC;            // image bases (wave-uniform)
     const T* yi = dyg + (size_t)n * a.Hout * a.Wout * a.dyC;
+    // tile bases for the precomputed offsets (may point before the image for border tiles: only in-range lanes dereference)
+    const T* xt = xi + ((long long)gy0 * a.Win + gx0) * a.x_ps;
+    const T* yt = yi + ((long long)oy0 * a.Wout + ox0) * a.dy_ps;
+    const bool lin = a.up == 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
       const int piece = (wave - WgWaves<KS>::NW) + kLoaderWaves * k;       // wave-uniform
@@ -280,12 +288,12 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       if (piece < XPIECES) {
         const int gy = gy0 + py, gx = gx0 + px;
         if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-          glds16(xi + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16), lds_addr(bx) + (unsigned)(piece * 1024));
+          glds16(lin ? xt + soff[k] : xi + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16), lds_addr(bx) + (unsigned)(piece * 1024));
         else *(u32x4*)(bx + (piece * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
       } else {
         const int oy = oy0 + py, ox = ox0 + px;
         if (oy < a.Hout && ox < a.Wout)
-          glds16(yi + ((oy * a.Wout + ox) * a.dy_ps + unit * a.dy_gs + w16 * E16), lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
+          glds16(yt + soff[k], lds_addr(by) + (unsigned)((piece - XPIECES) * 1024));
         else *(u32x4*)(by + ((piece - XPIECES) * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
       }
     }
