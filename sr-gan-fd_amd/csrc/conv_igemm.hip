@@ -706,6 +706,9 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   if (a->y.c0 + a->cout_store > a->y.cstride) return set_err(SRGANFD_EINVAL, "conv2d: y view exceeds buffer channels");
   if ((size_t)a->h_in * a->w_in * (size_t)a->x.cstride >= 0x7fffffffULL)
     return set_err(SRGANFD_EINVAL, "conv2d: one input image is too large for 32-bit element offsets");
+  // 16-bit kernels stage through a buffer descriptor per image; padding lanes carry the offset 0x7fffffff, which must lie beyond it
+  if (a->dtype != SRGANFD_F32 && (size_t)a->h_in * a->w_in * (size_t)a->x.cstride * 2 >= 0x7fffffffULL)
+    return set_err(SRGANFD_EINVAL, "conv2d: one input image exceeds the 2 GiB a buffer descriptor's range check can separate from padding");
   const size_t opix = sub ? (size_t)a->out_h_full * a->out_w_full : (size_t)a->h_out * a->w_out;   // per image
   auto fits = [&](const srganfd_view& v) { return !v.ptr || opix * (size_t)v.cstride < 0x7fffffffULL; };
   if (!fits(a->y) || !fits(a->y2) || !fits(a->r1) || !fits(a->r2) || !fits(a->mask))
