@@ -483,6 +483,33 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     // [pixel][channel]; (2) 16 output bytes per lane: residuals / LeakyReLU' mask via 16-byte global
     // loads, 16-byte stores.
     float* tile = (float*)smem;
+    // The residual / mask tensors of the WHOLE tile are requested here, before the accumulators go through LDS: inside the store loop
+    // each item's 16-byte load was followed by its s_waitcnt vmcnt(0) -- one exposed load latency per item, four per tile.  (16-bit
+    // kernels with four items per thread: every 3x3 / 4x4 / 2x2 tile shape; up to 48 registers, free at this point: the staging ones.)
+    constexpr int CPq = C::NB / C::E16, ITEMSq = C::TH * 32 * CPq, EIq = (ITEMSq + NTHR - 1) / NTHR;
+    constexpr bool kEpiPre = sizeof(T) == 2 && EIq <= 4;
+    u32x4 pre_r1[kEpiPre ? EIq : 1], pre_r2[kEpiPre ? EIq : 1], pre_m[kEpiPre ? EIq : 1];
+    if constexpr (kEpiPre) {
+      const size_t imgq = (size_t)n * a.HoutF * a.WoutF;
+#pragma unroll
+      for (int e = 0; e < EIq; ++e) {
+        const int item = tid + e * NTHR;
+        const int pix = item / CPq, ck = item % CPq;
+        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+        pre_r1[e] = pre_r2[e] = pre_m[e] = u32x4{0u, 0u, 0u, 0u};
+        if (item < ITEMSq && oy < a.Hout && ox < a.Wout) {
+          const int p = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+          const int cch = nb * C::NB + ck * C::E16;
+          auto ld = [&](const void* base, int Cs, int c0, int ps, int gs) -> u32x4 {
+            const int cc = c0 + cch;
+            return *(const u32x4*)((const T*)base + imgq * Cs + (p * ps + (cc >> 5) * gs + (cc & 31)));
+          };
+          if (a.r1) pre_r1[e] = ld(a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs);
+          if (a.r2) pre_r2[e] = ld(a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs);
+          if (a.mask) pre_m[e] = ld(a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs);
+        }
+      }
+    }
     __syncthreads();   // all waves are done with the staging buffers
     {
       // a lane's 16 values per row cover one channel (32x32 form) or two (16x16 form: elements 0-3 / 8-11 vs 4-7 / 12-15)
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     constexpr int EI = (ITEMS + NTHR - 1) / NTHR;
     const int cbase = nb * C::NB;
     const size_t img = (size_t)n * a.HoutF * a.WoutF;   // pixels before this image (block-uniform)
-#pragma unroll 2
+#pragma unroll (kEpiPre ? 4 : 2)
     for (int e = 0; e < EI; ++e) {
       const int item = tid + e * NTHR;
       const int pix = item / CP, ck = item % CP;
@@ -548,13 +575,17 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
         };
         if (a.y2) store16(a.y2, a.y2C, a.y2_c0, a.y2_ps, a.y2_gs, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
         float tt[C::E16];
-        if (a.r1) { load16(a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs, tt);
+        auto get16 = [&](const u32x4* pre, const void* base, int Cs, int c0, int ps, int gs, float* out) {
+          if constexpr (kEpiPre) unpack8<T>(pre[e], out);
+          else load16(base, Cs, c0, ps, gs, out);
+        };
+        if (a.r1) { get16(pre_r1, a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * tt[q]; }
-        if (a.r2) { load16(a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs, tt);
+        if (a.r2) { get16(pre_r2, a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * tt[q]; }
-        if (a.mask) { load16(a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs, tt);
+        if (a.mask) { get16(pre_m, a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs, tt);
 #pragma unroll
           for (int q = 0; q < C::E16; ++q) v[q] *= tt[q] > 0.f ? 1.f : a.mask_slope; }
         store16(a.y, a.yC, a.y_c0, a.y_ps, a.y_gs, v);
