@@ -293,6 +293,15 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
 #pragma unroll
   for (int kx = 0; kx < KS; ++kx) colt[kx] = ((lane & 15) + kx) * 64 + (((lane >> 4) ^ (((((lane & 15) + kx) >> 2) & 1) << 1)) << 4);
 
+  // epilogue operands requested before the main loop (their load latency used to sit at the head of every tile's epilogue): the
+  // device-side scale is a scalar load, the two bias values of this lane's channels cost two registers through the loop
+  float alpha = a.alpha;
+  if (a.alpha_dev) alpha *= *a.alpha_dev;
+  const int cow = (nb * WN + wn) * 32;      // first output channel of this wave; element e of a lane sits at channel cow + chan(e, lane)
+  float bvh0 = 0.f, bvh1 = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    if (a.bias && a.fast_epi) { bvh0 = a.bias[cow + AccSet<M16, MR>::chan(0, lane)]; bvh1 = a.bias[cow + AccSet<M16, MR>::chan(4, lane)]; }
+  }
   if constexpr (TS > 1) {
     // Tap-split main loop (16x16x32 form): stage (chunk, th) holds the chunk's patch and kernel rows [th*KYS, (th+1)*KYS) of its
     // weights; the patch is committed with th == 0 and stays for the chunk's TS weight pieces.  Same issue-early / write-late
@@ -475,9 +484,6 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
 
   // ---- epilogue (see srganfd.h for the formula) ----
   if (SRGANFD_DBG(a.dbg, 4)) { if (A_.get(0, 0) == 123.456f) ((float*)a.y)[0] = 1.f; return; }
-  float alpha = a.alpha;
-  if (a.alpha_dev) alpha *= *a.alpha_dev;
-  const int cow = (nb * WN + wn) * 32;      // first output channel of this wave; element e of a lane sits at channel cow + chan(e, lane)
   if (a.fast_epi) {
     // (1) per-channel part (alpha, bias, activation, scale) on the accumulators -> fp32 LDS tile
     // [pixel][channel]; (2) 16 output bytes per lane: residuals / LeakyReLU' mask via 16-byte global
@@ -513,7 +519,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     __syncthreads();   // all waves are done with the staging buffers
     {
       // a lane's 16 values per row cover one channel (32x32 form) or two (16x16 form: elements 0-3 / 8-11 vs 4-7 / 12-15)
-      const float bv0 = a.bias ? a.bias[cow + A_.chan(0, lane)] : 0.f, bv1 = a.bias ? a.bias[cow + A_.chan(4, lane)] : 0.f;
+      float bv0 = bvh0, bv1 = bvh1;
+      if constexpr (sizeof(T) != 2) { bv0 = a.bias ? a.bias[cow + A_.chan(0, lane)] : 0.f; bv1 = a.bias ? a.bias[cow + A_.chan(4, lane)] : 0.f; }
       // the activation as ONE select per element: factor of the negative side = slope (LeakyReLU), 0 (ReLU), 1 (none).  Written
       // as `if (act == ...)` inside the loop the compiler emitted two scalar compares and branches per element (630 branches in this
       // epilogue's ISA), and every wave walked them.
