@@ -177,6 +177,17 @@ int srganfd_wgrad_plan_build(const srganfd_wgrad_shape* s, const srganfd_wgrad_c
 int srganfd_conv2d_wgrad(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy,
                          float* grads, const float* scalars, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* The same in two steps, for launches whose slab reductions can share one kernel (the 69 dense blocks of the generator: the
+ * reduction is latency-bound at ~20 us whatever it reduces): _partial runs the MFMA kernel only and leaves the fp32 partial slabs in
+ * `workspace` (one workspace per pending launch); _reduce_batch finishes up to 8 pending launches of the same kernel size --
+ * identical results to srganfd_conv2d_wgrad (same summation order per element). */
+typedef struct {
+  const void* plan_host; const void* plan_dev;
+  float* grads; const float* scalars; const void* workspace;
+} srganfd_wgrad_reduce_job;
+int srganfd_conv2d_wgrad_partial(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int srganfd_wgrad_reduce_batch(const srganfd_wgrad_reduce_job* jobs, int32_t njobs, void* stream);
 
 /* ---- boundary layout conversion (the reference's modules take/return NCHW fp32) ---- */
 /* BSRGAN.forward input (model.py:366): NCHW fp32 -> NHWC dtype view, zero padded to cpad channels */

@@ -35,6 +35,10 @@ class ConvArgs(C.Structure):
     ]
 
 
+class WgradReduceJob(C.Structure):
+    _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("grads", C.c_void_p), ("scalars", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class PackSeg(C.Structure):
     _fields_ = [
         ("src_off", C.c_int64), ("scale_off", C.c_int64), ("co_src", C.c_int32), ("ci_src", C.c_int32),
@@ -80,6 +84,8 @@ SYMBOLS = {
     "srganfd_wgrad_plan_bytes": (C.c_size_t, [C.POINTER(WgradShape), C.POINTER(WgradConv)]),
     "srganfd_wgrad_plan_build": (C.c_int, [C.POINTER(WgradShape), C.POINTER(WgradConv), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]),
+    "srganfd_conv2d_wgrad_partial": (C.c_int, [C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "srganfd_wgrad_reduce_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "srganfd_conv2d_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
     "srganfd_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, View, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -23,6 +23,7 @@ int pack_weights_impl(const srganfd_pack_job* jobs_dev, int njobs, long long max
 size_t wgrad_plan_bytes_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs);
 int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs, void* plan_host, size_t plan_bytes,
                           size_t* workspace_bytes);
+int wgrad_reduce_batch_impl(const srganfd_wgrad_reduce_job* jobs, int njobs, hipStream_t stream);
 int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads, const float* scalars,
                void* workspace, size_t workspace_bytes, hipStream_t stream);
 int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s);
@@ -125,8 +126,16 @@ int srganfd_wgrad_plan_build(const srganfd_wgrad_shape* s, const srganfd_wgrad_c
                              size_t* workspace_bytes) {
   return wgrad_plan_build_impl(s, convs, plan_host, plan_bytes, workspace_bytes);
 }
+int srganfd_conv2d_wgrad_partial(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return wgrad_impl(plan_host, plan_dev, x, dy, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int srganfd_wgrad_reduce_batch(const srganfd_wgrad_reduce_job* jobs, int32_t njobs, void* stream) {
+  return wgrad_reduce_batch_impl(jobs, njobs, (hipStream_t)stream);
+}
 int srganfd_conv2d_wgrad(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads,
                          const float* scalars, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grads) return srganfd::set_err(SRGANFD_EINVAL, "wgrad: null gradient pointer (srganfd_conv2d_wgrad_partial is the reduce-later form)");
   return wgrad_impl(plan_host, plan_dev, x, dy, grads, scalars, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -553,9 +553,19 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
 // One block = one (task, tap); one thread = one element of its 32x32 fp32 tile (1024 threads: a launch has only
 // taps x tasks ~ 230 blocks, so the memory parallelism has to come from threads), eight slabs in flight per thread
 // (independent accumulators, fixed summation order -> bitwise reproducible).
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgTask* __restrict__ tasks, const float* __restrict__ slabs,
-                                                            const float* __restrict__ bslabs, float* __restrict__ grads,
-                                                            const float* __restrict__ scalars, int ntap_wave) {
+struct WgRedJob { const WgTask* tasks; const float* slabs; const float* bslabs; float* grads; const float* scalars; int ntasks; int pad_; };
+static constexpr int kRedBatch = 8;
+struct WgRedJobs { WgRedJob j[kRedBatch]; };
+// blockIdx.z selects the job: several weight-gradient launches (dense blocks) reduced by ONE launch -- the kernel is bound by load round
+// trips at ~17-23 us whatever it reduces, so four blocks' slabs cost little more than one's
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgRedJobs jobs, int ntap_wave) {
+  const WgRedJob& J = jobs.j[blockIdx.z];
+  if ((int)blockIdx.y >= J.ntasks) return;
+  const WgTask* __restrict__ tasks = J.tasks;
+  const float* __restrict__ slabs = J.slabs;
+  const float* __restrict__ bslabs = J.bslabs;
+  float* __restrict__ grads = J.grads;
+  const float* __restrict__ scalars = J.scalars;
   const WgTask T = tasks[blockIdx.y];
   const int KT = T.ksize * T.ksize;
   const int tl = blockIdx.x;              // tap
@@ -785,9 +795,10 @@ static int launch_wgrad(const WgHeader& H, const WgK& k, hipStream_t stream) {
   return H.dy_upad == 2 ? launch_wgrad2<T, KS, STRIDE, 1, 2>(H, k, stream) : launch_wgrad2<T, KS, STRIDE, 1, 1>(H, k, stream);
 }
 
+int wgrad_reduce_batch_impl(const srganfd_wgrad_reduce_job* jobs, int njobs, hipStream_t stream);
 int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srganfd_view dy, float* grads, const float* scalars,
                void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!plan_host || !plan_dev || !x.ptr || !dy.ptr || !grads || !workspace) return set_err(SRGANFD_EINVAL, "wgrad: null pointer");
+  if (!plan_host || !plan_dev || !x.ptr || !dy.ptr || !workspace) return set_err(SRGANFD_EINVAL, "wgrad: null pointer");
   const WgHeader& H = *(const WgHeader*)plan_host;
   if (H.magic != kWgMagic) return set_err(SRGANFD_EINVAL, "wgrad: bad plan");
   if ((size_t)H.Hin * H.Win * (size_t)x.cstride >= 0x7fffffffULL || (size_t)H.Hout * H.Wout * (size_t)dy.cstride >= 0x7fffffffULL)
@@ -813,9 +824,30 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   else rc = WG_BY_TYPE(1, 1);
 #undef WG_BY_TYPE
   if (rc != SRGANFD_OK) return rc;
-  const WgTask* tasks_dev = (const WgTask*)((const char*)plan_dev + H.tasks_off);
-  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(H.ntap_wave, H.ntasks), dim3(1024), 0, stream, tasks_dev,
-                     (const float*)k.slabs, (const float*)k.bslabs, grads, scalars, H.ntap_wave);
+  if (!grads) return SRGANFD_OK;          // srganfd_conv2d_wgrad_partial: the slabs stay in the workspace for srganfd_wgrad_reduce_batch
+  srganfd_wgrad_reduce_job job = {plan_host, plan_dev, grads, scalars, workspace};
+  return wgrad_reduce_batch_impl(&job, 1, stream);
+}
+
+int wgrad_reduce_batch_impl(const srganfd_wgrad_reduce_job* jobs, int njobs, hipStream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > kRedBatch) return set_err(SRGANFD_EINVAL, "wgrad_reduce_batch: 1..%d jobs", kRedBatch);
+  WgRedJobs J;
+  memset(&J, 0, sizeof(J));
+  int ntap = 0, maxtasks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const srganfd_wgrad_reduce_job& q = jobs[i];
+    if (!q.plan_host || !q.plan_dev || !q.grads || !q.workspace) return set_err(SRGANFD_EINVAL, "wgrad_reduce_batch: null pointer in job %d", i);
+    const WgHeader& H = *(const WgHeader*)q.plan_host;
+    if (H.magic != kWgMagic) return set_err(SRGANFD_EINVAL, "wgrad_reduce_batch: bad plan in job %d", i);
+    if (i && H.ntap_wave != ntap) return set_err(SRGANFD_EINVAL, "wgrad_reduce_batch: jobs of one batch share the kernel size");
+    ntap = H.ntap_wave;
+    if (H.ntasks > maxtasks) maxtasks = H.ntasks;
+    J.j[i].tasks = (const WgTask*)((const char*)q.plan_dev + H.tasks_off);
+    J.j[i].slabs = (const float*)q.workspace;
+    J.j[i].bslabs = (const float*)q.workspace + H.bias_slab_off;
+    J.j[i].grads = q.grads; J.j[i].scalars = q.scalars; J.j[i].ntasks = H.ntasks;
+  }
+  SRGANFD_LAUNCH(wgrad_reduce_kernel, dim3(ntap, maxtasks, njobs), dim3(1024), 0, stream, J, ntap);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -435,7 +435,7 @@ class TrunkEngine:
                 kdim = Cc + step * G
                 bw.append(("conv", ops.conv_args(dtc, VD(di), VD(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
                                                  mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
-            bw.append(("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight")))
+            bw.append(("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight"), i))     # 6th field: dense block (batched reduction)
             if self.full and R >= 4 and i == R // 2:      # upper half of the trunk is final: second bucket
                 bw.append(("ready", self._poff(pre + "conv1.weight"), self._poff("conv2.weight")))
             dst = VD(dyb(i - 1)) if i > 0 else V(sp.dx0)
@@ -453,6 +453,9 @@ class TrunkEngine:
         bw.append(("ready", 0, covered))
         sp.bw = bw
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        # four more workspaces of the dense-block plan's size for the batched slab reduction (34 MB each at B=32, 128x128)
+        dense_ws = max((p_.workspace_bytes for p_ in plans.values()), default=0)
+        sp.wg_ws4 = [torch.empty(dense_ws, dtype=torch.uint8, device=device) for _ in range(4)] if (dense_ws and _BATCH_REDUCE) else None
 
     # -- execution ----------------------------------------------------------------------------
     def forward(self, x: Tensor, train: bool) -> Tensor:
@@ -506,6 +509,21 @@ class TrunkEngine:
             A.check(L.srganfd_nchw_to_nhwc(dout.data_ptr(), N, self.Cc, H, W, A.view(sp.dy[(self.R - 1) % 4]), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
         gptr = flat_grad.data_ptr()
         rec = profiling.REC
+        pend_red = []          # dense-block weight-gradient launches whose slabs wait for the batched reduction
+
+        def flush_reduce():
+            if not pend_red:
+                return
+            jobs = (A.WgradReduceJob * len(pend_red))()
+            for j, (plan, goff, ws) in zip(jobs, pend_red):
+                j.plan_host, j.plan_dev = C.addressof(plan.host), plan.dev.data_ptr()
+                j.grads, j.scalars, j.workspace = gptr + 4 * goff, None, ws.data_ptr()
+            run = lambda: A.check(L.srganfd_wgrad_reduce_batch(jobs, len(pend_red), st), "wgrad_reduce_batch")
+            if rec is None:
+                run()
+            else:
+                rec.bracket("wgrad_reduce_batch", (0.0, float(sum(w.numel() for _, _, w in pend_red))), run)
+            pend_red.clear()
         for item in sp.bw:
             kind = item[0]
             if kind == "conv":
@@ -517,23 +535,43 @@ class TrunkEngine:
                     a = item[1]
                     rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
             elif kind == "wgrad":
-                _, plan, xv, dyv, goff = item
-                run = lambda: A.check(L.srganfd_conv2d_wgrad(plan.host, plan.dev.data_ptr(), xv, dyv, gptr + 4 * goff, None,
-                                                             sp.wg_ws.data_ptr(), sp.wg_ws.numel(), st), "conv2d_wgrad")
-                if rec is None:
-                    run()
+                plan, xv, dyv, goff = item[1:5]
+                if len(item) > 5 and sp.wg_ws4 is not None:
+                    # dense block: MFMA kernel now, slabs into one of four workspaces; the slab reduction of up to four blocks is ONE
+                    # launch (srganfd_wgrad_reduce_batch: the reduction is latency-bound at ~20 us whatever it reduces)
+                    ws = sp.wg_ws4[len(pend_red)]
+                    run = lambda: A.check(L.srganfd_conv2d_wgrad_partial(plan.host, plan.dev.data_ptr(), xv, dyv, ws.data_ptr(), ws.numel(), st),
+                                          "conv2d_wgrad_partial")
+                    if rec is None:
+                        run()
+                    else:
+                        rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
+                    pend_red.append((plan, goff, ws))
+                    if len(pend_red) == len(sp.wg_ws4):
+                        flush_reduce()
                 else:
-                    rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
+                    flush_reduce()                      # the launches share workspace slot 0
+                    run = lambda: A.check(L.srganfd_conv2d_wgrad(plan.host, plan.dev.data_ptr(), xv, dyv, gptr + 4 * goff, None,
+                                                                 sp.wg_ws.data_ptr(), sp.wg_ws.numel(), st), "conv2d_wgrad")
+                    if rec is None:
+                        run()
+                    else:
+                        rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
             elif kind == "ready":
+                flush_reduce()
                 if on_ready is not None:
                     on_ready(flat_grad, item[1], item[2])
             else:
                 item[1]()
+        flush_reduce()
         dx = None
         if need_dx and not self.full:
             dx = torch.empty(N, self.Cc, H, W, dtype=torch.float32, device=sp.device)
             A.check(L.srganfd_nhwc_to_nchw(A.view(sp.dx0), dtc, N, self.Cc, H, W, dx.data_ptr(), 0, st), "nhwc_to_nchw")
         return flat_grad, dx
+
+
+_BATCH_REDUCE = os.environ.get("SRGANFD_BATCH_REDUCE", "1") != "0"
 
 
 class _TrunkFn(torch.autograd.Function):

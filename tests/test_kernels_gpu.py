@@ -275,3 +275,39 @@ def test_resample_bwd_lrelu_equals_two_passes(dtype):
         assert torch.equal(masked, two)
     else:
         assert (masked.float() - two.float()).abs().max().item() < tol * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_wgrad_partial_plus_batched_reduction_equals_fused_call(dtype):
+    """srganfd_conv2d_wgrad_partial + srganfd_wgrad_reduce_batch (several launches' slabs reduced by one kernel: the generator's
+    dense blocks) give bit for bit what srganfd_conv2d_wgrad gives per launch."""
+    import ctypes as C
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(6)
+    dtc = ops.DT[dtype]
+    n, h, w, cx, cy = 2, 24, 40, 64, 64
+    convs = [dict(cin=64, cout=32, co_lo=32, dw_off=0, db_off=32 * 64 * 9, co_dst=32, ci_dst=64),
+             dict(cin=32, cout=32, co_lo=0, dw_off=32 * 64 * 9 + 32, db_off=-1, co_dst=32, ci_dst=32)]
+    total = 32 * 64 * 9 + 32 + 32 * 32 * 9
+    plan = ops.WgradPlan(torch.device("cuda"), dtc, n, h, w, cx, cy, convs)
+    L, st = A.lib(), A.stream_ptr()
+    inputs = [((torch.randn(n, h, w, cx, device="cuda") * 0.5).to(dtype), (torch.randn(n, h, w, cy, device="cuda") * 0.1).to(dtype)) for _ in range(3)]
+    fused, batched = [], []
+    ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
+    for x, dy in inputs:
+        g = torch.full((total,), 7.0, device="cuda")
+        plan.run(A.view(x), A.view(dy), g, ws)
+        fused.append(g)
+    wss = [torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda") for _ in inputs]
+    jobs = (A.WgradReduceJob * len(inputs))()
+    for j, (x, dy), w_ in zip(jobs, inputs, wss):
+        A.check(L.srganfd_conv2d_wgrad_partial(plan.host, plan.dev.data_ptr(), A.view(x), A.view(dy), w_.data_ptr(), w_.numel(), st))
+        g = torch.full((total,), 7.0, device="cuda")
+        batched.append(g)
+        j.plan_host, j.plan_dev, j.grads, j.scalars, j.workspace = C.addressof(plan.host), plan.dev.data_ptr(), g.data_ptr(), None, w_.data_ptr()
+    A.check(L.srganfd_wgrad_reduce_batch(jobs, len(inputs), st))
+    torch.cuda.synchronize()
+    for a, b in zip(fused, batched):
+        assert torch.equal(a, b) and a.abs().max().item() > 0
+    with pytest.raises(A.SrganfdError):
+        A.check(L.srganfd_wgrad_reduce_batch(jobs, 9, st))
