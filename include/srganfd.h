@@ -241,10 +241,26 @@ int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, floa
 int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols,
                           int32_t training, float eps, float* sigma_out, float* inv_sigma_out,
                           float* workspace, void* stream);
+/* The same for several layers at once (the discriminators normalise 8 / 20 layers before every forward pass: four dependent
+ * 5-14 us kernels per layer are launch latency, not work).  jobs: HOST array; each layer is computed exactly as by a call of its
+ * own (bit-identical); each job needs its own workspace of ceil(rows / 32) * cols + rows floats. */
+#define SRGANFD_SN_BATCH 8        /* layers per launch; longer job lists run in groups */
+typedef struct srganfd_sn_job {
+  const float* w_orig; float* u; float* v; float* sigma_out; float* inv_sigma_out; float* workspace;
+  int32_t rows, cols;
+} srganfd_sn_job;
+int srganfd_spectral_norm_batch(const srganfd_sn_job* jobs, int32_t njobs, int32_t training, float eps, void* stream);
 /* dW_orig = beta*dW_orig + (G - <G,W_orig>/sigma * u v^T)/sigma ; workspace >= 1025 floats */
 int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const float* u, const float* v,
                                const float* inv_sigma, float* dw_orig, int32_t rows, int32_t cols,
                                float beta, float* workspace, void* stream);
+/* Several layers at once (jobs: HOST array, each with its own 1025-float workspace), bit-identical to per-layer calls. */
+typedef struct srganfd_sn_grad_job {
+  const float* g_weight; const float* w_orig; const float* u; const float* v; const float* inv_sigma;
+  float* dw_orig; float* workspace;
+  int32_t rows, cols;
+} srganfd_sn_grad_job;
+int srganfd_spectral_norm_grad_batch(const srganfd_sn_grad_job* jobs, int32_t njobs, float beta, void* stream);
 
 /* ---- fused Adam + EMA over flat buffers (torch.optim.Adam maths, train_bsrgan.py:311-323,436,466;
  * AveragedModel with the reference's avg_fn, :290-291,470).  ema_mode: 0 none, 1 copy (first

@@ -39,6 +39,16 @@ class WgradReduceJob(C.Structure):
     _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("grads", C.c_void_p), ("scalars", C.c_void_p), ("workspace", C.c_void_p)]
 
 
+class SnJob(C.Structure):
+    _fields_ = [("w_orig", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma_out", C.c_void_p), ("inv_sigma_out", C.c_void_p),
+                ("workspace", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class SnGradJob(C.Structure):
+    _fields_ = [("g_weight", C.c_void_p), ("w_orig", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("inv_sigma", C.c_void_p),
+                ("dw_orig", C.c_void_p), ("workspace", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class PackSeg(C.Structure):
     _fields_ = [
         ("src_off", C.c_int64), ("scale_off", C.c_int64), ("co_src", C.c_int32), ("ci_src", C.c_int32),
@@ -101,6 +111,8 @@ SYMBOLS = {
     "srganfd_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_spectral_norm_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "srganfd_spectral_norm_grad_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_adam_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "srganfd_nonfinite_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -147,6 +159,12 @@ SYMBOLS = {
 
 LOSS_WS_FLOATS = 2049
 SN_WS_FLOATS = 16 * 8192 + 1024        # srganfd_spectral_norm: ceil(rows / 32) * cols + rows for rows <= 512, cols <= 8192
+SN_GRAD_WS_FLOATS = 1028               # srganfd_spectral_norm_grad: 1025, kept 16-byte aligned per job
+
+
+def sn_ws_floats(rows: int, cols: int) -> int:
+    """workspace of one srganfd_spectral_norm job (16-byte aligned)"""
+    return ((rows + 31) // 32 * cols + rows + 3) // 4 * 4
 _lib = None
 
 

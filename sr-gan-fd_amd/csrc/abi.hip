@@ -39,6 +39,8 @@ int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStr
 int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s);
 int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
                     float grad_scale, float* ws, hipStream_t s);
+int spectral_norm_grad_batch_impl(const srganfd_sn_grad_job* jobs, int njobs, float beta, hipStream_t s);
+int spectral_norm_batch_impl(const srganfd_sn_job* jobs, int njobs, int training, float eps, hipStream_t s);
 int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s);
 int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
                             float beta, float* ws, hipStream_t s);
@@ -183,9 +185,15 @@ int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows,
                           float* inv_sigma_out, float* workspace, void* stream) {
   return spectral_norm_impl(w_orig, u, v, rows, cols, training, eps, sigma_out, inv_sigma_out, workspace, (hipStream_t)stream);
 }
+int srganfd_spectral_norm_batch(const srganfd_sn_job* jobs, int32_t njobs, int32_t training, float eps, void* stream) {
+  return spectral_norm_batch_impl(jobs, njobs, training, eps, (hipStream_t)stream);
+}
 int srganfd_spectral_norm_grad(const float* g_weight, const float* w_orig, const float* u, const float* v, const float* inv_sigma, float* dw_orig,
                                int32_t rows, int32_t cols, float beta, float* workspace, void* stream) {
   return spectral_norm_grad_impl(g_weight, w_orig, u, v, inv_sigma, dw_orig, rows, cols, beta, workspace, (hipStream_t)stream);
+}
+int srganfd_spectral_norm_grad_batch(const srganfd_sn_grad_job* jobs, int32_t njobs, float beta, void* stream) {
+  return spectral_norm_grad_batch_impl(jobs, njobs, beta, (hipStream_t)stream);
 }
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode,

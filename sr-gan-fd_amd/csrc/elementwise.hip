@@ -507,17 +507,27 @@ __global__ __launch_bounds__(256) void finish_sigmoid_mean_kernel(const float* _
 // W^T u in row chunks of kSnRows: block (x, y) sums rows [y*kSnRows, ...) of 256 columns into part[y][k]; the normalise kernel adds the
 // chunks in order (deterministic).  One thread per column over ALL rows left the chip with <= 18 workgroups for 71 us per layer.
 static constexpr int kSnRows = 32;
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ part, int rows, int cols) {
+// Up to kSnBatch layers per launch (blockIdx.z / .y picks the layer): eight layers x four dependent 5-14 us kernels are launch latency,
+// not work.  Every layer is summed exactly as in a launch of its own, so batching does not change a bit.
+static constexpr int kSnBatch = SRGANFD_SN_BATCH;
+struct SnJobs { srganfd_sn_job j[kSnBatch]; };
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const SnJobs jobs) {
+  const srganfd_sn_job& J = jobs.j[blockIdx.z];
+  const int rows = J.rows, cols = J.cols;
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= cols) return;
   const int r0 = blockIdx.y * kSnRows, r1 = min(rows, r0 + kSnRows);
+  if (k >= cols || r0 >= rows) return;
+  const float* __restrict__ W = J.w_orig; const float* __restrict__ u = J.u;
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += W[(size_t)r * cols + k] * u[r];
-  part[(size_t)blockIdx.y * cols + k] = s;
+  J.workspace[(size_t)blockIdx.y * cols + k] = s;
 }
-__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out, int n, float eps) {
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const SnJobs jobs, float eps) {
   __shared__ float sh[16];
   __shared__ float inv;
+  const srganfd_sn_job& J = jobs.j[blockIdx.x];
+  const int n = J.cols, nparts = (J.rows + kSnRows - 1) / kSnRows;
+  const float* __restrict__ part = J.workspace; float* __restrict__ out = J.v;
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) {
     float v = 0.f;
@@ -530,19 +540,25 @@ __global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* __restr
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 1024) out[i] *= inv;
 }
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ t, int rows, int cols) {
+__device__ __forceinline__ float* sn_t(const srganfd_sn_job& J) { return J.workspace + (size_t)((J.rows + kSnRows - 1) / kSnRows) * J.cols; }
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const SnJobs jobs) {
   __shared__ float sh[4];
-  const int r = blockIdx.x;
+  const srganfd_sn_job& J = jobs.j[blockIdx.y];
+  const int r = blockIdx.x, cols = J.cols;
+  if (r >= J.rows) return;
+  const float* __restrict__ W = J.w_orig; const float* __restrict__ v = J.v;
   float s = 0.f;
   for (int k = threadIdx.x; k < cols; k += 256) s += W[(size_t)r * cols + k] * v[k];
   const float tot = block_reduce_sum(s, sh);
-  if (threadIdx.x == 0) t[r] = tot;
+  if (threadIdx.x == 0) sn_t(J)[r] = tot;
 }
 // u = normalize(t) (only if update_u), sigma = u . t, inv_sigma = 1/sigma
-__global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ t, float* __restrict__ u, int rows, float eps, int update_u,
-                                                        float* __restrict__ sigma_out, float* __restrict__ inv_sigma_out) {
+__global__ __launch_bounds__(256) void sn_finish_kernel(const SnJobs jobs, float eps, int update_u) {
   __shared__ float sh[4];
   __shared__ float inv;
+  const srganfd_sn_job& J = jobs.j[blockIdx.x];
+  const int rows = J.rows;
+  const float* __restrict__ t = sn_t(J); float* __restrict__ u = J.u;
   float s = 0.f;
   if (update_u) {
     for (int i = threadIdx.x; i < rows; i += 256) s += t[i] * t[i];
@@ -555,22 +571,43 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict_
   s = 0.f;
   for (int i = threadIdx.x; i < rows; i += 256) s += u[i] * t[i];
   const float sig = block_reduce_sum(s, sh);
-  if (threadIdx.x == 0) { *sigma_out = sig; *inv_sigma_out = 1.f / sig; }
+  if (threadIdx.x == 0) { *J.sigma_out = sig; *J.inv_sigma_out = 1.f / sig; }
 }
 // gradient through weight = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
 //   dW_orig = (G - <G, W_orig>/sigma * u v^T) / sigma        with G = dL/d(weight)
-__global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ G, const float* __restrict__ W, size_t n, float* __restrict__ partial) {
+// Batched like the forward kernels: blockIdx.y picks the layer; every layer keeps the grid (number of partial sums, element stride) a
+// launch of its own would have, so the sums are bit-identical.  kSnGradBlocks = the loss entry points' kRedBlocks.
+static constexpr int kSnGradBlocks = 1024;
+struct SnGradJobs { srganfd_sn_grad_job j[kSnBatch]; };
+__device__ __forceinline__ unsigned sn_grad_blocks(size_t n) { const size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > kSnGradBlocks ? kSnGradBlocks : g)); }
+__global__ __launch_bounds__(256) void sn_dot_partial_kernel(const SnGradJobs jobs) {
   __shared__ float sh[4];
+  const srganfd_sn_grad_job& J = jobs.j[blockIdx.y];
+  const size_t n = (size_t)J.rows * J.cols;
+  const unsigned g = sn_grad_blocks(n);
+  if (blockIdx.x >= g) return;
+  const float* __restrict__ G = J.g_weight; const float* __restrict__ W = J.w_orig;
   float s = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += G[i] * W[i];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)g * 256) s += G[i] * W[i];
   const float r = block_reduce_sum(s, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  if (threadIdx.x == 0) J.workspace[blockIdx.x] = r;
 }
-__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
-                                                      const float* __restrict__ dot, const float* __restrict__ inv_sigma, float* __restrict__ dW,
-                                                      int rows, int cols, float beta) {
-  const size_t n = (size_t)rows * cols;
-  const float is = *inv_sigma, coef = *dot * is;
+__global__ __launch_bounds__(256) void sn_dot_finish_kernel(const SnGradJobs jobs) {
+  __shared__ float sh[4];
+  const srganfd_sn_grad_job& J = jobs.j[blockIdx.x];
+  const int nblk = (int)sn_grad_blocks((size_t)J.rows * J.cols);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += J.workspace[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) J.workspace[kSnGradBlocks] = 0.f + r * 1.f;
+}
+__global__ __launch_bounds__(256) void sn_grad_kernel(const SnGradJobs jobs, float beta) {
+  const srganfd_sn_grad_job& J = jobs.j[blockIdx.y];
+  const int cols = J.cols;
+  const size_t n = (size_t)J.rows * cols;
+  const float* __restrict__ G = J.g_weight; const float* __restrict__ u = J.u; const float* __restrict__ v = J.v;
+  float* __restrict__ dW = J.dw_orig;
+  const float is = *J.inv_sigma, coef = J.workspace[kSnGradBlocks] * is;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / cols), k = (int)(i % cols);
     const float g = (G[i] - coef * u[r] * v[k]) * is;
@@ -1336,31 +1373,62 @@ int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStr
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
-// ws: cols + rows floats
-int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s) {
-  if (!W || !u || !v || !sigma || !inv_sigma || !ws || rows <= 0 || cols <= 0) return set_err(SRGANFD_EINVAL, "spectral_norm: bad args");
-  const int nparts = (rows + kSnRows - 1) / kSnRows;
-  float* part = ws; float* t = ws + (size_t)nparts * cols;
-  if (training) {
-    SRGANFD_LAUNCH(sn_wt_u_kernel, dim3((cols + 255) / 256, nparts), dim3(256), 0, s, W, (const float*)u, part, rows, cols);
-    SRGANFD_LAUNCH(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)part, nparts, v, cols, eps);
+// each job's workspace: ceil(rows / 32) * cols + rows floats
+int spectral_norm_batch_impl(const srganfd_sn_job* jobs, int njobs, int training, float eps, hipStream_t s) {
+  if (!jobs || njobs <= 0) return set_err(SRGANFD_EINVAL, "spectral_norm: no jobs");
+  for (int b = 0; b < njobs; b += kSnBatch) {
+    const int nb = std::min(kSnBatch, njobs - b);
+    SnJobs J;
+    int max_rows = 0, max_cols = 0;
+    for (int i = 0; i < nb; ++i) {
+      const srganfd_sn_job& q = jobs[b + i];
+      if (!q.w_orig || !q.u || !q.v || !q.sigma_out || !q.inv_sigma_out || !q.workspace || q.rows <= 0 || q.cols <= 0)
+        return set_err(SRGANFD_EINVAL, "spectral_norm: bad args");
+      J.j[i] = q; max_rows = std::max(max_rows, q.rows); max_cols = std::max(max_cols, q.cols);
+    }
+    for (int i = nb; i < kSnBatch; ++i) J.j[i] = J.j[0];            // never indexed: the grids stop at nb
+    if (training) {
+      SRGANFD_LAUNCH(sn_wt_u_kernel, dim3((max_cols + 255) / 256, (max_rows + kSnRows - 1) / kSnRows, nb), dim3(256), 0, s, J);
+      SRGANFD_LAUNCH(sn_normalize_kernel, dim3(nb), dim3(1024), 0, s, J, eps);
+    }
+    SRGANFD_LAUNCH(sn_w_v_kernel, dim3(max_rows, nb), dim3(256), 0, s, J);
+    SRGANFD_LAUNCH(sn_finish_kernel, dim3(nb), dim3(256), 0, s, J, eps, training);
   }
-  SRGANFD_LAUNCH(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, W, (const float*)v, t, rows, cols);
-  SRGANFD_LAUNCH(sn_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)t, u, rows, eps, training, sigma, inv_sigma);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
-// ws: kRedBlocks + 1 floats
-int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
-                            float beta, float* ws, hipStream_t s) {
-  if (!G || !W || !u || !v || !inv_sigma || !dW || !ws) return set_err(SRGANFD_EINVAL, "spectral_norm_grad: bad args");
-  const size_t n = (size_t)rows * cols;
-  const unsigned g = grid_for(n, 256, kRedBlocks);
-  SRGANFD_LAUNCH(sn_dot_partial_kernel, dim3(g), dim3(256), 0, s, G, W, n, ws);
-  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, 1.f, ws + kRedBlocks, 0);
-  SRGANFD_LAUNCH(sn_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, G, u, v, (const float*)(ws + kRedBlocks), inv_sigma, dW, rows, cols, beta);
+int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s) {
+  srganfd_sn_job q;
+  q.w_orig = W; q.u = u; q.v = v; q.sigma_out = sigma; q.inv_sigma_out = inv_sigma; q.workspace = ws; q.rows = rows; q.cols = cols;
+  return spectral_norm_batch_impl(&q, 1, training, eps, s);
+}
+// each job's workspace: kRedBlocks + 1 floats
+int spectral_norm_grad_batch_impl(const srganfd_sn_grad_job* jobs, int njobs, float beta, hipStream_t s) {
+  static_assert(kSnGradBlocks == kRedBlocks, "workspace contract of srganfd_spectral_norm_grad");
+  if (!jobs || njobs <= 0) return set_err(SRGANFD_EINVAL, "spectral_norm_grad: no jobs");
+  for (int b = 0; b < njobs; b += kSnBatch) {
+    const int nb = std::min(kSnBatch, njobs - b);
+    SnGradJobs J;
+    size_t max_n = 0;
+    for (int i = 0; i < nb; ++i) {
+      const srganfd_sn_grad_job& q = jobs[b + i];
+      if (!q.g_weight || !q.w_orig || !q.u || !q.v || !q.inv_sigma || !q.dw_orig || !q.workspace || q.rows <= 0 || q.cols <= 0)
+        return set_err(SRGANFD_EINVAL, "spectral_norm_grad: bad args");
+      J.j[i] = q; max_n = std::max(max_n, (size_t)q.rows * q.cols);
+    }
+    for (int i = nb; i < kSnBatch; ++i) J.j[i] = J.j[0];
+    SRGANFD_LAUNCH(sn_dot_partial_kernel, dim3(grid_for(max_n, 256, kRedBlocks), nb), dim3(256), 0, s, J);
+    SRGANFD_LAUNCH(sn_dot_finish_kernel, dim3(nb), dim3(256), 0, s, J);
+    SRGANFD_LAUNCH(sn_grad_kernel, dim3(grid_for(max_n), nb), dim3(256), 0, s, J, beta);
+  }
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
+}
+int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
+                            float beta, float* ws, hipStream_t s) {
+  srganfd_sn_grad_job q;
+  q.g_weight = G; q.w_orig = W; q.u = u; q.v = v; q.inv_sigma = inv_sigma; q.dw_orig = dW; q.workspace = ws; q.rows = rows; q.cols = cols;
+  return spectral_norm_grad_batch_impl(&q, 1, beta, s);
 }
 // flag = 1 if any element of x is inf or NaN (the found_inf of torch.cuda.amp.GradScaler.unscale_, train_bsrgan.py:436,466)
 __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, float* __restrict__ flag) {

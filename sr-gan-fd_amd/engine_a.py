@@ -110,20 +110,21 @@ class AesrganDiscriminatorEngine:
             pk = self._build_pack(dtc, device)
             pk["flat_ptr"] = flat.data_ptr()
             pk["scalars"] = torch.ones(2 * len(SN_LAYERS), dtype=torch.float32, device=device)
-            pk["sn_ws"] = torch.empty(A.SN_WS_FLOATS, dtype=torch.float32, device=device)
+            pk["sn_ws"] = torch.empty(sum(A.sn_ws_floats(self._wshape(n)[0], self._wshape(n)[1] * ks * ks) for n, ks, _, _ in SN_LAYERS),
+                                      dtype=torch.float32, device=device)
             self.packed[dtc] = pk
         return pk
 
     def _spectral_norm_and_pack(self, pk, training):
-        L, st = A.lib(), A.stream_ptr()
         flat = self.fp.flat
         sc = pk["scalars"].data_ptr()
+        layers = []
         for l, (name, ks, _, _) in enumerate(SN_LAYERS):
             co, ci = self._wshape(name)
             m = _mod(self.owner, name)
-            A.check(L.srganfd_spectral_norm(flat.data_ptr() + 4 * self._poff(name + ".weight_orig"), m.weight_u.data_ptr(), m.weight_v.data_ptr(),
-                                            co, ci * ks * ks, 1 if training else 0, 1e-12, sc + 8 * l, sc + 8 * l + 4, pk["sn_ws"].data_ptr(), st),
-                    "spectral_norm")
+            layers.append((flat.data_ptr() + 4 * self._poff(name + ".weight_orig"), m.weight_u.data_ptr(), m.weight_v.data_ptr(), co, ci * ks * ks,
+                           sc + 8 * l, sc + 8 * l + 4))
+        ops.spectral_norm_batch(layers, training, pk["sn_ws"])
         pk["table"].run(flat, pk["buf"], pk["scalars"])
 
     # ---- plan ----
@@ -362,7 +363,7 @@ class AesrganDiscriminatorEngine:
         sp.dx_conv = ops.conv_args(dtc, V(G["dx0"]), V(sp.dxp), Wp("b", "conv0"), N, H, W, nf, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
-        sp.sn_ws = torch.empty(2048, dtype=torch.float32, device=device)
+        sp.sn_ws = torch.empty(len(SN_LAYERS) * A.SN_GRAD_WS_FLOATS, dtype=torch.float32, device=device)
 
     # ---- execution ----
     def _run_conv(self, L, st, a, rec, what):
@@ -430,6 +431,7 @@ class AesrganDiscriminatorEngine:
         # the flat gradient also receives BatchNorm's dgamma/dbeta; frozen-parameter passes write them to scratch
         flat_grad = self.fp.new_grad(sp.device) if need_wgrad else sp.gtmp
         rec = profiling.REC
+        sn_grads = []
         for item in sp.bw:
             kind = item[0]
             if kind == "conv":
@@ -449,9 +451,8 @@ class AesrganDiscriminatorEngine:
                     co, ci = self._wshape(name)
                     off = 4 * self._poff(name + ".weight_orig")
                     m = _mod(self.owner, name)
-                    A.check(L.srganfd_spectral_norm_grad(sp.gtmp.data_ptr() + off, flat.data_ptr() + off, m.weight_u.data_ptr(), m.weight_v.data_ptr(),
-                                                         sp.inv_sigma.data_ptr() + 4 * (2 * sn_index + 1), flat_grad.data_ptr() + off, co, ci * ks * ks,
-                                                         0.0, sp.sn_ws.data_ptr(), st), "spectral_norm_grad")
+                    sn_grads.append((sp.gtmp.data_ptr() + off, flat.data_ptr() + off, m.weight_u.data_ptr(), m.weight_v.data_ptr(),
+                                     sp.inv_sigma.data_ptr() + 4 * (2 * sn_index + 1), flat_grad.data_ptr() + off, co, ci * ks * ks))
             elif kind == "bn_bwd":
                 xv, dyv, dxv, npix, Ck, pre, save = item[1]
                 if self.sync_bn is not None:
@@ -474,6 +475,7 @@ class AesrganDiscriminatorEngine:
                                                     flat_grad.data_ptr() + 4 * self._poff(pre + ".W.1.bias"), 0.0, sp.bn_ws.data_ptr(), st), "batchnorm_bwd")
             else:
                 item[1]()
+        ops.spectral_norm_grad_batch(sn_grads, sp.sn_ws)       # dL/d(W/sigma) -> dL/dW_orig for every normalised layer, batched
         dx = None
         if need_dx:
             A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv0)")

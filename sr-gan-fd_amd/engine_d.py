@@ -82,23 +82,24 @@ class DiscriminatorEngine:
             pk = self._build_pack(dtc, device)
             pk["flat_ptr"] = flat.data_ptr()
             pk["scalars"] = torch.ones(2 * len(SN_LAYERS), dtype=torch.float32, device=device)
-            pk["sn_ws"] = torch.empty(A.SN_WS_FLOATS, dtype=torch.float32, device=device)
+            pk["sn_ws"] = torch.empty(sum(A.sn_ws_floats(self.dims[n][0], self.dims[n][1] * k * k) for n, k, _ in SN_LAYERS),
+                                      dtype=torch.float32, device=device)
             self.packed[dtc] = pk
         return pk
 
     def _spectral_norm_and_pack(self, pk: dict, training: bool) -> None:
-        L, st = A.lib(), A.stream_ptr()
         flat = self.fp.flat
+        sc = pk["scalars"].data_ptr()
+        layers = []
         for l, (name, k, s) in enumerate(SN_LAYERS):
             co, ci, _, _ = self.dims[name]
             m = getattr(self.owner, name)[0]
             u, v = m.weight_u, m.weight_v
             if u.device != flat.device or not u.is_contiguous() or not v.is_contiguous():
                 raise A.SrganfdError("spectral-norm buffers must live on the module's GPU")
-            sc = pk["scalars"].data_ptr()
-            A.check(L.srganfd_spectral_norm(flat.data_ptr() + 4 * self._poff(f"{name}.0.weight_orig"), u.data_ptr(), v.data_ptr(),
-                                            co, ci * k * k, 1 if training else 0, 1e-12, sc + 8 * l, sc + 8 * l + 4,
-                                            pk["sn_ws"].data_ptr(), st), "spectral_norm")
+            layers.append((flat.data_ptr() + 4 * self._poff(f"{name}.0.weight_orig"), u.data_ptr(), v.data_ptr(), co, ci * k * k,
+                           sc + 8 * l, sc + 8 * l + 4))
+        ops.spectral_norm_batch(layers, training, pk["sn_ws"])            # all eight layers in four launches
         pk["table"].run(flat, pk["buf"], pk["scalars"])
 
     # ---- per-shape plan ----
@@ -235,7 +236,7 @@ class DiscriminatorEngine:
         sp.dx_conv = ops.conv_args(dtc, V(gD), V(sp.dxp), wptr + O[("b", "conv1")], N, H, W, 64, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
-        sp.sn_ws = torch.empty(2048, dtype=torch.float32, device=device)
+        sp.sn_ws = torch.empty(len(SN_LAYERS) * A.SN_GRAD_WS_FLOATS, dtype=torch.float32, device=device)
 
     # ---- execution ----
     def forward(self, x: Tensor, training: bool) -> Tensor:
@@ -279,6 +280,7 @@ class DiscriminatorEngine:
         flat = self.fp.flat
         flat_grad = self.fp.new_grad(sp.device) if need_wgrad else None
         rec = profiling.REC
+        sn_grads = []
         for item in sp.bw:
             kind = item[0]
             if kind == "conv":
@@ -304,11 +306,12 @@ class DiscriminatorEngine:
                     co, ci, k, _ = self.dims[name]
                     off = 4 * self._poff(f"{name}.0.weight_orig")
                     m = getattr(self.owner, name)[0]
-                    A.check(L.srganfd_spectral_norm_grad(sp.gtmp.data_ptr() + off, flat.data_ptr() + off, m.weight_u.data_ptr(), m.weight_v.data_ptr(),
-                                                         sp.inv_sigma.data_ptr() + 4 * (2 * sn_index + 1), flat_grad.data_ptr() + off, co, ci * k * k,
-                                                         0.0, sp.sn_ws.data_ptr(), st), "spectral_norm_grad")
+                    sn_grads.append((sp.gtmp.data_ptr() + off, flat.data_ptr() + off, m.weight_u.data_ptr(), m.weight_v.data_ptr(),
+                                     sp.inv_sigma.data_ptr() + 4 * (2 * sn_index + 1), flat_grad.data_ptr() + off, co, ci * k * k))
             else:
                 item[1]()
+        # dL/d(W/sigma) of every spectral-normalised layer sits in its own range of gtmp: one batched pass turns them into dL/dW_orig
+        ops.spectral_norm_grad_batch(sn_grads, sp.sn_ws)
         dx = None
         if need_dx:
             A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv1)")

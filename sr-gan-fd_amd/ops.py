@@ -5,6 +5,7 @@ Host code is plumbing only (device memory, streams); all arithmetic runs in libs
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -139,3 +140,39 @@ class WgradPlan:
                                              scalars.data_ptr() if scalars is not None else None,
                                              workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                              A.stream_ptr()), "conv2d_wgrad")
+
+
+# same-box A/B switch (0: one group of launches per layer, the round-1 form); both forms run in the HIP library and agree to the bit
+_SN_BATCH = os.environ.get("SRGANFD_SN_BATCH", "1") != "0"
+
+
+def spectral_norm_batch(layers: Sequence[tuple], training: bool, workspace: torch.Tensor, eps: float = 1e-12) -> None:
+    """layers: (w_orig_ptr, u_ptr, v_ptr, rows, cols, sigma_ptr, inv_sigma_ptr); all of them in ceil(n / 8) x 4 launches."""
+    if not _SN_BATCH:
+        for (w, u, v, rows, cols, sig, isig) in layers:
+            A.check(A.lib().srganfd_spectral_norm(w, u, v, rows, cols, 1 if training else 0, eps, sig, isig, workspace.data_ptr(), A.stream_ptr()), "spectral_norm")
+        return
+    arr = (A.SnJob * len(layers))()
+    off, base = 0, workspace.data_ptr()
+    for q, (w, u, v, rows, cols, sig, isig) in zip(arr, layers):
+        q.w_orig, q.u, q.v, q.sigma_out, q.inv_sigma_out, q.rows, q.cols = w, u, v, sig, isig, rows, cols
+        q.workspace = base + 4 * off
+        off += A.sn_ws_floats(rows, cols)
+    assert off <= workspace.numel() and workspace.dtype == torch.float32
+    A.check(A.lib().srganfd_spectral_norm_batch(arr, len(layers), 1 if training else 0, eps, A.stream_ptr()), "spectral_norm_batch")
+
+
+def spectral_norm_grad_batch(layers: Sequence[tuple], workspace: torch.Tensor, beta: float = 0.0) -> None:
+    """layers: (g_weight_ptr, w_orig_ptr, u_ptr, v_ptr, inv_sigma_ptr, dw_orig_ptr, rows, cols)."""
+    if not layers:
+        return
+    if not _SN_BATCH:
+        for (g, w, u, v, isig, dw, rows, cols) in layers:
+            A.check(A.lib().srganfd_spectral_norm_grad(g, w, u, v, isig, dw, rows, cols, beta, workspace.data_ptr(), A.stream_ptr()), "spectral_norm_grad")
+        return
+    arr = (A.SnGradJob * len(layers))()
+    assert len(layers) * A.SN_GRAD_WS_FLOATS <= workspace.numel() and workspace.dtype == torch.float32
+    for i, (q, (g, w, u, v, isig, dw, rows, cols)) in enumerate(zip(arr, layers)):
+        q.g_weight, q.w_orig, q.u, q.v, q.inv_sigma, q.dw_orig, q.rows, q.cols = g, w, u, v, isig, dw, rows, cols
+        q.workspace = workspace.data_ptr() + 4 * i * A.SN_GRAD_WS_FLOATS
+    A.check(A.lib().srganfd_spectral_norm_grad_batch(arr, len(layers), beta, A.stream_ptr()), "spectral_norm_grad_batch")

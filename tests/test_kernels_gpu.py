@@ -311,3 +311,57 @@ def test_wgrad_partial_plus_batched_reduction_equals_fused_call(dtype):
         assert torch.equal(a, b) and a.abs().max().item() > 0
     with pytest.raises(A.SrganfdError):
         A.check(L.srganfd_wgrad_reduce_batch(jobs, 9, st))
+
+
+def test_batched_spectral_norm_equals_per_layer_calls_and_torch():
+    """srganfd_spectral_norm_batch / _grad_batch (all normalised layers of a discriminator in one group of launches) against the
+    per-layer entry points -- bit for bit, including a list longer than one launch group and ragged shapes -- and the per-layer
+    result against torch's own power iteration (torch/nn/utils/spectral_norm.py:62-114) at 1e-5."""
+    import torch.nn.functional as F
+    from sr_gan_fd_amd import _abi as A, ops
+    L, st = A.lib(), A.stream_ptr()
+    torch.manual_seed(5)
+    shapes = [(128, 64 * 16), (256, 128 * 16), (512, 256 * 16), (256, 512 * 9), (128, 256 * 9), (64, 128 * 9), (64, 64 * 9), (64, 576),
+              (33, 70), (1, 5), (96, 1)]                                     # 11 layers: two launch groups, ragged tails
+    Ws = [torch.randn(r, c, device="cuda") for r, c in shapes]
+    us = [F.normalize(torch.randn(r, device="cuda"), dim=0) for r, _ in shapes]
+    vs = [F.normalize(torch.randn(c, device="cuda"), dim=0) for _, c in shapes]
+    for training in (True, False):
+        one = [(u.clone(), v.clone(), torch.zeros(2, device="cuda")) for u, v in zip(us, vs)]
+        for W, (u, v, sg) in zip(Ws, one):
+            ws = torch.empty(A.sn_ws_floats(*W.shape), device="cuda")
+            A.check(L.srganfd_spectral_norm(W.data_ptr(), u.data_ptr(), v.data_ptr(), W.shape[0], W.shape[1], int(training), 1e-12,
+                                            sg.data_ptr(), sg.data_ptr() + 4, ws.data_ptr(), st), "spectral_norm")
+        bat = [(u.clone(), v.clone(), torch.zeros(2, device="cuda")) for u, v in zip(us, vs)]
+        ws = torch.empty(sum(A.sn_ws_floats(*W.shape) for W in Ws), device="cuda")
+        ops.spectral_norm_batch([(W.data_ptr(), u.data_ptr(), v.data_ptr(), W.shape[0], W.shape[1], sg.data_ptr(), sg.data_ptr() + 4)
+                                 for W, (u, v, sg) in zip(Ws, bat)], training, ws)
+        torch.cuda.synchronize()
+        for W, a, b, u0, v0 in zip(Ws, one, bat, us, vs):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), W.shape
+            if training:
+                v1 = F.normalize(torch.mv(W.t(), u0), dim=0, eps=1e-12)
+                u1 = F.normalize(torch.mv(W, v1), dim=0, eps=1e-12)
+            else:
+                u1, v1 = u0, v0
+            sigma = torch.dot(u1, torch.mv(W, v1))
+            assert torch.allclose(a[0], u1, atol=1e-5) and torch.allclose(a[1], v1, atol=1e-5)
+            assert abs(a[2][0].item() - sigma.item()) <= 1e-5 * max(1.0, abs(sigma.item())) and abs(a[2][1].item() * sigma.item() - 1) < 1e-5
+    # gradient through W / sigma
+    Gs = [torch.randn_like(W) for W in Ws]
+    isg = [torch.tensor([1.0 / torch.dot(u, torch.mv(W, v)).item()], device="cuda") for W, u, v in zip(Ws, us, vs)]
+    one = [torch.full_like(W, 7.0) for W in Ws]
+    for W, G, u, v, i, d in zip(Ws, Gs, us, vs, isg, one):
+        ws = torch.empty(A.SN_GRAD_WS_FLOATS, device="cuda")
+        A.check(L.srganfd_spectral_norm_grad(G.data_ptr(), W.data_ptr(), u.data_ptr(), v.data_ptr(), i.data_ptr(), d.data_ptr(), W.shape[0], W.shape[1],
+                                             0.0, ws.data_ptr(), st), "spectral_norm_grad")
+    bat = [torch.full_like(W, 7.0) for W in Ws]
+    ws = torch.empty(len(Ws) * A.SN_GRAD_WS_FLOATS, device="cuda")
+    ops.spectral_norm_grad_batch([(G.data_ptr(), W.data_ptr(), u.data_ptr(), v.data_ptr(), i.data_ptr(), d.data_ptr(), W.shape[0], W.shape[1])
+                                  for W, G, u, v, i, d in zip(Ws, Gs, us, vs, isg, bat)], ws)
+    torch.cuda.synchronize()
+    for W, G, u, v, i, a, b in zip(Ws, Gs, us, vs, isg, one, bat):
+        assert torch.equal(a, b), W.shape
+        Wl = W.clone().requires_grad_(True)
+        ((Wl / torch.dot(u, torch.mv(Wl, v))) * G).sum().backward()
+        assert (a - Wl.grad).abs().max().item() <= 1e-4 * Wl.grad.abs().max().item()
