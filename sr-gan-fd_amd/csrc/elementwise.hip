@@ -140,6 +140,104 @@ __global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restric
   }
 }
 
+// ---- bilinear x2 (align_corners=False, model.py:150-158), row-grid forms: blockIdx.y = low-res row, blockIdx.z = image, one thread per
+// (low-res column, 16-byte channel vector).  The generic kernel above spends its time on 64-bit div/mod chains and per-thread tap tables;
+// here the row taps are wave-uniform, the column taps closed-form, and every address is 32-bit arithmetic on top of one 64-bit row base.
+// Same products and the same accumulation order per output as resample_vec_kernel<T, 1 / 2>: results are bit-identical.
+// forward: each thread writes the 2x2 high-res block of its low-res pixel from the 3x3 neighbourhood (9 loads per 4 stores, not 16)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_block_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int h, int w, int c, int cv_shift) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (unsigned)(w * cv)) return;
+  const int kx = cv_shift >= 0 ? (int)(i >> cv_shift) : (int)(i / (unsigned)cv), ch = ((int)i - kx * cv) * N;
+  const int ky = blockIdx.y;
+  const size_t img = blockIdx.z;
+  const int ys[3] = {max(ky - 1, 0), ky, min(ky + 1, h - 1)}, xs[3] = {max(kx - 1, 0), kx, min(kx + 1, w - 1)};
+  float t[3][3][N];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const size_t row = (img * h + ys[r]) * (size_t)w;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ldv<T>(a, (row + xs[q]) * aC + a0 + ch, t[r][q]);
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    // even output row: taps (k-1: .25, k: .75); odd: (k: .75, k+1: .25)
+    const int ra = dy, rb = dy + 1;
+    const float wya = dy ? 0.75f : 0.25f, wyb = dy ? 0.25f : 0.75f;
+    const size_t orow = (img * 2 * h + 2 * ky + dy) * (size_t)(2 * w) + 2 * kx;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int qa = dx, qb = dx + 1;
+      const float wxa = dx ? 0.75f : 0.25f, wxb = dx ? 0.25f : 0.75f;
+      float acc[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = wya * wxa * t[ra][qa][q];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wya * wxb * t[ra][qb][q];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wyb * wxa * t[rb][qa][q];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] += wyb * wxb * t[rb][qb][q];
+      stv<T>(b, (orow + dx) * (size_t)bC + b0 + ch, acc);
+    }
+  }
+}
+// adjoint (gather form): low-res pixel k collects high-res 2k-1 .. 2k+2 with (.25, .75, .75, .25); at the borders the clamped taps fold
+// into the edge pixel (weight 1) and the out-of-range tap is dropped -- the table bil_bwd_taps builds, in closed form.
+__device__ __forceinline__ void bil_bwd_taps4(int k, int n, int* d, float* wt, bool* on) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dd = 2 * k - 1 + j;
+    on[j] = dd >= 0 && dd < 2 * n;
+    d[j] = dd;
+    wt[j] = (j == 0 || j == 3) ? 0.25f : 0.75f;
+  }
+  if (k == 0) wt[1] = 1.0f;
+  if (k == n - 1) wt[2] = 1.0f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_rows_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int h, int w, int c, int cv_shift,
+                                                                    const void* __restrict__ act, int actC, int act0, void* b2, int b2C, int b20, float slope) {
+  constexpr int N = VecN<T>::N;
+  const int cv = c / N;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (unsigned)(w * cv)) return;
+  const int kx = cv_shift >= 0 ? (int)(i >> cv_shift) : (int)(i / (unsigned)cv), ch = ((int)i - kx * cv) * N;
+  const int ky = blockIdx.y;
+  const size_t img = blockIdx.z;
+  int dys[4], dxs[4]; float wys[4], wxs[4]; bool ony[4], onx[4];
+  bil_bwd_taps4(ky, h, dys, wys, ony);
+  bil_bwd_taps4(kx, w, dxs, wxs, onx);
+  float acc[N], t[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) acc[q] = 0.f;
+#pragma unroll
+  for (int ia = 0; ia < 4; ++ia) {
+    if (!ony[ia]) continue;                                  // wave-uniform
+    const size_t row = (img * 2 * h + dys[ia]) * (size_t)(2 * w);
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      if (onx[ib]) {
+        ldv<T>(a, (row + dxs[ib]) * aC + a0 + ch, t);
+        const float ww = wys[ia] * wxs[ib];
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc[q] += ww * t[q];
+      }
+    }
+  }
+  const size_t op_ = (img * h + ky) * (size_t)w + kx;
+  if (b) stv<T>(b, op_ * (size_t)bC + b0 + ch, acc);
+  if (act) {
+    ldv<T>(act, op_ * (size_t)actC + act0 + ch, t);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] *= t[q] > 0.f ? 1.f : slope;
+    stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void lrelu_bwd_vec_kernel(const void* __restrict__ dy, int dC, int d0, const void* __restrict__ act, int aC, int a0,
                                                             const void* __restrict__ skip, int sC, int s0, void* out, int oC, int o0, size_t npix, int c, float slope) {
@@ -1260,8 +1358,18 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
                    ((uintptr_t)a.ptr & 15) == 0 && ((uintptr_t)b.ptr & 15) == 0;
 #define RSV(OP, TOTAL) DISPATCH_T(dtype, \
     SRGANFD_LAUNCH((resample_vec_kernel<TT, OP>), dim3(grid_for((TOTAL) / vn, 256, 65536)), dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, n, h, w, c))
+  // row-grid forms of the two bilinear ops: grid (column blocks, low-res rows, images)
+  const int cv = c / vn, cv_shift = (cv & (cv - 1)) == 0 ? __builtin_ctz(cv) : -1;
+  const bool rows_ok = h <= 65535 && n <= 65535 && (size_t)w * cv < (1u << 31);
+  const dim3 rows_grid((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)h, (unsigned)n);
   if (vec) {
     if (op == 0) { RSV(0, lo); }
+    else if (rows_ok && op == 1) {
+      DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_block_kernel<TT>, rows_grid, dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, h, w, c, cv_shift));
+    } else if (rows_ok && op == 2) {
+      DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_bwd_rows_kernel<TT>, rows_grid, dim3(256), 0, s, a.ptr, a.cstride, a.c0, b.ptr, b.cstride, b.c0, h, w, c, cv_shift,
+                                       (const void*)nullptr, 0, 0, (void*)nullptr, 0, 0, 0.f));
+    }
     else if (op == 1) { RSV(1, lo * 4); }
     else if (op == 2) { RSV(2, lo); }
     else if (op == 3) { RSV(3, lo / 4); }
@@ -1288,6 +1396,12 @@ int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view a
   auto ok = [&](const srganfd_view& v) { return !v.ptr || (v.c0 % vn == 0 && v.cstride % vn == 0 && ((uintptr_t)v.ptr & 15) == 0 && v.c0 + c <= v.cstride && !v.planar); };
   if (c % vn || !ok(dy) || !ok(dx_raw) || !ok(act) || !ok(dx_masked)) return set_err(SRGANFD_EINVAL, "resample_bwd_lrelu: views must be 16-byte aligned NHWC slices");
   const size_t lo = (size_t)n * h * w * c;
+  const int cv = c / vn, cv_shift = (cv & (cv - 1)) == 0 ? __builtin_ctz(cv) : -1;
+  if (h <= 65535 && n <= 65535 && (size_t)w * cv < (1u << 31)) {
+    DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_bwd_rows_kernel<TT>, dim3((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)h, (unsigned)n), dim3(256), 0, s, dy.ptr,
+                                     dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride, dx_raw.c0, h, w, c, cv_shift, (const void*)act.ptr, act.cstride, act.c0,
+                                     dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
+  } else
   DISPATCH_T(dtype, SRGANFD_LAUNCH((resample_vec_kernel<TT, 2>), dim3(grid_for(lo / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride,
                                    dx_raw.c0, n, h, w, c, (const void*)act.ptr, act.cstride, act.c0, dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
   SRGANFD_HIP_CHECK(hipGetLastError());

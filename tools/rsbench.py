@@ -1,21 +1,54 @@
-"""Time the resampling kernels at the discriminator's shapes.  python tools/rsbench.py"""
-import sys, torch
-sys.path.insert(0, '.')
-from sr_gan_fd_amd import _abi as A
+"""Timing + output digests of the bilinear x2 resampling entry points at the U-Net discriminator's three up-block shapes (B=32, 512x512
+input: 512ch@64^2, 256ch@128^2, 128ch@256^2 low-res).  Run twice (SRGANFD_LIB=<other build>) and compare digests for bit-equality."""
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sr_gan_fd_amd import _abi as A  # noqa: E402
+
 L = A.lib()
-def t(op, n, h, w, c, reps=10):
-    x = torch.randn(n, h, w, c, device='cuda').bfloat16()
-    y = torch.empty(n, 2 * h, 2 * w, c, device='cuda', dtype=torch.bfloat16)
-    a, b = (x, y) if op == 1 else (y, x)
-    for _ in range(2): A.check(L.srganfd_resample(op, A.view(a), A.view(b), A.BF16, n, h, w, c, A.stream_ptr()))
+B = int(os.environ.get("B", "32"))
+dt, dtc = torch.float16, A.F16
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): A.check(L.srganfd_resample(op, A.view(a), A.view(b), A.BF16, n, h, w, c, A.stream_ptr()))
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    gb = (x.numel() + y.numel()) * 2 / 1e9
-    print(f"op {op} n={n} {h}x{w}x{c}: {us:8.1f} us  {gb / us * 1e6:6.0f} GB/s  ptrs {x.data_ptr() % 256} {y.data_ptr() % 256}")
-for op in (1, 2):
-    for (h, c) in ((64, 512), (128, 256), (256, 128)):
-        t(op, 32, h, h, c)
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def digest(t):
+    return hashlib.sha1(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()[:12]
+
+
+torch.manual_seed(0)
+for (c, h) in ((512, 64), (256, 128), (128, 256), (40, 37)):
+    n = B if c != 40 else 3
+    lo = torch.randn(n, h, h, c, device="cuda").to(dt)
+    hi = torch.empty(n, 2 * h, 2 * h, c, device="cuda", dtype=dt)
+    st = A.stream_ptr()
+    f = lambda: A.check(L.srganfd_resample(1, A.view(lo), A.view(hi), dtc, n, h, h, c, st), "fwd")
+    us = timed(f)
+    gb = (lo.numel() + hi.numel()) * 2 / 1e9
+    print(f"fwd  c={c:4d} h={h:4d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  {digest(hi)}")
+    g = torch.randn(n, 2 * h, 2 * h, c, device="cuda").to(dt)
+    act = torch.randn(n, h, h, c, device="cuda").to(dt)
+    raw, msk = torch.empty_like(act), torch.empty_like(act)
+    f = lambda: A.check(L.srganfd_resample_bwd_lrelu(A.view(g), A.view(raw), A.view(act), A.view(msk), dtc, n, h, h, c, 0.2, st), "bwd")
+    us = timed(f)
+    gb = (g.numel() + 3 * act.numel()) * 2 / 1e9
+    print(f"bwd+ c={c:4d} h={h:4d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  {digest(raw)} {digest(msk)}")
+    f = lambda: A.check(L.srganfd_resample(2, A.view(g), A.view(raw), dtc, n, h, h, c, st), "bwd")
+    us = timed(f)
+    gb = (g.numel() + act.numel()) * 2 / 1e9
+    print(f"bwd  c={c:4d} h={h:4d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  {digest(raw)}")
