@@ -140,48 +140,63 @@ __global__ __launch_bounds__(256) void resample_vec_kernel(const void* __restric
   }
 }
 
-// ---- bilinear x2 (align_corners=False, model.py:150-158), row-grid forms: blockIdx.y = low-res row, blockIdx.z = image, one thread per
+// ---- bilinear x2 (align_corners=False, model.py:150-158), row-grid forms: blockIdx.y = group of kBilRows low-res rows, blockIdx.z = image, one thread per
 // (low-res column, 16-byte channel vector).  The generic kernel above spends its time on 64-bit div/mod chains and per-thread tap tables;
 // here the row taps are wave-uniform, the column taps closed-form, and every address is 32-bit arithmetic on top of one 64-bit row base.
 // Same products and the same accumulation order per output as resample_vec_kernel<T, 1 / 2>: results are bit-identical.
-// forward: each thread writes the 2x2 high-res block of its low-res pixel from the 3x3 neighbourhood (9 loads per 4 stores, not 16)
+// Each thread walks kBilRows consecutive low-res rows with a sliding window of source rows in registers: the forward pass reads
+// (R + 2) x 3 vectors for 4R stores (2x2 high-res block per low-res pixel), the adjoint (2R + 2) x 4 for R.
+static constexpr int kBilRows = 4;
+// raw 16-byte vector (8 halves or 4 floats), widened to floats where it is used
+template <typename T> __device__ __forceinline__ u32x4 ldraw(const void* p, size_t i) { return *(const u32x4*)((const T*)p + i); }
+template <typename T> __device__ __forceinline__ void widen(const u32x4 raw, float* o) {
+  if constexpr (sizeof(T) == 2) unpack8<T>(raw, o);
+  else { o[0] = __uint_as_float(raw[0]); o[1] = __uint_as_float(raw[1]); o[2] = __uint_as_float(raw[2]); o[3] = __uint_as_float(raw[3]); }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up2_block_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int h, int w, int c, int cv_shift) {
-  constexpr int N = VecN<T>::N;
+  constexpr int N = VecN<T>::N, R = kBilRows;
   const int cv = c / N;
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (unsigned)(w * cv)) return;
   const int kx = cv_shift >= 0 ? (int)(i >> cv_shift) : (int)(i / (unsigned)cv), ch = ((int)i - kx * cv) * N;
-  const int ky = blockIdx.y;
+  const int ky0 = blockIdx.y * R;
   const size_t img = blockIdx.z;
-  const int ys[3] = {max(ky - 1, 0), ky, min(ky + 1, h - 1)}, xs[3] = {max(kx - 1, 0), kx, min(kx + 1, w - 1)};
-  float t[3][3][N];
+  const int xs[3] = {max(kx - 1, 0), kx, min(kx + 1, w - 1)};
+  float t[3][3][N];                                         // window slot (row - ky0 + 1) % 3
+  auto load_row = [&](float (*dst)[N], int y) {
+    const size_t row = (img * h + y) * (size_t)w;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const size_t row = (img * h + ys[r]) * (size_t)w;
+    for (int q = 0; q < 3; ++q) ldv<T>(a, (row + xs[q]) * aC + a0 + ch, dst[q]);
+  };
+  load_row(t[0], max(ky0 - 1, 0));
+  load_row(t[1], ky0);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) ldv<T>(a, (row + xs[q]) * aC + a0 + ch, t[r][q]);
-  }
+  for (int r = 0; r < R; ++r) {
+    const int ky = ky0 + r;
+    if (ky >= h) break;                                     // wave-uniform
+    load_row(t[(r + 2) % 3], min(ky + 1, h - 1));
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy) {
-    // even output row: taps (k-1: .25, k: .75); odd: (k: .75, k+1: .25)
-    const int ra = dy, rb = dy + 1;
-    const float wya = dy ? 0.75f : 0.25f, wyb = dy ? 0.25f : 0.75f;
-    const size_t orow = (img * 2 * h + 2 * ky + dy) * (size_t)(2 * w) + 2 * kx;
+    for (int dy = 0; dy < 2; ++dy) {
+      // even output row: taps (k-1: .25, k: .75); odd: (k: .75, k+1: .25)
+      const int ra = (r + dy) % 3, rb = (r + dy + 1) % 3;
+      const float wya = dy ? 0.75f : 0.25f, wyb = dy ? 0.25f : 0.75f;
+      const size_t orow = (img * 2 * h + 2 * ky + dy) * (size_t)(2 * w) + 2 * kx;
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int qa = dx, qb = dx + 1;
-      const float wxa = dx ? 0.75f : 0.25f, wxb = dx ? 0.25f : 0.75f;
-      float acc[N];
+      for (int dx = 0; dx < 2; ++dx) {
+        const int qa = dx, qb = dx + 1;
+        const float wxa = dx ? 0.75f : 0.25f, wxb = dx ? 0.25f : 0.75f;
+        float acc[N];
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc[q] = wya * wxa * t[ra][qa][q];
+        for (int q = 0; q < N; ++q) acc[q] = wya * wxa * t[ra][qa][q];
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc[q] += wya * wxb * t[ra][qb][q];
+        for (int q = 0; q < N; ++q) acc[q] += wya * wxb * t[ra][qb][q];
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc[q] += wyb * wxa * t[rb][qa][q];
+        for (int q = 0; q < N; ++q) acc[q] += wyb * wxa * t[rb][qa][q];
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc[q] += wyb * wxb * t[rb][qb][q];
-      stv<T>(b, (orow + dx) * (size_t)bC + b0 + ch, acc);
+        for (int q = 0; q < N; ++q) acc[q] += wyb * wxb * t[rb][qb][q];
+        stv<T>(b, (orow + dx) * (size_t)bC + b0 + ch, acc);
+      }
     }
   }
 }
@@ -201,40 +216,57 @@ __device__ __forceinline__ void bil_bwd_taps4(int k, int n, int* d, float* wt, b
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd_rows_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int h, int w, int c, int cv_shift,
                                                                     const void* __restrict__ act, int actC, int act0, void* b2, int b2C, int b20, float slope) {
-  constexpr int N = VecN<T>::N;
+  constexpr int N = VecN<T>::N, R = kBilRows;
   const int cv = c / N;
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (unsigned)(w * cv)) return;
   const int kx = cv_shift >= 0 ? (int)(i >> cv_shift) : (int)(i / (unsigned)cv), ch = ((int)i - kx * cv) * N;
-  const int ky = blockIdx.y;
+  const int ky0 = blockIdx.y * R;
   const size_t img = blockIdx.z;
-  int dys[4], dxs[4]; float wys[4], wxs[4]; bool ony[4], onx[4];
-  bil_bwd_taps4(ky, h, dys, wys, ony);
+  int dxs[4]; float wxs[4]; bool onx[4];
   bil_bwd_taps4(kx, w, dxs, wxs, onx);
-  float acc[N], t[N];
+  u32x4 win[4][4];                                          // high-res row 2*ky0 - 1 + m lives in slot m % 4, as loaded (16 bytes per tap)
+  auto load_row = [&](u32x4* dst, int d) {
+    if (d < 0 || d >= 2 * h) return;                        // wave-uniform
+    const size_t row = (img * 2 * h + d) * (size_t)(2 * w);
 #pragma unroll
-  for (int q = 0; q < N; ++q) acc[q] = 0.f;
+    for (int ib = 0; ib < 4; ++ib)
+      if (onx[ib]) dst[ib] = ldraw<T>(a, (row + dxs[ib]) * aC + a0 + ch);
+  };
+  load_row(win[0], 2 * ky0 - 1);
+  load_row(win[1], 2 * ky0);
 #pragma unroll
-  for (int ia = 0; ia < 4; ++ia) {
-    if (!ony[ia]) continue;                                  // wave-uniform
-    const size_t row = (img * 2 * h + dys[ia]) * (size_t)(2 * w);
+  for (int r = 0; r < R; ++r) {
+    const int ky = ky0 + r;
+    if (ky >= h) break;                                     // wave-uniform
+    load_row(win[(2 * r + 2) % 4], 2 * ky + 1);
+    load_row(win[(2 * r + 3) % 4], 2 * ky + 2);
+    int dys[4]; float wys[4]; bool ony[4];
+    bil_bwd_taps4(ky, h, dys, wys, ony);
+    float acc[N], t[N];
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-      if (onx[ib]) {
-        ldv<T>(a, (row + dxs[ib]) * aC + a0 + ch, t);
-        const float ww = wys[ia] * wxs[ib];
+    for (int q = 0; q < N; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int q = 0; q < N; ++q) acc[q] += ww * t[q];
+    for (int ia = 0; ia < 4; ++ia) {
+      if (!ony[ia]) continue;                               // wave-uniform
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        if (onx[ib]) {
+          widen<T>(win[(2 * r + ia) % 4][ib], t);
+          const float ww = wys[ia] * wxs[ib];
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc[q] += ww * t[q];
+        }
       }
     }
-  }
-  const size_t op_ = (img * h + ky) * (size_t)w + kx;
-  if (b) stv<T>(b, op_ * (size_t)bC + b0 + ch, acc);
-  if (act) {
-    ldv<T>(act, op_ * (size_t)actC + act0 + ch, t);
+    const size_t op_ = (img * h + ky) * (size_t)w + kx;
+    if (b) stv<T>(b, op_ * (size_t)bC + b0 + ch, acc);
+    if (act) {
+      ldv<T>(act, op_ * (size_t)actC + act0 + ch, t);
 #pragma unroll
-    for (int q = 0; q < N; ++q) acc[q] *= t[q] > 0.f ? 1.f : slope;
-    stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
+      for (int q = 0; q < N; ++q) acc[q] *= t[q] > 0.f ? 1.f : slope;
+      stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
+    }
   }
 }
 
@@ -1361,7 +1393,7 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
   // row-grid forms of the two bilinear ops: grid (column blocks, low-res rows, images)
   const int cv = c / vn, cv_shift = (cv & (cv - 1)) == 0 ? __builtin_ctz(cv) : -1;
   const bool rows_ok = h <= 65535 && n <= 65535 && (size_t)w * cv < (1u << 31);
-  const dim3 rows_grid((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)h, (unsigned)n);
+  const dim3 rows_grid((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)((h + kBilRows - 1) / kBilRows), (unsigned)n);
   if (vec) {
     if (op == 0) { RSV(0, lo); }
     else if (rows_ok && op == 1) {
@@ -1398,7 +1430,7 @@ int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view a
   const size_t lo = (size_t)n * h * w * c;
   const int cv = c / vn, cv_shift = (cv & (cv - 1)) == 0 ? __builtin_ctz(cv) : -1;
   if (h <= 65535 && n <= 65535 && (size_t)w * cv < (1u << 31)) {
-    DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_bwd_rows_kernel<TT>, dim3((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)h, (unsigned)n), dim3(256), 0, s, dy.ptr,
+    DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_bwd_rows_kernel<TT>, dim3((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)((h + kBilRows - 1) / kBilRows), (unsigned)n), dim3(256), 0, s, dy.ptr,
                                      dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride, dx_raw.c0, h, w, c, cv_shift, (const void*)act.ptr, act.cstride, act.c0,
                                      dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
   } else
