@@ -52,3 +52,15 @@ for (c, h) in ((512, 64), (256, 128), (128, 256), (40, 37)):
     us = timed(f)
     gb = (g.numel() + act.numel()) * 2 / 1e9
     print(f"bwd  c={c:4d} h={h:4d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  {digest(raw)}")
+
+# 2x2 reductions: op 0 nearest-x2 adjoint (generator tail), op 3 max pool (VGG-19), op 4 relu copy; (h, w) = the ABI's h, w arguments
+for (op, c, h, n) in ((0, 64, 128, B), (0, 64, 256, B), (3, 64, 512, B), (3, 128, 256, B), (3, 256, 128, B), (3, 512, 64, B), (4, 64, 512, B), (0, 24, 9, 3), (3, 24, 18, 3)):
+    st = A.stream_ptr()
+    ih = 2 * h if op == 0 else h
+    oh = h // 2 if op == 3 else h
+    src = torch.randn(n, ih, ih, c, device="cuda").to(dt)
+    dst = torch.empty(n, oh, oh, c, device="cuda", dtype=dt)
+    f = lambda: A.check(L.srganfd_resample(op, A.view(src), A.view(dst), dtc, n, h, h, c, st), "resample")
+    us = timed(f)
+    gb = (src.numel() + dst.numel()) * 2 / 1e9
+    print(f"op{op}  c={c:4d} h={h:4d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  {digest(dst)}")
