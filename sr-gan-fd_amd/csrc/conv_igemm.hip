@@ -167,6 +167,10 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   // columns) + wave-uniform row offset + immediate, instead of one precomputed VGPR per (row, column, pixel half) -- those 24
   // registers pushed the 64-channel kernel over its 128 and spilled a prefetch pointer (scratch reload + vmcnt(0) inside the loop).
   constexpr bool kColSwz = M16 && STRIDE == 1;
+  constexpr bool kDeint = M16 && STRIDE == 2;
+  constexpr int kHalf = (C::PC + 1) / 2;                  // even columns of a patch row
+  // storage pixel (within a patch row) of column 2*l + kx + 32*ph, before the lane term l: the A-fragment reads of the stride-2 forms
+  auto deint_col = [](int kx, int ph) { return (kx & 1) * kHalf + (kx >> 1) + 16 * ph; };
   constexpr int kM16Pipe = WN == 2 ? SRGANFD_M16_PIPE : SRGANFD_M16_PIPE - 1;     // fragment read-ahead (what fits 128 VGPRs) of the 3x3 stride-1 16x16x32 loop (0 = the compiler's own schedule)
   int ldsxo[kColSwz ? C::XI : 1];
   // per-thread source offsets (elements) of the X staging items; -1 = zero padding
@@ -175,7 +179,11 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   for (int i = 0; i < C::XI; ++i) {
     const int item = tid + i * NTHR;
     const int pix = item / C::CPP, c16 = item % C::CPP;
-    const int py = pix / C::PC, px = pix % C::PC;
+    const int py = pix / C::PC, pq = pix % C::PC;
+    // stride 2 (16x16x32 form): a patch row is stored even columns first, then the odd ones -- the 16 lanes of a fragment read want
+    // columns 2*l + kx, which interleaved sit 128 bytes apart (four 16-byte slots of the 256-byte bank row for 16 lanes: 4-way
+    // conflicts on every A read); de-interleaved they are 16 consecutive storage pixels, the stride-1 pattern the slot swizzle spreads
+    const int px = kDeint ? (pq < kHalf ? 2 * pq : 2 * (pq - kHalf) + 1) : pq;
     if constexpr (kColSwz) ldsxo[i] = pix * 64 + ((c16 ^ (((px >> 2) & 1) << 1)) << 4);
     const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
     const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
@@ -341,7 +349,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
           for (int rr = 0; rr < NR_; ++rr)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
-              av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + (th * KYS + rr) * C::PC + kx + 16 * ph * STRIDE, sl));
+              if constexpr (kDeint) av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off((wr * MR * STRIDE + th * KYS + rr) * C::PC + l15 + deint_col(kx, ph), sl));
+              else av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + (th * KYS + rr) * C::PC + kx + 16 * ph * STRIDE, sl));
 #pragma unroll
           for (int kyl = 0; kyl < KYS; ++kyl) {
 #pragma unroll
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
 #pragma unroll
           for (int ph = 0; ph < 2; ++ph) {
             if constexpr (kColSwz) av[rr][ph] = *(const Frag*)(ldsXw + colterm + (rr * C::PC + 16 * ph) * 64);
+            else if constexpr (kDeint) av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off((wr * MR * STRIDE + rr) * C::PC + l15 + deint_col(kx, ph), sl));
             else av[rr][ph] = *(const Frag*)(ldsX + lds_x16_m16_off(pixb + rr * C::PC + kx + 16 * ph * STRIDE, sl));
           }
 #pragma unroll
