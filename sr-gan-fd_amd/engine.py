@@ -455,7 +455,7 @@ class TrunkEngine:
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         # four more workspaces of the dense-block plan's size for the batched slab reduction (34 MB each at B=32, 128x128)
         dense_ws = max((p_.workspace_bytes for p_ in plans.values()), default=0)
-        sp.wg_ws4 = [torch.empty(dense_ws, dtype=torch.uint8, device=device) for _ in range(4)] if (dense_ws and _BATCH_REDUCE) else None
+        sp.wg_ws4 = [torch.empty(dense_ws, dtype=torch.uint8, device=device) for _ in range(_BATCH_REDUCE)] if (dense_ws and _BATCH_REDUCE > 1) else None
 
     # -- execution ----------------------------------------------------------------------------
     def forward(self, x: Tensor, train: bool) -> Tensor:
@@ -571,7 +571,8 @@ class TrunkEngine:
         return flat_grad, dx
 
 
-_BATCH_REDUCE = os.environ.get("SRGANFD_BATCH_REDUCE", "1") != "0"
+# dense blocks whose weight-gradient slabs one srganfd_wgrad_reduce_batch launch reduces (<= 8 = SRGANFD's kRedBatch; 0 / 1: every block's own)
+_BATCH_REDUCE = max(0, min(8, int(os.environ.get("SRGANFD_BATCH_REDUCE", "4"))))
 
 
 class _TrunkFn(torch.autograd.Function):
