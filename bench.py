@@ -54,7 +54,7 @@ def csrc_sha() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "sr-gan-fd_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "srganfd.h")]:
+    for f in sorted(glob.glob(os.path.join(ROOT, "sr_gan_fd_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", "srganfd.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -1,7 +1,7 @@
 """CPU oracle for the on-device degradation stages.  TEST INFRASTRUCTURE ONLY.
 
 A torch-CPU restatement of ``Real_ESRGAN/imgproc.py``'s filter2d_torch / USMSharp / DiffJPEG and the closing
-quantisation of degradation_process.  Only ``tests/`` may import it; the product (``sr-gan-fd_amd``) never does.
+quantisation of degradation_process.  Only ``tests/`` may import it; the product (``sr_gan_fd_amd``) never does.
 
 Pinned by ``tests/golden/degradation.npz`` -- outputs of the reference's own functions, captured by importing
 ``Real_ESRGAN/imgproc.py`` in the build container (``tests/golden/make_golden.py``; cv2 / torchvision / scipy.stats stubs:

@@ -3,7 +3,7 @@
 This file is a CPU restatement (torch-CPU tensor ops, fp32 or fp64) of the reference's
 generator / discriminator / loss / optimizer arithmetic.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the product
-path (``sr-gan-fd_amd``) never does and fails loudly when its HIP library is missing.
+path (``sr_gan_fd_amd``) never does and fails loudly when its HIP library is missing.
 
 Pinned by: ``tests/golden/*.npz`` -- vectors captured by importing the reference's own
 ``BSRGAN/model.py`` / ``ESRGAN/model.py`` in the build container (``tests/golden/make_golden.py``,

@@ -1,8 +1,7 @@
-"""Import shim: the package directory is ``sr-gan-fd_amd/`` (hyphenated, as the project layout
-names it); Python imports it as ``sr_gan_fd_amd``."""
-import os as _os
+"""sr-gan-fd_amd -- MI355X-native (gfx950) hot path of MiNeves00/SR-GAN-FD.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "sr-gan-fd_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+Drop-in for the reference's ``model.py`` surface (``sr_gan_fd_amd.model``): same class/factory
+names, constructor kwargs and ``state_dict`` keys, with every convolution, resampling, loss and
+optimizer step running as hand-written HIP kernels behind the C ABI in ``include/srganfd.h``.
+"""
+__version__ = "0.1.0"

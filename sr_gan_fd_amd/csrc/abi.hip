@@ -6,8 +6,10 @@
 namespace srganfd {
 thread_local char g_err[512] = {0};
 int g_dry_run = 0;
+#ifdef SRGANFD_EXPERIMENT
 int g_debug = 0;
 unsigned long long* g_stamp_buf = nullptr;
+#endif
 thread_local char* g_describe = nullptr;
 thread_local size_t g_describe_len = 0;
 int set_err(int code, const char* fmt, ...) {

@@ -1,5 +1,5 @@
 // conv_common.hpp -- launch arguments and MFMA helpers shared by the fused-convolution kernels
-// (conv_igemm.hip: every kernel shape, f32 parity mode; conv3x3_ring.hip: the 3x3 stride-1 16-bit hot path).
+// (conv_igemm.hip: every kernel shape; tools/experiments/conv3x3_ring.hip: the LDS-DMA ring experiment).
 #pragma once
 #include "common.hpp"
 
@@ -29,10 +29,14 @@ struct ConvK {
   unsigned m_nNb, m_tx, m_ty;   // ceil(2^32 / d) for the block-index decode (0: divide), see fast_div
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
   int act, y_f32, fast_epi;
-  int dbg;            // SRGANFD_EXPERIMENT builds only: 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
-  unsigned long long* stamps;   // SRGANFD_EXPERIMENT builds only: s_memtime stamps of the first workgroups (tools/stamps.py), else NULL
+#ifdef SRGANFD_EXPERIMENT
+  int dbg;            // 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
+  unsigned long long* stamps;   // s_memtime stamps of the first workgroups (tools/stamps.py), else NULL
+#endif
 };
+#ifdef SRGANFD_EXPERIMENT
 extern unsigned long long* g_stamp_buf;
+#endif
 
 template <typename T> struct FragAB;
 template <> struct FragAB<bf16_t> { typedef bf16x8 type; };
@@ -78,6 +82,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
-int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);
+#ifdef SRGANFD_EXPERIMENT
+int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);   // tools/experiments/conv3x3_ring.hip
+#endif
 
 }  // namespace srganfd

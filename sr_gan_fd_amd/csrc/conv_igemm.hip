@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     constexpr int EI = (ITEMS + NTHR - 1) / NTHR;
     const int cbase = nb * C::NB;
     const size_t img = (size_t)n * a.HoutF * a.WoutF;   // pixels before this image (block-uniform)
-#pragma unroll (kEpiPre ? 4 : 2)
+#pragma unroll kEpiPre ? 4 : 2
     for (int e = 0; e < EI; ++e) {
       const int item = tid + e * NTHR;
       const int pix = item / CP, ck = item % CP;
@@ -791,8 +791,6 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
 #ifdef SRGANFD_EXPERIMENT
   k.dbg = g_debug; k.stamps = g_stamp_buf;
-#else
-  k.dbg = 0; k.stamps = nullptr;
 #endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
 #ifdef SRGANFD_EXPERIMENT

@@ -45,7 +45,9 @@ struct WgK {
   int xC, x_c0v, dyC, dy_c0v;
   int x_ps, x_gs, dy_ps, dy_gs;   // pixel / 32-channel-group strides in elements: NHWC (C, 32) or planar groups (32, H*W*32), see srganfd_view
   int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y, ngroups;
-  int dbg;   // timing experiments only (srganfd_set_debug): 1 no global loads, 4 no slab store, 8 no LDS commit, 16 no LDS reads, 32 no barriers
+#ifdef SRGANFD_EXPERIMENT
+  int dbg;   // timing experiments (srganfd_set_debug): 1 no global loads, 4 no slab store, 8 no LDS commit, 16 no LDS reads, 32 no barriers
+#endif
 };
 
 
@@ -70,10 +72,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
   // m0 is declared clobbered instead of saved and restored around every piece (nothing else in these kernels lives in m0: LDS
   // instructions do not need it on gfx9+)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                : : "v"(gsrc), "s"(dst) : "m0");   // no "memory" clobber: it pins every by-reference lambda capture to scratch,
                                                    // and scratch loads share vmcnt with the copies; ordering comes from the
                                                    // explicit vmcnt(0) + barrier that publish a buffer
+#pragma clang diagnostic pop
 }
 
 template <int KS, int STRIDE> struct WgTile { static constexpr int TH = (STRIDE == 1) ? 8 : 4; };
@@ -814,7 +819,10 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.x_ps = x.planar ? 32 : x.cstride; k.x_gs = x.planar ? H.Hin * H.Win * 32 : 32;
   k.dy_ps = dy.planar ? 32 : dy.cstride; k.dy_gs = dy.planar ? H.Hout * H.Wout * 32 : 32;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
-  k.dbg = SRGANFD_DBG(g_debug, ~0); k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
+#ifdef SRGANFD_EXPERIMENT
+  k.dbg = g_debug;
+#endif
+  k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
 #define WG_BY_TYPE(KS_, S_) (H.dtype == SRGANFD_BF16 ? launch_wgrad<bf16_t, KS_, S_>(H, k, stream) : H.dtype == SRGANFD_F16 ? launch_wgrad<f16_t, KS_, S_>(H, k, stream) : launch_wgrad<float, KS_, S_>(H, k, stream))
   if (H.ks == 3 && H.stride == 1) rc = WG_BY_TYPE(3, 1);
