@@ -26,6 +26,7 @@ struct ConvK {
   int nNb;            // cout / (output channels per workgroup)
   int cout_store;
   int tiles_x, tiles_y;
+  int nblocks;        // N * tiles_y * tiles_x * nNb virtual blocks; the grid may be smaller (persistent workgroups, see the kernel)
   unsigned m_nNb, m_tx, m_ty;   // ceil(2^32 / d) for the block-index decode (0: divide), see fast_div
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
   int act, y_f32, fast_epi;

@@ -49,11 +49,16 @@ __host__ __device__ constexpr int m16_pipe_hi(int i, int d, int nl) { const int 
 __host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need = 7 * (i / 6) + (i % 6) + 1; return need + d < nl - 1 ? need + d : nl - 1; }
 }
 
+// epilogue kinds with any of these operand bits keep one tile per workgroup (0: every fixed kind runs persistent, 7: only kind 0)
+#ifndef SRGANFD_CROSS_MASK
+#define SRGANFD_CROSS_MASK 7
+#endif
 #ifndef SRGANFD_M16_PIPE
 #define SRGANFD_M16_PIPE 3
 #endif
 
 namespace srganfd {
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 // TS = tap split: the weight slab of a 32-channel chunk is staged in TS pieces of KS/TS kernel rows (the 4x4 stride-2 kernel: 64 KiB of
 // weights per chunk next to a 42 KiB patch would leave room for ONE workgroup per CU; in halves two fit)
@@ -86,8 +91,10 @@ struct ConvCfg {
   static constexpr int PIX_PER_I = NTHR / CPP;                 // pixels advanced per staging item index
   static_assert(PIX_PER_I % 32 == 0, "swizzle term must not depend on the staging item index");
   // workgroups per CU allowed by LDS (160 KiB) -> minimum waves per SIMD to ask the register allocator for
-  static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
-  static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NTHR / 256;
+  // (at most 16 waves per CU: the kernels are written for 128 registers per lane or more)
+  static constexpr int WG_BY_LDS = 160 * 1024 / LDS_BYTES, WG_BY_WAVES = 16 / NWAVES;
+  static constexpr int WG_PER_CU = WG_BY_LDS < 1 ? 1 : (WG_BY_LDS < WG_BY_WAVES ? WG_BY_LDS : WG_BY_WAVES);
+  static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU * NTHR / 256 < 1 ? 1 : WG_PER_CU * NTHR / 256;
 };
 
 // LDS patch layout.  bf16: 4 chunks of 16 B per pixel, chunk index XOR (pix>>2)&3.  f32: 32 dwords per
@@ -127,7 +134,12 @@ template <int MR> struct AccSet<true, MR> {
   static __device__ __forceinline__ int chan(int e, int lane) { return 16 * ((e >> 2) & 1) + (lane & 15); }
 };
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1>
+// EK = epilogue kind, fixed at compile time for the hot 3x3 stride-1 16-bit launches: -1 = every operand decided at run time (any
+// launch); >= 0 = vectorised epilogue with exactly the operands of the bit set (1: residual r1, 2: residual r2, 4: LeakyReLU' mask), no
+// y2, no fp32 / partial-channel output.  A fixed kind carries no loads, address arithmetic, prefetch registers or branches for tensors
+// the launch does not have: the four growth convs of a dense block (kind 0) and their data-gradient twins (kind 4) are 80 % of a
+// generator step's launches.
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
 __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
@@ -143,23 +155,50 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
+#ifdef SRGANFD_EXPERIMENT
+  // stagger experiment (dbg bit 128, delay = dbg >> 8 units of s_sleep 127): the workgroup whose wave 0 sits in wave slot >= 2 of its SIMD
+  // (the second resident workgroup of the CU at 4 waves per SIMD) starts late, so that the two workgroups' MFMA phases interleave
+  if ((a.dbg & 128) && wave == 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID: wave slot in bits 3:0
+    if ((hwid & 0xf) >= 2)
+      for (int i = 0; i < (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
-  // XCD-aware bijective remap: blocks b and b+8 share an XCD (L2), give each XCD a contiguous range
-  // (block-uniform by construction; the readfirstlane tells the compiler so: the divisions go through v_rcp, and without it every
-  // address product downstream -- image bases of five tensors, tile origins -- stays in quarter-rate vector multiplies)
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
-  const int nb = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
-  const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
-  const int tx = __builtin_amdgcn_readfirstlane(t0 - t1 * a.tiles_x);
-  const int t2 = (int)fast_div((unsigned)t1, (unsigned)a.tiles_y, a.m_ty);
-  const int ty = __builtin_amdgcn_readfirstlane(t1 - t2 * a.tiles_y);
-  const int n = __builtin_amdgcn_readfirstlane(t2);
-  const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+#ifdef SRGANFD_EXPERIMENT
+  // timeline stamps (tools/r3/conv_stamps.py): s_memtime of wave 0 and wave NWAVES-1 of 256 sampled workgroups at fixed points of the tile
+  unsigned long long* stamp_p = (a.stamps && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 256 && (wave == 0 || wave == WR * WN - 1) && lane == 0)
+                                    ? a.stamps + (((size_t)(blockIdx.x >> 2) * 2 + (wave ? 1 : 0)) * 32) : nullptr;
+  int stamp_i = 0;
+#define CONV_STAMP() do { if (stamp_p && stamp_i < 32) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_p[stamp_i++] = t_; } } while (0)
+#else
+#define CONV_STAMP() do { } while (0)
+#endif
+  CONV_STAMP();   // 0: kernel entry
+  // Persistent tiles: workgroup b runs the virtual blocks b, b + gridDim.x, ... (the host sizes the grid to the workgroups the chip
+  // holds at once for the kernels that prefetch across tiles, and to one block per workgroup otherwise).  A tile's first chunk is
+  // requested while the previous tile of the workgroup is still in its last MFMA phase and epilogue: measured per tile (s_memrealtime
+  // stamps, profiles/r03_conv_timeline.txt) the head of a tile -- address set-up, the first loads' round trip, the first commit -- was
+  // 4-6 us of 14 (64 -> 32 channels) to 27 us (192 -> 64), none of it overlapped with anything of the same workgroup.
+  // Virtual block -> tile: XCD-aware bijective remap (blocks v and v+8 share an XCD and its L2; each XCD gets a contiguous range of
+  // tiles), block-uniform by construction; the readfirstlane tells the compiler so (otherwise every address product downstream
+  // stays in quarter-rate vector multiplies).
+  auto decode = [&](int vb, int& n_, int& oy_, int& ox_, int& nb_) {
+    const int bid = xcd_remap(vb, a.nblocks);
+    const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
+    nb_ = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
+    const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
+    const int tx = __builtin_amdgcn_readfirstlane(t0 - t1 * a.tiles_x);
+    const int t2 = (int)fast_div((unsigned)t1, (unsigned)a.tiles_y, a.m_ty);
+    const int ty = __builtin_amdgcn_readfirstlane(t1 - t2 * a.tiles_y);
+    n_ = __builtin_amdgcn_readfirstlane(t2);
+    oy_ = ty * C::TH; ox_ = tx * C::TW;
+  };
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
-  // 64-bit per-image base (block-uniform, scalar registers) + 32-bit offsets inside the image (host-checked)
-  const T* __restrict__ xg = (const T*)a.x + (size_t)n * a.Hin * a.Win * a.xC;
+  // load side of the tile being staged (may run one tile ahead of the tile being computed): 64-bit per-image base (block-uniform,
+  // scalar registers) + 32-bit offsets inside the image (host-checked)
+  const T* __restrict__ xg = nullptr;
 
   // 16x16x32 form, stride 1: the slot swizzle is keyed on the patch COLUMN, 2*((px>>2)&1).  What keeps a 16-lane read group
   // conflict free is that the four lanes whose pixels are 4 apart (same 64-byte position of the 256-byte bank row) alternate
@@ -175,20 +214,40 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   int ldsxo[kColSwz ? C::XI : 1];
   // per-thread source offsets (elements) of the X staging items; -1 = zero padding
   int xoff[C::XI];
+  // patch position of staging item i (tile-independent).  stride 2 (16x16x32 form): a patch row is stored even columns first, then
+  // the odd ones -- the 16 lanes of a fragment read want columns 2*l + kx, which interleaved sit 128 bytes apart (four 16-byte slots
+  // of the 256-byte bank row for 16 lanes: 4-way conflicts on every A read); de-interleaved they are 16 consecutive storage pixels,
+  // the stride-1 pattern the slot swizzle spreads
+  auto item_pos = [&](int tid_, int i, int& py, int& px, int& c16) {
+    const int item = tid_ + i * NTHR;
+    const int pix = item / C::CPP;
+    c16 = item % C::CPP;
+    py = pix / C::PC;
+    const int pq = pix % C::PC;
+    px = kDeint ? (pq < kHalf ? 2 * pq : 2 * (pq - kHalf) + 1) : pq;
+  };
+  if constexpr (kColSwz) {
 #pragma unroll
-  for (int i = 0; i < C::XI; ++i) {
-    const int item = tid + i * NTHR;
-    const int pix = item / C::CPP, c16 = item % C::CPP;
-    const int py = pix / C::PC, pq = pix % C::PC;
-    // stride 2 (16x16x32 form): a patch row is stored even columns first, then the odd ones -- the 16 lanes of a fragment read want
-    // columns 2*l + kx, which interleaved sit 128 bytes apart (four 16-byte slots of the 256-byte bank row for 16 lanes: 4-way
-    // conflicts on every A read); de-interleaved they are 16 consecutive storage pixels, the stride-1 pattern the slot swizzle spreads
-    const int px = kDeint ? (pq < kHalf ? 2 * pq : 2 * (pq - kHalf) + 1) : pq;
-    if constexpr (kColSwz) ldsxo[i] = pix * 64 + ((c16 ^ (((px >> 2) & 1) << 1)) << 4);
-    const int gy = oy0 * STRIDE - a.pad_y + py, gx = ox0 * STRIDE - a.pad_x + px;
-    const bool ok = item < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
-    xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
+    for (int i = 0; i < C::XI; ++i) {
+      int py, px, c16;
+      item_pos(tid, i, py, px, c16);
+      ldsxo[i] = ((tid + i * NTHR) / C::CPP) * 64 + ((c16 ^ (((px >> 2) & 1) << 1)) << 4);
+    }
   }
+  auto tile_offsets = [&](int oy_, int ox_) {
+    // (the thread id goes through an opaque copy: otherwise the patch positions of all staging items -- tile-independent -- are hoisted
+    // out of the tile loop and held in ~15 registers across it, which this kernel does not have)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+#pragma unroll
+    for (int i = 0; i < C::XI; ++i) {
+      int py, px, c16;
+      item_pos(tid_o, i, py, px, c16);
+      const int gy = oy_ * STRIDE - a.pad_y + py, gx = ox_ * STRIDE - a.pad_x + px;
+      const bool ok = tid_o + i * NTHR < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
+      xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
+    }
+  };
   // LDS destination of staging item i = ldsx0 + i * (PIX_PER_I * PIXB): the swizzle term is i-invariant
   int ldsx0;
   {
@@ -197,7 +256,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     else if constexpr (sizeof(T) == 2) ldsx0 = lds_x_bf16_off(pix, c16);
     else ldsx0 = pix * 128;   // f32: per-dword XOR below
   }
-  const u32x4* __restrict__ wgp = (const u32x4*)a.w + (size_t)nb * WN * a.nChunks * (C::WN_BYTES / 16);
+  const u32x4* __restrict__ wgp = nullptr;
 
   // bf16: register prefetch of the next chunk (issue-early / write-late).  f32 (parity mode) stages
   // synchronously: its 2x larger tiles would not fit the register budget next to the accumulators.
@@ -217,7 +276,8 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return (void*)(((unsigned long long)hi << 32) | lo);
   };
-  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(xg), (short)0, kBuf ? (int)((unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.xC * (unsigned)sizeof(T)) : 0, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x), (short)0, 0, 0x00020000);      // re-pointed per tile by setup_loads
+  auto wrsrc = xrsrc;
   auto load_x = [&](int i, int chunk) -> u32x4 {
     if constexpr (kBuf) {
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned v4u;
@@ -229,7 +289,6 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       return v;
     }
   };
-  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wgp), (short)0, kBuf ? (int)((unsigned)WN * (unsigned)a.nChunks * (unsigned)C::WN_BYTES) : 0, 0x00020000);
   auto load_w = [&](int i, int chunk, int th = 0) -> u32x4 {
     const int item = tid + i * NTHR;
     // LDS slab order [n-tile][tap][kstep][lane]; global order [n-tile][chunk][tap][kstep][lane]; piece th = taps [th, th+1) * KT/TS
@@ -288,8 +347,41 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     }
   };
 
+  float bvn0 = 0.f, bvn1 = 0.f;
+  // point the load side at virtual block vb: image / weight-block descriptors and the staging offsets of its tile
+  auto setup_loads = [&](int vb) {
+    int n_, oy_, ox_, nb_;
+    decode(vb, n_, oy_, ox_, nb_);
+    xg = (const T*)a.x + (size_t)n_ * a.Hin * a.Win * a.xC;
+    wgp = (const u32x4*)a.w + (size_t)nb_ * WN * a.nChunks * (C::WN_BYTES / 16);
+    if constexpr (kBuf) {
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(xg), (short)0, (int)((unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.xC * (unsigned)sizeof(T)), 0x00020000);
+      wrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wgp), (short)0, (int)((unsigned)WN * (unsigned)a.nChunks * (unsigned)C::WN_BYTES), 0x00020000);
+    }
+    // the two bias values this lane's epilogue adds, requested here so that they are OLDER than the tile's staging loads: the copy at
+    // the top of the tile then waits for them alone.  (Loaded at the top of the tile they were younger than the next tile's first
+    // loads, and the epilogue's use of them drained those loads -- s_waitcnt vmcnt(0) -- before the tile could finish.)
+    if constexpr (sizeof(T) == 2) {
+      const int cow_ = (nb_ * WN + wn) * 32;
+      bvn0 = bvn1 = 0.f;
+      if (a.bias && (EK >= 0 || a.fast_epi)) { bvn0 = a.bias[cow_ + AccSet<M16, MR>::chan(0, lane)]; bvn1 = a.bias[cow_ + AccSet<M16, MR>::chan(4, lane)]; }
+    }
+    tile_offsets(oy_, ox_);
+  };
+  // the first stage's loads of the tile the load side points at
+  auto first_loads = [&]() {
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, 0);
+#pragma unroll
+      for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, 0, 0);
+    }
+  };
+  // tiles after the first: requested during the previous tile's last MFMA phase (the kinds whose epilogue leaves room for the 32
+  // staging registers), else after its epilogue
+  constexpr bool kCross = kPrefetch && EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0;
+
   AccSet<M16, MR> A_;
-  A_.zero();
   auto& acc = A_.a;
 
   // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
@@ -305,11 +397,21 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   // device-side scale is a scalar load, the two bias values of this lane's channels cost two registers through the loop
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
+  if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(2);
+  setup_loads(blockIdx.x);
+  if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(0);
+  CONV_STAMP();   // 1: prologue done
+  first_loads();
+  for (int vt = blockIdx.x;; vt += gridDim.x) {
+  // (cin >= 32 is host-checked; without the hint the compiler sees a path from the bias loads below to the epilogue that skips the
+  // chunk loop's waits, and guards the epilogue with s_waitcnt vmcnt(0) -- which would also wait for the next tile's staging loads)
+  __builtin_assume(a.nChunks >= 1);
+  const bool more = kCross && vt + (int)gridDim.x < a.nblocks;      // this workgroup has another tile after this one (the host gives the other kinds one block per workgroup)
+  int n, oy0, ox0, nb;
+  decode(vt, n, oy0, ox0, nb);
+  A_.zero();
   const int cow = (nb * WN + wn) * 32;      // first output channel of this wave; element e of a lane sits at channel cow + chan(e, lane)
-  float bvh0 = 0.f, bvh1 = 0.f;
-  if constexpr (sizeof(T) == 2) {
-    if (a.bias && a.fast_epi) { bvh0 = a.bias[cow + AccSet<M16, MR>::chan(0, lane)]; bvh1 = a.bias[cow + AccSet<M16, MR>::chan(4, lane)]; }
-  }
+  const float bvh0 = bvn0, bvh1 = bvn1;     // this tile's bias values (requested with its first loads)
   if constexpr (TS > 1) {
     // Tap-split main loop (16x16x32 form): stage (chunk, th) holds the chunk's patch and kernel rows [th*KYS, (th+1)*KYS) of its
     // weights; the patch is committed with th == 0 and stays for the chunk's TS weight pieces.  Same issue-early / write-late
@@ -317,10 +419,6 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     constexpr int KYS = KS / TS, NR_ = (MR - 1) * STRIDE + KYS;
     const int l15 = lane & 15, sl = lane >> 4;
     const int pixb = (wr * MR * STRIDE) * C::PC + l15 * STRIDE;
-#pragma unroll
-    for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, 0);
-#pragma unroll
-    for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, 0, 0);
     for (int chunk = 0; chunk < a.nChunks; ++chunk) {
       static_for<TS>([&](auto thc) {
         constexpr int th = decltype(thc)::v;
@@ -340,6 +438,9 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
           for (int i = 0; i < C::XI; ++i) xr[i] = load_x(i, chunk + 1);
 #pragma unroll
           for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, chunk + 1, 0);
+        } else if (kCross && more) {
+          setup_loads(vt + gridDim.x);
+          first_loads();
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -367,12 +468,20 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       });
     }
   } else {
-  prefetch(0);
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
+    CONV_STAMP();   // 2 + 4c: previous MFMA phase of every wave done
     if (!SRGANFD_DBG(a.dbg, 8)) commit(chunk);
+    CONV_STAMP();   // 3 + 4c: this wave's loads arrived and are written to LDS
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
+    CONV_STAMP();   // 4 + 4c: stage published
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
+    else if (kCross && more) {
+      if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(2);
+      setup_loads(vt + gridDim.x);
+      first_loads();
+      if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(0);
+    }
 
     auto col_body = [&](int kx, int s) {
       if constexpr (!M16) {
@@ -448,6 +557,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      CONV_STAMP();   // 5 + 4c: MFMA phase done
     } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MR == 2) {
       // Software-pipelined fragment reads: the chunk's 42 ds_read_b128 and 36 MFMAs in one fixed issue order, every read kD
       // fragments ahead of the MFMA that consumes it (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> MFMA on two
@@ -493,26 +603,103 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   }
 
   // ---- epilogue (see srganfd.h for the formula) ----
+  if (SRGANFD_DBG(a.dbg, 512)) __builtin_amdgcn_s_setprio(2);
+  [&]() __attribute__((always_inline)) {
   if (SRGANFD_DBG(a.dbg, 4)) { if (A_.get(0, 0) == 123.456f) ((float*)a.y)[0] = 1.f; return; }
-  if (a.fast_epi) {
+  if constexpr (EK == 0 && M16 && WN == 1 && sizeof(T) == 2) {
+    // Kind 0, 32-channel tiles (the growth convs of a dense block): bias + activation in registers, rounded to T there (the value
+    // the fp32 tile path would round after its LDS round trip: same bits), and a 16-bit CHANNEL-major LDS tile per image row --
+    // a lane's four accumulator registers of one (row, pixel half, channel half) are four consecutive pixels of one channel, so
+    // they go out as one ds_write_b64; ds_read_b64_tr_b16 hands them back pixel-major (lane i of a 16-lane group: pixel i, four
+    // channels), two reads = the 16 bytes of (pixel, 8 channels) one lane stores.  Every wave reads only the rows it wrote: one
+    // barrier (staging buffers free) instead of two, 8 LDS writes + 8 reads per lane instead of 16 + 8 wider ones, no fp32 tile
+    // unpacking / conversion after the reads.  Row tile = 32 channels x 64 bytes, dword index XOR (channel & 14): conflict-free
+    // for the ds_write_b64 (16 channels of one 8-byte column) and for the transposed reads (4 channels x 16 pixels per group).
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));      // keeps this block's lane-only address terms out of the registers carried around the tile loop
+    const int cl = lane_o & 15, g4 = lane_o >> 4;
+    const float neg = a.act == SRGANFD_ACT_LRELU ? a.slope : (a.act == SRGANFD_ACT_RELU ? 0.f : 1.f);
+    const float ps_pos = a.post_scale, ps_neg = neg * a.post_scale;
+    char* rowt = smem + (wr * MR) * 2048;                                   // this wave's first row tile
+    const int w0 = cl * 64 + (((2 * g4) ^ (cl & 14)) << 2);                 // write: channel cl (+16 nh), pixels 4 g4 .. 4 g4 + 3 (+16 ph)
+    const int rq = 8 * g4 + ((lane_o >> 2) & 3), rp = lane_o & 3;               // read: this lane addresses channel rq (+4), pixels 4 rp .. (+16 pb)
+    const int r0 = rq * 64 + (((2 * rp) ^ (rq & 14)) << 2), r1 = (rq + 4) * 64 + (((2 * rp) ^ ((rq + 4) & 14)) << 2);
+    __syncthreads();   // all waves are done with the staging buffers
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          float v4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = alpha * acc[m][ph][nh][i] + (nh ? bvh1 : bvh0);
+            v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
+          }
+          u32x2_t pk;
+          if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+            const h4 hv = {(_Float16)v4[0], (_Float16)v4[1], (_Float16)v4[2], (_Float16)v4[3]};
+            pk = __builtin_bit_cast(u32x2_t, hv);
+          } else {
+            pk = u32x2_t{(unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16), (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16)};
+          }
+          *(u32x2_t*)(rowt + m * 2048 + nh * 1024 + (w0 ^ (ph << 5))) = pk;
+        }
+    const size_t img = (size_t)n * a.HoutF * a.WoutF;
+    const int cch = nb * C::NB + 8 * g4;                                    // this lane's 8 output channels
+    const int cc = a.y_c0 + cch;
+    T* ybase = (T*)a.y + img * a.yC + ((cc >> 5) * a.y_gs + (cc & 31));
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const u32x2_t lo = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(rowt + m * 2048 + (r0 ^ (pb << 5)))));
+        const u32x2_t hi = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(rowt + m * 2048 + (r1 ^ (pb << 5)))));
+        const int oy = oy0 + wr * MR + m, ox = ox0 + 16 * pb + cl;
+        if (oy < a.Hout && ox < a.Wout) {
+          const int pp = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+          *(u32x4*)(ybase + pp * a.y_ps) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    CONV_STAMP();   // stores issued
+#ifdef SRGANFD_EXPERIMENT
+    if (stamp_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CONV_STAMP(); }   // stores acknowledged
+#endif
+    return;
+  }
+  constexpr bool kR1 = EK < 0 || (EK & 1), kR2 = EK < 0 || (EK & 2), kMk = EK < 0 || (EK & 4);   // operands this instantiation can have
+  const bool has_r1 = EK < 0 ? a.r1 != nullptr : kR1, has_r2 = EK < 0 ? a.r2 != nullptr : kR2, has_mk = EK < 0 ? a.mask != nullptr : kMk;
+  if (EK >= 0 || a.fast_epi) {
     // (1) per-channel part (alpha, bias, activation, scale) on the accumulators -> fp32 LDS tile
     // [pixel][channel]; (2) 16 output bytes per lane: residuals / LeakyReLU' mask via 16-byte global
     // loads, 16-byte stores.
     float* tile = (float*)smem;
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));     // opaque copy: this block's thread-only address terms stay out of the tile loop's carried registers
     // The residual / mask tensors of the WHOLE tile are requested here, before the accumulators go through LDS: inside the store loop
     // each item's 16-byte load was followed by its s_waitcnt vmcnt(0) -- one exposed load latency per item, four per tile.  (16-bit
     // kernels with four items per thread: every 3x3 / 4x4 / 2x2 tile shape; up to 48 registers, free at this point: the staging ones.)
     constexpr int CPq = C::NB / C::E16, ITEMSq = C::TH * 32 * CPq, EIq = (ITEMSq + NTHR - 1) / NTHR;
+    // (not in the kinds that run persistent: there the staging registers hold the next tile's first chunk through the epilogue)
+    // (kinds that run persistent request them LATE, after the accumulators have gone to the LDS tile: the staging registers hold the
+    // next tile's first chunk through the epilogue, the accumulators' 32 registers are what is free)
     constexpr bool kEpiPre = sizeof(T) == 2 && EIq <= 4;
-    u32x4 pre_r1[kEpiPre ? EIq : 1], pre_r2[kEpiPre ? EIq : 1], pre_m[kEpiPre ? EIq : 1];
-    if constexpr (kEpiPre) {
+    constexpr bool kEpiLate = kEpiPre && kCross;
+    u32x4 pre_r1[kEpiPre && kR1 ? EIq : 1], pre_r2[kEpiPre && kR2 ? EIq : 1], pre_m[kEpiPre && kMk ? EIq : 1];
+    auto request_operands = [&]() __attribute__((always_inline)) {
+    if constexpr (kEpiPre && (kR1 || kR2 || kMk)) {
       const size_t imgq = (size_t)n * a.HoutF * a.WoutF;
 #pragma unroll
       for (int e = 0; e < EIq; ++e) {
-        const int item = tid + e * NTHR;
+        const int item = tid_e + e * NTHR;
         const int pix = item / CPq, ck = item % CPq;
         const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-        pre_r1[e] = pre_r2[e] = pre_m[e] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (kR1) pre_r1[e] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (kR2) pre_r2[e] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (kMk) pre_m[e] = u32x4{0u, 0u, 0u, 0u};
         if (item < ITEMSq && oy < a.Hout && ox < a.Wout) {
           const int p = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
           const int cch = nb * C::NB + ck * C::E16;
@@ -520,12 +707,14 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
             const int cc = c0 + cch;
             return *(const u32x4*)((const T*)base + imgq * Cs + (p * ps + (cc >> 5) * gs + (cc & 31)));
           };
-          if (a.r1) pre_r1[e] = ld(a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs);
-          if (a.r2) pre_r2[e] = ld(a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs);
-          if (a.mask) pre_m[e] = ld(a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs);
+          if constexpr (kR1) { if (has_r1) pre_r1[e] = ld(a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs); }
+          if constexpr (kR2) { if (has_r2) pre_r2[e] = ld(a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs); }
+          if constexpr (kMk) { if (has_mk) pre_m[e] = ld(a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs); }
         }
       }
     }
+    };
+    if constexpr (!kEpiLate) request_operands();
     __syncthreads();   // all waves are done with the staging buffers
     {
       // a lane's 16 values per row cover one channel (32x32 form) or two (16x16 form: elements 0-3 / 8-11 vs 4-7 / 12-15)
@@ -545,6 +734,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
           tile[((wr * MR + m) * 32 + A_.pixel(i, lane)) * C::NB + wn * 32 + A_.chan(i, lane)] = v * (v > 0.f ? ps_pos : ps_neg);
         }
     }
+    if constexpr (kEpiLate) request_operands();
     __syncthreads();
     constexpr int CP = C::NB / C::E16;                 // 16-byte output chunks per pixel
     constexpr int ITEMS = C::TH * 32 * CP;
@@ -553,7 +743,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     const size_t img = (size_t)n * a.HoutF * a.WoutF;   // pixels before this image (block-uniform)
 #pragma unroll kEpiPre ? 4 : 2
     for (int e = 0; e < EI; ++e) {
-      const int item = tid + e * NTHR;
+      const int item = tid_e + e * NTHR;
       const int pix = item / CP, ck = item % CP;
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (item < ITEMS && oy < a.Hout && ox < a.Wout) {
@@ -590,27 +780,32 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
             *(f32x4*)dstp = o;
           }
         };
-        if (a.y2) store16(a.y2, a.y2C, a.y2_c0, a.y2_ps, a.y2_gs, v);   // activation before the skip add (exact LeakyReLU' sign for backward)
+        if constexpr (EK < 0) { if (a.y2) store16(a.y2, a.y2C, a.y2_c0, a.y2_ps, a.y2_gs, v); }   // activation before the skip add (exact LeakyReLU' sign for backward)
         float tt[C::E16];
         auto get16 = [&](const u32x4* pre, const void* base, int Cs, int c0, int ps, int gs, float* out) {
           if constexpr (kEpiPre) unpack8<T>(pre[e], out);
           else load16(base, Cs, c0, ps, gs, out);
         };
-        if (a.r1) { get16(pre_r1, a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs, tt);
+        if constexpr (kR1) { if (has_r1) { get16(pre_r1, a.r1, a.r1C, a.r1_c0, a.r1_ps, a.r1_gs, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * tt[q]; }
-        if (a.r2) { get16(pre_r2, a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs, tt);
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r1s * tt[q]; } }
+        if constexpr (kR2) { if (has_r2) { get16(pre_r2, a.r2, a.r2C, a.r2_c0, a.r2_ps, a.r2_gs, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * tt[q]; }
-        if (a.mask) { get16(pre_m, a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs, tt);
+          for (int q = 0; q < C::E16; ++q) v[q] += a.r2s * tt[q]; } }
+        if constexpr (kMk) { if (has_mk) { get16(pre_m, a.mask, a.mC, a.m_c0, a.m_ps, a.m_gs, tt);
 #pragma unroll
-          for (int q = 0; q < C::E16; ++q) v[q] *= tt[q] > 0.f ? 1.f : a.mask_slope; }
+          for (int q = 0; q < C::E16; ++q) v[q] *= tt[q] > 0.f ? 1.f : a.mask_slope; } }
         store16(a.y, a.yC, a.y_c0, a.y_ps, a.y_gs, v);
       }
     }
+    CONV_STAMP();   // stores issued
+#ifdef SRGANFD_EXPERIMENT
+    if (stamp_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CONV_STAMP(); }   // stores acknowledged
+#endif
     return;
   }
   // generic epilogue (padded channel counts, fp32 output): scalar stores
+  if constexpr (EK < 0) {
   T* __restrict__ yg = (T*)a.y;
   const T* __restrict__ r1g = (const T*)a.r1;
   const T* __restrict__ r2g = (const T*)a.r2;
@@ -641,13 +836,46 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       }
     }
   }
+  }
+  }();
+  if (SRGANFD_DBG(a.dbg, 512)) __builtin_amdgcn_s_setprio(0);
+  if (!more) break;
+  if constexpr (!kCross) {
+    setup_loads(vt + gridDim.x);
+    first_loads();
+  }
+  }   // tiles of this workgroup
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1>
+// compute units of the current device (cached per device id); 256 when nothing can be asked (dry runs on the CPU)
+static int device_cus() {
+  static int cus[64] = {0};
+  if (g_dry_run) return 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& c = cus[dev & 63];
+  if (!c) {
+    int v = 0;
+    c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return c;
+}
+#ifdef SRGANFD_EXPERIMENT
+int g_no_persist = [] { const char* e = getenv("SRGANFD_NO_PERSIST"); return e ? atoi(e) : 0; }();   // A/B: one workgroup per tile (srganfd_set_igemm_variant bit 9)
+#else
+constexpr int g_no_persist = 0;
+#endif
+
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS>;
-  if (g_describe) { snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : ""); return SRGANFD_OK; }
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>;
+  if (g_describe) {
+    char ek[8] = "";
+    if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
+    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek);
+    return SRGANFD_OK;
+  }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
   if (!g_dry_run) {
     int dev = 0;
@@ -663,16 +891,29 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   kk.tiles_y = ceil_div(k.Hout, C::TH);
   const long long nblk = (long long)k.N * kk.tiles_x * kk.tiles_y * kk.nNb;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d: bad grid %lld", nblk);
+  kk.nblocks = (int)nblk;
   kk.m_nNb = div_magic((unsigned)kk.nNb, (unsigned long long)nblk);
   kk.m_tx = div_magic((unsigned)kk.tiles_x, (unsigned long long)nblk);
   kk.m_ty = div_magic((unsigned)kk.tiles_y, (unsigned long long)nblk);
-  SRGANFD_LAUNCH(kern, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS_BYTES, stream, kk);
+  // kinds that prefetch across tiles run as persistent workgroups: as many as the chip holds at once (a multiple of 8, so that the
+  // virtual blocks v, v + grid, ... of one workgroup keep their XCD class in xcd_remap)
+  long long grid = nblk;
+  if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2 && !g_no_persist) {
+    const long long slots = (long long)device_cus() * C::WG_PER_CU;
+    if (slots >= 8 && nblk > slots) grid = slots / 8 * 8;
+  }
+  SRGANFD_LAUNCH(kern, dim3((unsigned)grid), dim3(C::NTHR), C::LDS_BYTES, stream, kk);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 
 
 int g_igemm_variant = 0;
+#ifdef SRGANFD_EXPERIMENT
+int g_no_epi_kinds = [] { const char* e = getenv("SRGANFD_NO_EPI_KINDS"); return e ? atoi(e) : 0; }();   // A/B: run-time epilogue for every launch (srganfd_set_igemm_variant bit 8)
+#else
+constexpr int g_no_epi_kinds = 0;
+#endif
 // MFMA form of the 16-bit kernels (srganfd_set_mfma16 / environment SRGANFD_MFMA16 at load): 0 = v_mfma_f32_32x32x16 everywhere,
 // 1 = 16x16x32 for the 3x3 kernels with 32-channel tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default).
 // Same-box A/B of the training steps (profiles/r02_mfma16_ab.txt): generator-only 78.3 (0) -> 72.7 (1) -> 69.4 ms (2), GAN 179.6 (1)
@@ -698,7 +939,28 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
   constexpr bool bf = sizeof(T) == 2;
   if constexpr (bf) {
     if (conv_uses_m16(a->dtype, a->ksize, a->cout)) {
-      if (a->ksize == 3 && a->stride == 1) return wide ? launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
+      if (a->ksize == 3 && a->stride == 1) {
+        // epilogue kind fixed at compile time where the launch has the vectorised epilogue and no y2 (see the kernel's EK)
+        const int ek = (k.fast_epi && !k.y2 && !g_no_epi_kinds) ? ((k.r1 ? 1 : 0) | (k.r2 ? 2 : 0) | (k.mask ? 4 : 0)) : -1;
+#ifdef SRGANFD_EXPERIMENT
+        // tile-shape experiments on the plain kind (srganfd_set_igemm_variant low byte): 1 = 8-row tiles of 4 waves (40 KB of LDS: four
+        // workgroups per CU, four independent latency chains instead of two); 2 = 4 rows per wave (16-row tiles of 4 waves, two
+        // workgroups per CU at 256 registers)
+        if (ek == 0 && !wide && g_igemm_variant == 1) return launch_conv<T, 3, 1, 2, 4, 1, true, 1, 0>(k, a->cout, s);
+        if (ek == 0 && !wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 1, true, 1, 0>(k, a->cout, s);
+        if (ek == 0 && wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 2, true, 1, 0>(k, a->cout, s);
+#endif
+        if (wide) {
+          if (ek == 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 0>(k, a->cout, s);
+          if (ek == 1) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 1>(k, a->cout, s);
+          if (ek == 3) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 3>(k, a->cout, s);
+          if (ek == 4) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 4>(k, a->cout, s);
+          return launch_conv<T, 3, 1, 2, 4, 2, true>(k, a->cout, s);
+        }
+        if (ek == 0) return launch_conv<T, 3, 1, 2, 8, 1, true, 1, 0>(k, a->cout, s);
+        if (ek == 4) return launch_conv<T, 3, 1, 2, 8, 1, true, 1, 4>(k, a->cout, s);
+        return launch_conv<T, 3, 1, 2, 8, 1, true>(k, a->cout, s);
+      }
       if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2, true>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1, true>(k, a->cout, s);
       if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 4, 2, true>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1, true>(k, a->cout, s);
       // 4x4 stride 2, 64-channel tiles: weights staged in two halves of two kernel rows -> 73 KiB of LDS, two workgroups per CU

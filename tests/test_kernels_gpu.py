@@ -121,6 +121,55 @@ def test_conv2d_forward(dtype, case, mfma16):
     assert torch.all(ybuf[..., :y_c0] == 7.0) and torch.all(ybuf[..., y_c0 + cout:] == 7.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("planar", [0, 1])
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=32, act=1, bias=True, kind="E0"),                                   # growth conv: 16-bit transposed tile
+    dict(cin=160, cout=32, act=1, bias=True, post_scale=0.5, alpha=1.5, kind="E0"),
+    dict(cin=96, cout=32, mask=True, kind="E4"),                                          # its data-gradient twin
+    dict(cin=192, cout=64, bias=True, r1=True, kind="E1"),                                # conv5
+    dict(cin=192, cout=64, bias=True, r1=True, r2=True, kind="E3"),                       # conv5 at the end of an RRDB
+    dict(cin=64, cout=64, act=1, bias=True, kind="E0"),                                   # tail / VGG convs
+    dict(cin=64, cout=64, mask=True, kind="E4"),
+])
+def test_conv2d_compile_time_epilogue_kinds_are_bitwise_the_runtime_epilogue(dtype, planar, case):
+    """The 3x3 stride-1 16-bit launches run with an epilogue fixed at compile time (conv_igemm_kernel's EK); a launch that also asks for
+    y2 takes the run-time epilogue.  Same inputs through both: y must be identical bit for bit (ragged tile edges included), and the
+    kernel label must show the kind."""
+    from sr_gan_fd_amd import _abi as A, ops, profiling
+    torch.manual_seed(11)
+    dt = ops.DT[dtype]
+    n, h, w, cin, cout = 2, 21, 45, case["cin"], case["cout"]
+    x = (torch.randn(n, h, w, 192, device="cuda") * 0.7).to(dtype)
+    wt = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+    wp = ops.pack_single(wt, dt)
+    b = torch.randn(cout, device="cuda") if case.get("bias") else None
+    C_ = 96 if cout == 32 else 64
+    c0 = 32 if cout == 32 else 0
+    kw = dict(bias=b, act=case.get("act", 0), post_scale=case.get("post_scale", 1.0), alpha=case.get("alpha", 1.0))
+    keep = []
+    if case.get("r1"):
+        r1 = torch.randn(n, h, w, C_, device="cuda").to(dtype); keep.append(r1)
+        kw.update(r1=A.view(r1, c0=c0, planar=planar), r1_scale=0.2)
+    if case.get("r2"):
+        r2 = torch.randn(n, h, w, C_, device="cuda").to(dtype); keep.append(r2)
+        kw.update(r2=A.view(r2, c0=c0, planar=planar), r2_scale=1.0)
+    if case.get("mask"):
+        m = torch.randn(n, h, w, C_, device="cuda").to(dtype); keep.append(m)
+        kw.update(mask=A.view(m, c0=c0, planar=planar), mask_slope=0.2)
+    ya = torch.full((n, h, w, C_), 7.0, dtype=dtype, device="cuda")
+    yb = torch.full((n, h, w, C_), 7.0, dtype=dtype, device="cuda")
+    y2 = torch.empty(n, h, w, C_, dtype=dtype, device="cuda")
+    a = ops.conv_args(dt, A.view(x, planar=planar), A.view(ya, c0=c0, planar=planar), wp, n, h, w, cin, cout, **kw)
+    bq = ops.conv_args(dt, A.view(x, planar=planar), A.view(yb, c0=c0, planar=planar), wp, n, h, w, cin, cout, y2=A.view(y2, c0=c0, planar=planar), **kw)
+    assert profiling.conv_label(a).endswith("," + case["kind"] + ">"), profiling.conv_label(a)
+    assert ",E" not in profiling.conv_label(bq)
+    ops.conv2d(a); ops.conv2d(bq)
+    torch.cuda.synchronize()
+    assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
+    assert torch.isfinite(ya.float()).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_dgrad_orientation(dtype, mfma16):
     """weights packed with transposed=1 turn the same kernel into the data-gradient pass"""

@@ -26,6 +26,7 @@ PLANAR = 0 if "--nhwc" in sys.argv else 1
 MODES = [int(m) for m in arg("--modes", "0,1,2,3").split(",")]
 ROUNDS, REPS = int(arg("--rounds", "5")), int(arg("--reps", "20"))
 DBGS = [int(d) for d in arg("--dbg", "0").split(",")]      # SRGANFD_EXPERIMENT builds only (SRGANFD_LIB=build_exp/libsrganfd_exp.so)
+IGV = [int(d) for d in arg("--igv", "0").split(",")]       # experiment builds: srganfd_set_igemm_variant values (bit 8 = run-time epilogue everywhere, low byte = tile variant)
 ONLY = arg("--only", "")                                    # substring filter on the shape names
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}[arg("--dtype", "bf16")]
 
@@ -94,10 +95,12 @@ if __name__ == "__main__":
     for rnd in range(ROUNDS + 1):                      # round 0 = warm-up
         for name, (a32, a16), keep, fl in shapes:
             for m in MODES:
-                for d in DBGS:
+                for d, gv in [(d_, g_) for d_ in DBGS for g_ in IGV]:
                     a = a16 if m == 8 else a32           # mode 8: conv_igemm on v_mfma_f32_16x16x32
                     _switch("srganfd_set_mfma16", 3 if m == 8 else 0)
                     _switch("srganfd_set_ring_mode", 0 if m == 8 else m)
+                    if len(IGV) > 1 or gv:
+                        L.srganfd_set_igemm_variant(gv)       # (after the ring-mode switch, which resets the tile variant)
                     if d or len(DBGS) > 1:
                         L.srganfd_set_debug(d)
                     if hasattr(a, "_kernel_label"):
@@ -105,10 +108,10 @@ if __name__ == "__main__":
                     lab = profiling.conv_label(a)
                     us = time_one(a, 3 if rnd == 0 else REPS)
                     if rnd:
-                        res.setdefault((name, m, d, lab, fl), []).append(us)
+                        res.setdefault((name, m, d + 100000 * gv, lab, fl), []).append(us)
     _switch("srganfd_set_ring_mode", -1)
     _switch("srganfd_set_mfma16", 3)
     for (name, m, d, lab, fl), v in res.items():
         v.sort()
         med = v[len(v) // 2]
-        print(f"{name:38s} mode {m} dbg {d:2d}: median {med:7.1f} us  min {v[0]:7.1f}  {fl / med / 1e6:7.1f} TFLOP/s   {lab}")
+        print(f"{name:38s} mode {m} dbg {d % 100000:2d} igv {d // 100000:3d}: median {med:7.1f} us  min {v[0]:7.1f}  {fl / med / 1e6:7.1f} TFLOP/s   {lab}")

@@ -12,6 +12,9 @@ def arg(name, default):
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}[arg("--dtype", "bf16")]
 SPLITS = [int(x) for x in arg("--splits", "0").split(",")]
 VARIANTS = [int(x) for x in arg("--variants", "0,1,2").split(",")]
+DBG = int(arg("--dbg", "0"))     # experiment builds: 1 no global loads, 16 no LDS reads / MFMA, 4 no slab store (results are wrong)
+if DBG:
+    A.lib().srganfd_set_debug(DBG)
 N, H, W, Cc, G = int(arg("--batch", "32")), 128, 128, 64, 32
 Ccat = Cc + 4 * G
 dtc = ops.DT[DT]
