@@ -223,15 +223,17 @@ int srganfd_axpby(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, i
 /* ---- losses (train_bsrgan.py:297,301,417,427,450-452).  workspace: >= 2048 floats.
  * *out = (accumulate ? *out : 0) + weight * mean(...).  Deterministic two-stage reductions. */
 #define SRGANFD_LOSS_WS_FLOATS 2049
+/* grad = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) * d(mean)/d(input): grad_scale_dev is the device-resident loss scale of
+ * f16 training (srganfd_loss_scale_update), NULL otherwise. */
 int srganfd_l1_loss(const float* a, const float* b, int64_t numel, float weight, float* out,
-                    int32_t accumulate, float* grad_a /* or NULL */, float grad_scale, float* workspace,
-                    void* stream);
+                    int32_t accumulate, float* grad_a /* or NULL */, float grad_scale,
+                    const float* grad_scale_dev /* or NULL */, float* workspace, void* stream);
 int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t npix, int32_t c,
                           int32_t relu_first, float weight, float* out, int32_t accumulate,
                           float* workspace, void* stream);
 int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out,
                        int32_t accumulate, float* sigmoid_mean_out /* or NULL */, float* grad /* or NULL */,
-                       float grad_scale, float* workspace, void* stream);
+                       float grad_scale, const float* grad_scale_dev /* or NULL */, float* workspace, void* stream);
 /* *out = sigmoid(mean(logits)): the D(x) probability as ESRGAN / Real-ESRGAN log it (train_esrgan.py:430-431,
  * train_realesrgan.py:475-476; BSRGAN logs mean(sigmoid), srganfd_bce_logits' sigmoid_mean_out). */
 int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, float* workspace, void* stream);
@@ -270,7 +272,14 @@ int srganfd_spectral_norm_grad_batch(const srganfd_sn_grad_job* jobs, int32_t nj
  * followed by the unconditional ema update of train_bsrgan.py:466-470. */
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                      int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
-                     int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, const float* skip_flag, void* stream);
+                     int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, const float* skip_flag,
+                     const float* grad_scale_dev /* or NULL: multiplies grad_scale (1 / loss scale from the scaler state) */, void* stream);
+/* torch.amp.GradScaler.update() on a device-resident state (torch keeps its scale on the device as well, so that neither the host nor a
+ * captured graph carries a stale value): state = 8 floats {scale, 1 / scale, growth tracker, optimizer steps, skipped steps, 0, 0, 0}.
+ * *found_inf != 0: scale *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth_factor (kept if that
+ * would overflow), tracker = 0.  Loss kernels read state[0] as grad_scale_dev, the Adam kernels state[1]; train_bsrgan.py:109,436-437,466-467. */
+int srganfd_loss_scale_update(float* state, const float* found_inf, float growth_factor, float backoff_factor,
+                              int32_t growth_interval, void* stream);
 /* *flag = 1.0 if any element of x is inf or NaN, else 0.0 (accumulate != 0: keeps an earlier 1.0): the found_inf of
  * GradScaler.unscale_ (train_bsrgan.py:436,466), computed on the flat (all-reduced) gradient. */
 int srganfd_nonfinite_flag(const float* x, int64_t numel, float* flag, int32_t accumulate, void* stream);
@@ -279,7 +288,7 @@ int srganfd_nonfinite_flag(const float* x, int64_t numel, float* flag, int32_t a
 int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                          int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode,
-                         const float* skip_flag, void* stream);
+                         const float* skip_flag, const float* grad_scale_dev /* or NULL */, void* stream);
 
 /* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
 /* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);

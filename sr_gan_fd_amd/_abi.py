@@ -105,23 +105,24 @@ SYMBOLS = {
     "srganfd_resample_bwd_lrelu": (C.c_int, [View, View, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_resample": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_axpby": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
-    "srganfd_l1_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_l1_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_l1_loss_views": (C.c_int, [View, View, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "srganfd_sigmoid_of_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "srganfd_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "srganfd_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "srganfd_spectral_norm_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_spectral_norm_grad_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "srganfd_adam_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                   C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+                                   C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srganfd_loss_scale_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "srganfd_nonfinite_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "srganfd_resize_bilinear": (C.c_int, [C.c_int32, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_add_relu": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "srganfd_sigmoid": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "srganfd_adam_ema_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_l1_grad_views": (C.c_int, [View, View, View, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]),
     "srganfd_maxpool2_relu_bwd": (C.c_int, [View, View, View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srganfd_nhwc_to_nchw_scaled": (C.c_int, [View, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -39,18 +39,20 @@ int resample_impl(int op, srganfd_view a, srganfd_view b, int dtype, int n, int 
 int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view act, srganfd_view dx_masked, int dtype, int n, int h, int w, int c, float slope,
                             hipStream_t s);
 int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, float a, float b, hipStream_t s);
-int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s);
+int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale,
+                 const float* grad_scale_dev, float* ws, hipStream_t s);
 int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStream_t s);
 int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s);
 int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
-                    float grad_scale, float* ws, hipStream_t s);
+                    float grad_scale, const float* grad_scale_dev, float* ws, hipStream_t s);
 int spectral_norm_grad_batch_impl(const srganfd_sn_grad_job* jobs, int njobs, float beta, hipStream_t s);
 int spectral_norm_batch_impl(const srganfd_sn_job* jobs, int njobs, int training, float eps, hipStream_t s);
 int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s);
 int spectral_norm_grad_impl(const float* G, const float* W, const float* u, const float* v, const float* inv_sigma, float* dW, int rows, int cols,
                             float beta, float* ws, hipStream_t s);
 int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s);
+                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, const float* grad_scale_dev, hipStream_t s);
+int loss_scale_update_impl(float* state, const float* found_inf, float growth, float backoff, int interval, hipStream_t s);
 int nonfinite_flag_impl(const float* x, size_t n, float* flag, int accumulate, hipStream_t s);
 int resize_bilinear_impl(int bwd, srganfd_view a, srganfd_view b, int dtype, int n, int hi, int wi, int ho, int wo, int c, hipStream_t s);
 int add_relu_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dtype, size_t npix, int c, hipStream_t s);
@@ -58,7 +60,8 @@ int l1_grad_views_impl(srganfd_view a, srganfd_view b, srganfd_view out, int dty
 int maxpool2_relu_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dtype, int n, int h, int w, int c, hipStream_t s);
 int nhwc_to_nchw_scaled_impl(srganfd_view src, int n, int c, int h, int w, float* dst, const float* ch_div, hipStream_t s);
 int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s);
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag,
+                      const float* grad_scale_dev, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
 int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
@@ -97,7 +100,7 @@ using namespace srganfd;
 extern "C" {
 
 const char* srganfd_last_error(void) { return g_err; }
-int srganfd_abi_version(void) { return 2; }
+int srganfd_abi_version(void) { return 3; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 int srganfd_get_mfma16(void) { return srganfd::g_mfma16; }
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganfd::conv_uses_m16(dtype, ksize, n) ? 1 : 0; }
@@ -173,8 +176,8 @@ int srganfd_axpby(srganfd_view x, srganfd_view y, int32_t dtype, int64_t npix, i
   return axpby_impl(x, y, dtype, (size_t)npix, c, alpha, beta, (hipStream_t)stream);
 }
 int srganfd_l1_loss(const float* a, const float* b, int64_t numel, float weight, float* out, int32_t accumulate, float* grad_a, float grad_scale,
-                    float* workspace, void* stream) {
-  return l1_loss_impl(a, b, (size_t)numel, weight, out, accumulate, grad_a, grad_scale, workspace, (hipStream_t)stream);
+                    const float* grad_scale_dev, float* workspace, void* stream) {
+  return l1_loss_impl(a, b, (size_t)numel, weight, out, accumulate, grad_a, grad_scale, grad_scale_dev, workspace, (hipStream_t)stream);
 }
 int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t npix, int32_t c, int32_t relu_first, float weight, float* out,
                           int32_t accumulate, float* workspace, void* stream) {
@@ -184,8 +187,9 @@ int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, floa
   return sigmoid_of_mean_impl(logits, numel > 0 ? (size_t)numel : 0, out, workspace, (hipStream_t)stream);
 }
 int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out, int32_t accumulate,
-                       float* sigmoid_mean_out, float* grad, float grad_scale, float* workspace, void* stream) {
-  return bce_logits_impl(logits, (size_t)numel, target, weight, loss_out, accumulate, sigmoid_mean_out, grad, grad_scale, workspace, (hipStream_t)stream);
+                       float* sigmoid_mean_out, float* grad, float grad_scale, const float* grad_scale_dev, float* workspace, void* stream) {
+  return bce_logits_impl(logits, (size_t)numel, target, weight, loss_out, accumulate, sigmoid_mean_out, grad, grad_scale, grad_scale_dev, workspace,
+                         (hipStream_t)stream);
 }
 int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma_out,
                           float* inv_sigma_out, float* workspace, void* stream) {
@@ -203,9 +207,12 @@ int srganfd_spectral_norm_grad_batch(const srganfd_sn_grad_job* jobs, int32_t nj
 }
 int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float ema_decay, int32_t ema_mode,
-                     const float* skip_flag, void* stream) {
+                     const float* skip_flag, const float* grad_scale_dev, void* stream) {
   return adam_ema_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay,
-                       ema_mode, skip_flag, (hipStream_t)stream);
+                       ema_mode, skip_flag, grad_scale_dev, (hipStream_t)stream);
+}
+int srganfd_loss_scale_update(float* state, const float* found_inf, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream) {
+  return loss_scale_update_impl(state, found_inf, growth_factor, backoff_factor, growth_interval, (hipStream_t)stream);
 }
 int srganfd_nonfinite_flag(const float* x, int64_t numel, float* flag, int32_t accumulate, void* stream) {
   return nonfinite_flag_impl(x, (size_t)numel, flag, accumulate, (hipStream_t)stream);
@@ -217,9 +224,9 @@ int srganfd_resize_bilinear(int32_t bwd, srganfd_view a, srganfd_view b, int32_t
 }
 int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay,
-                         int32_t ema_mode, const float* skip_flag, void* stream) {
+                         int32_t ema_mode, const float* skip_flag, const float* grad_scale_dev, void* stream) {
   return adam_ema_dev_impl(param, grad, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step_dev, bc_dev, grad_scale,
-                           ema_decay, ema_mode, skip_flag, (hipStream_t)stream);
+                           ema_decay, ema_mode, skip_flag, grad_scale_dev, (hipStream_t)stream);
 }
 int srganfd_l1_grad_views(srganfd_view a, srganfd_view b, srganfd_view out, int32_t dtype, int64_t npix, int32_t c, const float* upstream,
                           float scale, void* stream) {

@@ -539,9 +539,10 @@ __global__ void lrelu_bwd_kernel(const void* __restrict__ dy, int dC, int d0, co
 // ---- losses.  out[slot] (+)= weight * mean(...) ; two-stage deterministic reduction ----
 // L1 (nn.L1Loss, train_bsrgan.py:297,450) on flat fp32 arrays, optional gradient wrt a.
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float gscale,
-                                                         float* __restrict__ grad, float* __restrict__ partial) {
+                                                         const float* __restrict__ gscale_dev, float* __restrict__ grad, float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
+  if (gscale_dev) gscale *= *gscale_dev;      // the loss scale lives in device memory (srganfd_loss_scale_update), as torch's GradScaler keeps it
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float d = a[i] - b[i];
     s += fabsf(d);
@@ -593,9 +594,11 @@ __global__ __launch_bounds__(256) void l1_views_vec_partial_kernel(const void* _
 }
 // BCE-with-logits against a constant label map (train_bsrgan.py:301,403-404): loss and sigmoid mean
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ x, size_t n, float target, float gscale,
-                                                          float* __restrict__ grad, float* __restrict__ partial, float* __restrict__ partial_sig) {
+                                                          const float* __restrict__ gscale_dev, float* __restrict__ grad, float* __restrict__ partial,
+                                                          float* __restrict__ partial_sig) {
   __shared__ float sh[4];
   float s = 0.f, sg = 0.f;
+  if (gscale_dev) gscale *= *gscale_dev;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = x[i];
     s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
@@ -749,7 +752,8 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(const SnGradJobs jobs, flo
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
                                                        float bc1, float bc2_sqrt, float gscale, float ema_decay, int ema_mode,
-                                                       const float* __restrict__ skip) {
+                                                       const float* __restrict__ skip, const float* __restrict__ gscale_dev) {
+  if (gscale_dev) gscale *= *gscale_dev;      // 1 / loss scale, from the device-resident scaler state
   // loss-scaled (f16) training: a non-finite gradient skips the parameter update (GradScaler.step, train_bsrgan.py:436,466); the
   // EMA still advances -- the reference calls update_parameters() after every iteration (:470)
   const bool skipped = skip && *skip != 0.f;
@@ -786,8 +790,9 @@ __global__ void adam_step_kernel(int* __restrict__ step, float b1, float b2, flo
 __global__ __launch_bounds__(256) void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
                                                            const float* __restrict__ bc, float gscale, float ema_decay, int ema_mode,
-                                                           const float* __restrict__ skip) {
+                                                           const float* __restrict__ skip, const float* __restrict__ gscale_dev) {
   const float bc1 = bc[0], bc2_sqrt = bc[1];
+  if (gscale_dev) gscale *= *gscale_dev;
   const bool skipped = skip && *skip != 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     if (skipped) {
@@ -1478,10 +1483,11 @@ int axpby_impl(srganfd_view x, srganfd_view y, int dtype, size_t npix, int c, fl
 
 static constexpr int kRedBlocks = 1024;  // workspace floats needed by the loss entry points: 2 * kRedBlocks
 
-int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale, float* ws, hipStream_t s) {
+int l1_loss_impl(const float* a, const float* b, size_t n, float weight, float* out, int accumulate, float* grad, float grad_scale,
+                 const float* grad_scale_dev, float* ws, hipStream_t s) {
   if (!a || !b || !out || !ws || n == 0) return set_err(SRGANFD_EINVAL, "l1_loss: bad args");
   const unsigned g = grid_for(n, 256, kRedBlocks);
-  SRGANFD_LAUNCH(l1_partial_kernel, dim3(g), dim3(256), 0, s, a, b, n, grad_scale / (float)n, grad, ws);
+  SRGANFD_LAUNCH(l1_partial_kernel, dim3(g), dim3(256), 0, s, a, b, n, grad_scale / (float)n, grad_scale_dev, grad, ws);
   SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, out, accumulate);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
@@ -1502,10 +1508,10 @@ int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c,
   return SRGANFD_OK;
 }
 int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
-                    float grad_scale, float* ws, hipStream_t s) {
+                    float grad_scale, const float* grad_scale_dev, float* ws, hipStream_t s) {
   if (!x || !loss_out || !ws || n == 0) return set_err(SRGANFD_EINVAL, "bce: bad args");
   const unsigned g = grid_for(n, 256, kRedBlocks);
-  SRGANFD_LAUNCH(bce_partial_kernel, dim3(g), dim3(256), 0, s, x, n, target, grad_scale / (float)n, grad, ws, ws + kRedBlocks);
+  SRGANFD_LAUNCH(bce_partial_kernel, dim3(g), dim3(256), 0, s, x, n, target, grad_scale / (float)n, grad_scale_dev, grad, ws, ws + kRedBlocks);
   SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, loss_out, accumulate);
   if (sig_mean_out) SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + kRedBlocks), (int)g, 1.f / (float)n, sig_mean_out, 0);
   SRGANFD_HIP_CHECK(hipGetLastError());
@@ -1596,21 +1602,47 @@ int nonfinite_flag_impl(const float* x, size_t n, float* flag, int accumulate, h
 }
 
 int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s) {
+                  float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, const float* grad_scale_dev, hipStream_t s) {
   if (!p || !g || !m || !v || n == 0 || step < 1 || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam: bad args");
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   SRGANFD_LAUNCH(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2),
-                     grad_scale, ema_decay, ema_mode, skip_flag);
+                     grad_scale, ema_decay, ema_mode, skip_flag, grad_scale_dev);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
+// torch.amp.GradScaler.update() (torch/amp/grad_scaler.py, _amp_update_scale_) on a device-resident state, so that neither the host nor a
+// captured graph ever carries a stale scale: state = {scale, 1 / scale, growth tracker, optimizer steps, skipped steps}.
+__global__ void loss_scale_update_kernel(float* __restrict__ st, const float* __restrict__ found_inf, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float scale = st[0], tracker = st[2];
+  st[3] += 1.f;
+  if (*found_inf != 0.f) {
+    scale *= backoff; tracker = 0.f; st[4] += 1.f;
+  } else {
+    tracker += 1.f;
+    if (tracker >= (float)interval) {
+      const float grown = scale * growth;
+      if (fabsf(grown) <= 3.402823466e38f) scale = grown;       // torch keeps the scale when growing it would overflow
+      tracker = 0.f;
+    }
+  }
+  st[0] = scale; st[1] = 1.f / scale; st[2] = tracker;
+}
+int loss_scale_update_impl(float* state, const float* found_inf, float growth, float backoff, int interval, hipStream_t s) {
+  if (!state || !found_inf || interval < 1 || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f)) return set_err(SRGANFD_EINVAL, "loss_scale_update: bad args");
+  SRGANFD_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), 0, s, state, found_inf, growth, backoff, interval);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 
 int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag, hipStream_t s) {
+                      int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag,
+                      const float* grad_scale_dev, hipStream_t s) {
   if (!p || !g || !m || !v || n == 0 || !step_dev || !bc_dev || (ema_mode && !ema)) return set_err(SRGANFD_EINVAL, "adam(dev): bad args");
   SRGANFD_LAUNCH(adam_step_kernel, dim3(1), dim3(64), 0, s, step_dev, b1, b2, bc_dev, skip_flag);
   SRGANFD_LAUNCH(adam_ema_dev_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, wd, (const float*)bc_dev, grad_scale,
-                 ema_decay, ema_mode, skip_flag);
+                 ema_decay, ema_mode, skip_flag, grad_scale_dev);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -21,7 +21,7 @@ from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
 from .parallel import BucketReducer, SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
-from .trainer import FlatAdamEMA, LossScaler, needs_loss_scaling
+from .trainer import FlatAdamEMA, LossScaler, check_loss_scaling, needs_loss_scaling
 
 
 class GanTrainer:
@@ -93,12 +93,13 @@ class GanTrainer:
                 if "ema_state_dict" in c and opt.ema is not None:
                     opt.load_ema_state_dict(c["ema_state_dict"])
 
-    def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor, S: float = 1.0) -> None:
-        """loss value weighted by ``weight``; its gradient by ``weight * S`` (S = the loss scale of the backward pass it seeds)"""
+    def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
+        """loss value weighted by ``weight``; its gradient by ``weight`` times the loss scale the device holds when the kernel runs
+        (scaler.scale(loss): trainer.LossScaler)"""
         s = self.scalars.data_ptr()
         A.check(A.lib().srganfd_bce_logits(logits.data_ptr(), logits.numel(), target, weight, s + 4 * slot, 0,
-                                           (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight * S,
-                                           self.ws.data_ptr(), A.stream_ptr()), "bce_logits")
+                                           (s + 4 * prob_slot) if prob_slot is not None else None, dlogits.data_ptr(), weight,
+                                           self.scaler.seed_ptr, self.ws.data_ptr(), A.stream_ptr()), "bce_logits")
 
     def _content(self, sr: Tensor, gt: Tensor) -> None:
         if self.content is not None:
@@ -117,32 +118,31 @@ class GanTrainer:
         sr = ge.forward(lr_img, True)
         g_sp, g_tok = ge._last, ge.token
         dsr = self._buf("dsr", sr)
-        Sg = self.scaler.current()
-        A.check(L.srganfd_l1_loss(sr.data_ptr(), gtu.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw * Sg,
-                                  self.ws.data_ptr(), st), "l1_loss")
+        check_loss_scaling(self.scaler, self.g, self.d)
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gtu.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+                                  self.scaler.seed_ptr, self.ws.data_ptr(), st), "l1_loss")
         self._content(sr, gtu)
         adv_out = de.forward(sr, True)
         dl = self._buf("dl", adv_out)
-        self._bce(adv_out, 1.0, self.aw, 3, None, dl, Sg)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             self.g_reducer.begin()
             gg, _ = ge.backward(g_sp, g_tok, dsr, False, on_ready=self.g_reducer.bucket)
-            self.scaler.step(self.g_opt, gg, self.g_reducer.finish(), Sg)
+            self.scaler.step(self.g_opt, gg, self.g_reducer.finish())
             ge.fp.touch()
         s = self.scalars.data_ptr()
-        Sd = self.scaler.current()
         gt_out = de.forward(gt, True)
-        self._bce(gt_out, 1.0, 1.0, 0, None, dl, Sd)
+        self._bce(gt_out, 1.0, 1.0, 0, None, dl)
         A.check(L.srganfd_sigmoid_of_mean(gt_out.data_ptr(), gt_out.numel(), s + 16, self.ws.data_ptr(), st), "sigmoid_of_mean")
         gd1, _ = de.backward(de._last, de.token, dl, True, False)
         sr_out = de.forward(sr, True)
-        self._bce(sr_out, 0.0, 1.0, 1, None, dl, Sd)
+        self._bce(sr_out, 0.0, 1.0, 1, None, dl)
         A.check(L.srganfd_sigmoid_of_mean(sr_out.data_ptr(), sr_out.numel(), s + 20, self.ws.data_ptr(), st), "sigmoid_of_mean")
         gd2, _ = de.backward(de._last, de.token, dl, True, False)
         A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
-        self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd)
+        self.scaler.step(self.d_opt, gd2, self._allreduce(gd2))
         self.sr = sr
         return self.scalars
 
@@ -158,35 +158,35 @@ class GanTrainer:
         ge, de = self.ge, self.de
         gt = gt.contiguous().float()
         # ---- discriminator ----
-        Sd = self.scaler.current()                          # scaler.scale(d_loss_*): train_bsrgan.py:420,430
+        check_loss_scaling(self.scaler, self.g, self.d)
         gt_out = de.forward(gt, True)
         dl = self._buf("dl", gt_out)
-        self._bce(gt_out, 1.0, 1.0, 0, 4, dl, Sd)
+        self._bce(gt_out, 1.0, 1.0, 0, 4, dl)                 # scaler.scale(d_loss_*): train_bsrgan.py:420,430
         gd1, _ = de.backward(de._last, de.token, dl, True, False)
         sr = ge.forward(lr_img, True)
         g_sp, g_tok = ge._last, ge.token
         sr_out = de.forward(sr, True)
-        self._bce(sr_out, 0.0, 1.0, 1, 5, dl, Sd)
+        self._bce(sr_out, 0.0, 1.0, 1, 5, dl)
         gd2, _ = de.backward(de._last, de.token, dl, True, False)
         A.check(L.srganfd_axpby(A.View(gd1.data_ptr(), 1, 0), A.View(gd2.data_ptr(), 1, 0), A.F32, gd2.numel(), 1, 1.0, 1.0, st), "axpby")
         # scaler.step(d_optimizer); scaler.update()  (:436-437).  Under data parallelism the all-reduce and the Adam kernel go to a
         # side stream: the pixel loss and the VGG-19 content forwards below do not read D's parameters
-        self.d_reducer.launch(lambda: self.scaler.step(self.d_opt, gd2, self._allreduce(gd2), Sd), tensors=(gd2,))
+        self.d_reducer.launch(lambda: self.scaler.step(self.d_opt, gd2, self._allreduce(gd2)), tensors=(gd2,))
         # ---- generator ----
-        Sg = self.scaler.current()                          # the scale after the discriminator's update()  (:463)
         dsr = self._buf("dsr", sr)
-        A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw * Sg,
-                                  self.ws.data_ptr(), st), "l1_loss")
         self._content(sr, gt)
-        self.d_reducer.wait()                               # D's updated parameters from here on
+        self.d_reducer.wait()                               # D's updated parameters -- and the loss scale after its update() -- from here on
+        # the pixel loss seeds the generator's backward pass with the scale AFTER the discriminator's scaler.update() (:463)
+        A.check(L.srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.pw, self.scalars.data_ptr() + 8, 0, dsr.data_ptr(), self.pw,
+                                  self.scaler.seed_ptr, self.ws.data_ptr(), st), "l1_loss")
         adv_out = de.forward(sr, True)                      # updated D, SN state advances again (train_bsrgan.py:452)
-        self._bce(adv_out, 1.0, self.aw, 3, None, dl, Sg)
+        self._bce(adv_out, 1.0, self.aw, 3, None, dl)
         if self.train_generator:
             _, dsr_adv = de.backward(de._last, de.token, dl, False, True)
             A.check(L.srganfd_axpby(A.View(dsr_adv.data_ptr(), 1, 0), A.View(dsr.data_ptr(), 1, 0), A.F32, dsr.numel(), 1, 1.0, 1.0, st), "axpby")
             self.g_reducer.begin()
             gg, _ = ge.backward(g_sp, g_tok, dsr, False, on_ready=self.g_reducer.bucket)
-            self.scaler.step(self.g_opt, gg, self.g_reducer.finish(), Sg)    # scaler.step(g_optimizer); scaler.update(); EMA  (:466-470)
+            self.scaler.step(self.g_opt, gg, self.g_reducer.finish())        # scaler.step(g_optimizer); scaler.update(); EMA  (:466-470)
             ge.fp.touch()
         self.sr = sr
         return self.scalars

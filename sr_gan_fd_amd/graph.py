@@ -6,8 +6,8 @@ cost, at small batches (BASELINE configs[0]: 4 x 32x32) the step is launch-bound
 the engines only launch kernels on torch's current stream (no host synchronisation, no host-side scalars that change
 between iterations once the Adam step count lives in device memory), so the capture is exact.
 Single-process only: the RCCL all-reduce of the data-parallel path is not captured here.  f16 trainers (dynamic loss scaling,
-trainer.LossScaler) are supported: the scale is a captured by-value argument, the found_inf flags the captured step writes are
-copied out after every replay and folded in at the scaler's fixed lag, and a changed scale captures the graph again.
+trainer.LossScaler) need nothing special: the scale, the found_inf flag and GradScaler.update() all live on the device, so the
+captured kernels read and advance them at every replay exactly as the eager step does.
 """
 from __future__ import annotations
 
@@ -22,8 +22,6 @@ class GraphedStep:
         if getattr(trainer, "pg", None) is not None:
             raise ValueError("GraphedStep: data-parallel trainers are not captured (the all-reduce stays eager)")
         self.trainer = trainer
-        sc = getattr(trainer, "scaler", None)
-        self.scaler = sc if getattr(sc, "enabled", False) else None      # f16 trainers: dynamic loss scaling (trainer.LossScaler)
         self.lr, self.gt = lr_example.clone(), gt_example.clone()      # static input buffers
         for opt in (getattr(trainer, "opt", None), getattr(trainer, "g_opt", None), getattr(trainer, "d_opt", None)):
             if opt is not None:
@@ -46,16 +44,9 @@ class GraphedStep:
         a change (the reference steps MultiStepLR every epoch, train_bsrgan.py:193-195) re-captures the graph."""
         opts = self._opts()
         before = [(o.t, o.n_averaged) for o in opts]
-        if self.scaler is not None:
-            # the scale is a by-value argument of the loss-seed and Adam kernels: the captured step runs with the scale of this
-            # moment; the found_inf flags it writes are copied out after every replay, folded in at the scaler's fixed lag by
-            # current() before the next one, and a changed scale re-captures (it is part of _hyper())
-            self.scaler.current()
-            self.scaler.captured_flags = []
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self.trainer.step(self.lr, self.gt)
-        self._flags = list(self.scaler.captured_flags) if self.scaler is not None else []
         # the host-side counters advanced during capture although nothing ran: undo exactly what moved (an optimizer that
         # did not step -- train_generator=False -- keeps its counters)
         self._delta = []
@@ -67,18 +58,14 @@ class GraphedStep:
     def _hyper(self):
         tr = self.trainer
         return ([(o.lr, tuple(o.betas), o.eps, o.wd, o.ema_decay) for o in self._opts()],
-                tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")) + (getattr(getattr(tr, "scaler", None), "scale", 1.0),))
+                tuple(repr(getattr(tr, k, None)) for k in ("pw", "cw", "aw", "loss_weight", "train_generator")))
 
     def __call__(self, lr_img: Tensor, gt: Tensor) -> Tensor:
-        if self.scaler is not None:
-            self.scaler.current()                       # folds finished found_inf flags in (backoff / growth), as trainer.step does
         if self._hyper() != self._frozen:
             self._capture()
         self.lr.copy_(lr_img)
         self.gt.copy_(gt)
         self.graph.replay()
-        for f in self._flags:                           # one per optimizer step of the iteration, in order
-            self.scaler.read_back(f)
         for o, (dt, dn) in zip(self._opts(), self._delta):
             o.t += dt
             o.n_averaged += dn

@@ -106,7 +106,7 @@ class SideStreamReducer:
     generator's pixel loss and the two VGG-19 forwards, train_bsrgan.py:436-452).  RCCL's ring over xGMI is per-link bound and
     needs no compute units to speak of; the point is to take the exchange off the critical path, not to shorten it.
 
-        ev = reducer.launch(lambda: scaler.step(opt, grad, allreduce_sum_(grad, pg), S))   # enqueued behind the main stream's work
+        ev = reducer.launch(lambda: scaler.step(opt, grad, allreduce_sum_(grad, pg)))   # enqueued behind the main stream's work
         ...                                                                               # main stream: independent work
         reducer.wait()                                                                    # before the first reader of the parameters
 

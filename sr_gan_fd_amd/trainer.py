@@ -30,85 +30,88 @@ class LossScaler:
     ``step(optimizer)``, ``update()`` after EACH optimizer step: train_bsrgan.py:109,420,430,436-437,463,466-467), defaults of
     torch/amp/grad_scaler.py: init_scale 65536, growth x2 after 2000 consecutive finite steps, backoff x0.5 on a non-finite one.
 
-    Differences in mechanics, not in arithmetic: the loss is never materialised scaled -- the factor multiplies the gradient
-    seeds that the loss kernels emit; the unscale is the Adam kernel's ``grad_scale``; found_inf is one reduction over the flat
-    (already all-reduced: every rank sees the same value) gradient; the skip happens on the device (``skip_flag``), so the host
-    never waits for a fresh flag -- it reads it back asynchronously and applies backoff / growth exactly ``LAG`` optimizer steps
-    late.  The lag is a fixed count, not "whatever has arrived": under data parallelism every rank must fold the same flags in
-    before the same backward pass, or for one iteration the ranks would seed their gradients with different scales."""
-    LAG = 2
+    Like torch's, the scale lives in DEVICE memory (``state``: scale, 1 / scale, growth tracker, step and skip counts): the loss
+    kernels multiply their gradient seeds by ``state[0]`` (``seed_ptr``), the Adam kernel unscales with ``state[1]`` and skips on the
+    found_inf flag, and ``srganfd_loss_scale_update`` applies GradScaler.update()'s rule right behind the optimizer step, in stream
+    order.  So the backward pass that follows an overflow already runs at the halved scale -- one skipped step per overflow, as in
+    torch -- the host never waits for a flag, a captured graph never carries a stale scale, and under data parallelism every rank
+    updates its copy from the same flag (found_inf is computed on the all-reduced gradient).  The loss is never materialised scaled.
+    ``tests/test_gan_gpu.py::test_loss_scaler_follows_torch_gradscaler`` replays an overflow / growth sequence through both."""
 
     def __init__(self, device, enabled: bool = True, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
                  growth_interval: int = 2000):
         self.enabled = enabled
-        self.scale = float(init_scale) if enabled else 1.0
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
-        self.good_steps = 0
-        self.n_steps = self.n_skipped = 0
-        self.pending = []           # (event, pinned host flag) of optimizer steps whose found_inf has not been read yet
-        self.captured_flags = []    # flag slots written by a step that was captured into a hipGraph
+        self._host_scale = float(init_scale) if enabled else 1.0       # only for a disabled scaler / before the first report
         if enabled:
-            self.flags = torch.zeros(8, dtype=torch.float32, device=device)      # ring: one slot per optimizer step in flight
-            self.slot = 0
+            self.state = torch.zeros(8, dtype=torch.float32, device=device)
+            self.state[0] = float(init_scale)
+            self.state[1] = 1.0 / float(init_scale)
+            self.flag = torch.zeros(1, dtype=torch.float32, device=device)
+
+    # -- what the kernels read ------------------------------------------------------------------------------------------
+    @property
+    def seed_ptr(self):
+        """device address of the scale: multiplies the gradient seed of a loss kernel (``grad_scale_dev``); None when disabled"""
+        return self.state.data_ptr() if self.enabled else None
+
+    @property
+    def inv_ptr(self):
+        return self.state.data_ptr() + 4 if self.enabled else None
+
+    # -- host views (each one synchronises: reports, tests, checkpoints) ------------------------------------------------
+    @property
+    def scale(self) -> float:
+        return float(self.state[0].item()) if self.enabled else 1.0
+
+    @scale.setter
+    def scale(self, value: float) -> None:
+        if self.enabled:
+            self.state[0] = float(value)
+            self.state[1] = 1.0 / float(value)
 
     def current(self) -> float:
-        """Scale for the backward pass that starts now (finished found_inf flags are folded in first, without blocking)."""
-        if self.enabled:
-            self._drain(self.LAG)
+        """The scale the next backward pass will be seeded with (host copy: synchronises; the training loops do not call it)."""
         return self.scale
 
-    def _drain(self, keep: int) -> None:
-        """Fold in every flag but the newest ``keep`` (blocking on steps that old costs nothing: they finished long ago)."""
-        while len(self.pending) > keep:
-            ev, host = self.pending.pop(0)
-            ev.synchronize()
-            self.n_steps += 1
-            if host.item() != 0.0:
-                self.n_skipped += 1
-                self.scale *= self.backoff_factor
-                self.good_steps = 0
-            else:
-                self.good_steps += 1
-                if self.good_steps >= self.growth_interval:
-                    self.scale *= self.growth_factor
-                    self.good_steps = 0
-
-    def step(self, opt: "FlatAdamEMA", grad: Tensor, grad_scale: float, scale_used: float, update_ema: bool = True) -> None:
-        """GradScaler.step(optimizer) + update(): unscale, found_inf, (skipped) Adam step, flag queued for the scale update."""
+    def step(self, opt: "FlatAdamEMA", grad: Tensor, grad_scale: float, update_ema: bool = True) -> None:
+        """GradScaler.step(optimizer) + update(): found_inf on the (all-reduced) flat gradient, unscale inside the (skipped) Adam
+        step, then the scale update -- all on the device, in stream order."""
         if not self.enabled:
             opt.step(grad, grad_scale, update_ema)
             return
-        if len(self.pending) >= 6:
-            raise RuntimeError("LossScaler: step() without current() -- the scale must be read before every backward pass")
-        flag = self.flags[self.slot:self.slot + 1]
-        self.slot = (self.slot + 1) % 8
-        A.check(A.lib().srganfd_nonfinite_flag(grad.data_ptr(), grad.numel(), flag.data_ptr(), 0, A.stream_ptr()), "nonfinite_flag")
-        opt.step(grad, grad_scale / scale_used, update_ema, skip_flag=flag)
-        if torch.cuda.is_current_stream_capturing():
-            self.captured_flags.append(flag)          # graph.GraphedStep reads these back after every replay (read_back)
-        else:
-            self.read_back(flag)
-
-    def read_back(self, flag: Tensor) -> None:
-        """Queue one optimizer step's found_inf flag for the scale update: asynchronous copy to pinned memory + an event."""
-        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-        host.copy_(flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending.append((ev, host))
+        L, st = A.lib(), A.stream_ptr()
+        A.check(L.srganfd_nonfinite_flag(grad.data_ptr(), grad.numel(), self.flag.data_ptr(), 0, st), "nonfinite_flag")
+        opt.step(grad, grad_scale, update_ema, skip_flag=self.flag, grad_scale_dev=self.inv_ptr)
+        A.check(L.srganfd_loss_scale_update(self.state.data_ptr(), self.flag.data_ptr(), self.growth_factor, self.backoff_factor,
+                                            int(self.growth_interval), st), "loss_scale_update")
 
     def report(self) -> dict:
-        if self.enabled:
-            self._drain(0)
-        return {"enabled": self.enabled, "scale": self.scale, "optimizer_steps": self.n_steps, "skipped": self.n_skipped}
+        if not self.enabled:
+            return {"enabled": False, "scale": 1.0, "optimizer_steps": 0, "skipped": 0}
+        st = self.state.cpu()
+        return {"enabled": True, "scale": float(st[0]), "optimizer_steps": int(st[3]), "skipped": int(st[4])}
+
+    @property
+    def n_steps(self) -> int:
+        return self.report()["optimizer_steps"]
+
+    @property
+    def n_skipped(self) -> int:
+        return self.report()["skipped"]
 
     def state_dict(self) -> dict:
         """torch GradScaler.state_dict() keys (the reference does not checkpoint its scaler; kept for symmetry)."""
-        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
-                "growth_interval": self.growth_interval, "_growth_tracker": self.good_steps}
+        st = self.state.cpu() if self.enabled else None
+        return {"scale": float(st[0]) if st is not None else 1.0, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[2]) if st is not None else 0}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.scale, self.good_steps = float(sd["scale"]), int(sd.get("_growth_tracker", 0))
+        if self.enabled:
+            sc = float(sd["scale"])
+            self.state[0] = sc
+            self.state[1] = 1.0 / sc
+            self.state[2] = float(int(sd.get("_growth_tracker", 0)))
 
 
 class MultiStepLR:
@@ -153,6 +156,14 @@ class MultiStepLR:
 
 def needs_loss_scaling(*modules) -> bool:
     return any(getattr(m, "compute_dtype", None) == torch.float16 for m in modules if m is not None)
+
+
+def check_loss_scaling(scaler: "LossScaler", *modules) -> None:
+    """``compute_dtype`` is a plain attribute of the modules: switched to float16 AFTER the trainer was built, training would run f16
+    with the scaler disabled and the gradients would silently underflow.  Checked at every step (an attribute read per module)."""
+    if not scaler.enabled and needs_loss_scaling(*modules):
+        raise A.SrganfdError("compute_dtype was set to torch.float16 after the trainer was built: its loss scaler is disabled "
+                             "(gradients would underflow) -- set the dtype first, then build the trainer")
 
 
 class FlatAdamEMA:
@@ -246,9 +257,11 @@ class FlatAdamEMA:
                     t.copy_(src)
         self.n_averaged = int(sd.get("n_averaged", 0))
 
-    def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True, skip_flag: Optional[Tensor] = None) -> None:
+    def step(self, grad: Tensor, grad_scale: float = 1.0, update_ema: bool = True, skip_flag: Optional[Tensor] = None,
+             grad_scale_dev: Optional[int] = None) -> None:
         """``skip_flag`` (device float, LossScaler): non-zero skips the update on the device; the step count then has to live on
-        the device too (a skipped step does not advance torch's ``state["step"]``), so the device-step kernel is used."""
+        the device too (a skipped step does not advance torch's ``state["step"]``), so the device-step kernel is used.
+        ``grad_scale_dev``: device address of a float that multiplies ``grad_scale`` (1 / loss scale)."""
         if skip_flag is not None:
             self.use_device_step()
         if self.layout is not None and self.layout.flat is not self.flat:
@@ -264,12 +277,12 @@ class FlatAdamEMA:
                                                  self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                                  self.betas[0], self.betas[1], self.eps, self.wd, self.step_dev.data_ptr(),
                                                  self.bc_dev.data_ptr(), grad_scale, self.ema_decay or 0.0, mode,
-                                                 skip_flag.data_ptr() if skip_flag is not None else None, A.stream_ptr()), "adam_ema_dev")
+                                                 skip_flag.data_ptr() if skip_flag is not None else None, grad_scale_dev, A.stream_ptr()), "adam_ema_dev")
             return
         A.check(A.lib().srganfd_adam_ema(self.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale,
-                                         self.ema_decay or 0.0, mode, None, A.stream_ptr()), "adam_ema")
+                                         self.ema_decay or 0.0, mode, None, grad_scale_dev, A.stream_ptr()), "adam_ema")
 
 
 class GeneratorTrainer:
@@ -319,14 +332,15 @@ class GeneratorTrainer:
         if self.dsr is None or self.dsr.shape != sr.shape:
             self.dsr = torch.empty_like(sr)
         gt = gt.contiguous().float()
-        S = self.scaler.current()                       # scaler.scale(loss): the factor rides on the gradient seed
+        check_loss_scaling(self.scaler, self.g)
+        # scaler.scale(loss): the (device-resident) factor rides on the gradient seed
         A.check(A.lib().srganfd_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), self.loss_weight, self.loss_buf.data_ptr(), 0,
-                                        self.dsr.data_ptr(), self.loss_weight * S, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
+                                        self.dsr.data_ptr(), self.loss_weight, self.scaler.seed_ptr, self.ws.data_ptr(), A.stream_ptr()), "l1_loss")
         # RCCL over xGMI: the flat gradient goes out in three buckets as the backward pass finishes them (parallel.BucketReducer)
         self.g_reducer.begin()
         grad, _ = eng.backward(sp, token, self.dsr, False, on_ready=self.g_reducer.bucket)
         scale = self.g_reducer.finish()
-        self.scaler.step(self.opt, grad, scale, S)     # scaler.step(optimizer); scaler.update(); ema update
+        self.scaler.step(self.opt, grad, scale)        # scaler.step(optimizer); scaler.update(); ema update
         eng.fp.touch()                             # parameters changed behind autograd's back -> re-pack
         self.sr = sr
         return self.loss_buf

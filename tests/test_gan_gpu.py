@@ -87,7 +87,7 @@ def test_losses_match_torch():
     ref.backward()
     out, ws = torch.zeros(2, device="cuda"), torch.empty(A.LOSS_WS_FLOATS, device="cuda")
     ag, grad = a.cuda(), torch.empty(2, 3, 40, 40, device="cuda")
-    A.check(L.srganfd_l1_loss(ag.data_ptr(), b.cuda().data_ptr(), a.numel(), 20.0, out.data_ptr(), 0, grad.data_ptr(), 20.0, ws.data_ptr(), st))
+    A.check(L.srganfd_l1_loss(ag.data_ptr(), b.cuda().data_ptr(), a.numel(), 20.0, out.data_ptr(), 0, grad.data_ptr(), 20.0, None, ws.data_ptr(), st))
     torch.cuda.synchronize()
     assert abs(out[0].item() - ref.item()) < 1e-5 * abs(ref.item()) and _rel(grad, ar.grad) < 1e-6
     x = torch.randn(2, 1, 40, 40) * 3
@@ -96,7 +96,7 @@ def test_losses_match_torch():
         ref = 0.5 * F.binary_cross_entropy_with_logits(xr, torch.full_like(x, target))
         ref.backward()
         xg, g2 = x.cuda(), torch.empty_like(x, device="cuda")
-        A.check(L.srganfd_bce_logits(xg.data_ptr(), x.numel(), target, 0.5, out.data_ptr(), 0, out.data_ptr() + 4, g2.data_ptr(), 0.5, ws.data_ptr(), st))
+        A.check(L.srganfd_bce_logits(xg.data_ptr(), x.numel(), target, 0.5, out.data_ptr(), 0, out.data_ptr() + 4, g2.data_ptr(), 0.5, None, ws.data_ptr(), st))
         torch.cuda.synchronize()
         assert abs(out[0].item() - ref.item()) < 1e-5 * abs(ref.item())
         assert abs(out[1].item() - torch.sigmoid(x).mean().item()) < 1e-6
@@ -302,8 +302,7 @@ def test_loss_scaler_skips_nonfinite_step():
     sc = LossScaler(p.device, enabled=True, init_scale=1024.0)
     g = torch.randn(1000, device="cuda")
     p0 = p.clone()
-    S = sc.current()
-    sc.step(opt, g * S, 1.0, S)                       # finite: an ordinary Adam step on g
+    sc.step(opt, g * 1024.0, 1.0)                     # finite: an ordinary Adam step on g (the kernel unscales with the device's 1 / scale)
     ref = torch.nn.Parameter(p0.clone())
     o = torch.optim.Adam([ref], 1e-2, (0.9, 0.999), 1e-8)
     ref.grad = g.clone()
@@ -312,8 +311,7 @@ def test_loss_scaler_skips_nonfinite_step():
     p1, m1, ema1 = p.clone(), opt.m.clone(), opt.ema.clone()
     bad = g.clone()
     bad[123] = float("inf")
-    S = sc.current()
-    sc.step(opt, bad, 1.0, S)                         # non-finite: skipped on the device
+    sc.step(opt, bad, 1.0)                            # non-finite: skipped on the device
     torch.cuda.synchronize()
     assert torch.equal(p, p1) and torch.equal(opt.m, m1) and int(opt.step_dev.item()) == 1
     assert torch.allclose(opt.ema, 0.001 * ema1 + 0.999 * p1)
@@ -321,17 +319,66 @@ def test_loss_scaler_skips_nonfinite_step():
     assert rep == {"enabled": True, "scale": 512.0, "optimizer_steps": 2, "skipped": 1}, rep
     nan = g.clone()
     nan[7] = float("nan")
-    sc.step(opt, nan, 1.0, sc.current())
+    sc.step(opt, nan, 1.0)
     assert sc.report()["scale"] == 256.0 and torch.equal(p, p1)
-    # the scale moves a FIXED number of optimizer steps after the overflow (every data-parallel rank folds the same flags in before
-    # the same backward pass), not whenever the asynchronous read-back happens to have landed
-    sc = LossScaler(p.device, enabled=True, init_scale=1024.0)
-    sc.step(opt, bad, 1.0, sc.current())
-    torch.cuda.synchronize()                          # the flag has certainly arrived ...
-    for k in range(LossScaler.LAG):
-        assert sc.current() == 1024.0                 # ... and is still not applied
-        sc.step(opt, g * 1024.0, 1.0, 1024.0)
-    assert sc.current() == 512.0
+    # the very next step already runs at the backed-off scale (no lag): a gradient scaled by 256 is unscaled by 1 / 256
+    sc.step(opt, g * 256.0, 1.0)
+    ref.grad = g.clone()
+    o.step()
+    assert torch.allclose(p, ref.data, rtol=1e-5, atol=1e-7)
+
+
+def test_loss_scaler_follows_torch_gradscaler():
+    """A forced-overflow / growth sequence through torch.amp.GradScaler (the reference's object, train_bsrgan.py:109,436-437,466-467)
+    and through LossScaler: the same steps are skipped and the scale is the same after EVERY update -- overflows at steps 3, 4 and 9
+    (two in a row: two backoffs, one skipped step each), growth after every 5 clean steps (growth_interval shortened from 2000),
+    and a growth right after a backoff's tracker reset."""
+    from sr_gan_fd_amd.trainer import FlatAdamEMA, LossScaler
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    kw = dict(init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=5)
+    ts = torch.amp.GradScaler("cuda", **kw)
+    ts.scale(torch.ones(1, device=dev))          # torch creates its device-side scale lazily, at the first scale(loss)
+    tp = torch.nn.Parameter(torch.randn(256, device=dev))
+    topt = torch.optim.Adam([tp], 1e-2, (0.9, 0.999), 1e-8)
+    p = tp.detach().clone()
+    opt = FlatAdamEMA(p, 1e-2, (0.9, 0.999), 1e-8, 0.0, ema_decay=None)
+    sc = LossScaler(dev, enabled=True, **kw)
+    bad_steps = {3, 4, 9, 27}
+    skipped_t, skipped_s = [], []
+    for k in range(40):
+        g = torch.randn(256, device=dev)
+        S_t, S_s = ts.get_scale(), sc.scale
+        assert S_t == S_s, (k, S_t, S_s)                       # the scale the backward pass of step k is seeded with
+        gt_, gs_ = g * S_t, g * S_s
+        if k in bad_steps:
+            gt_[5] = float("inf"); gs_[5] = float("inf")
+        before_t, before_s = tp.detach().clone(), p.clone()
+        tp.grad = gt_
+        ts.step(topt)                                          # unscale_ + found_inf + (skipped) step
+        ts.update()
+        sc.step(opt, gs_, 1.0, update_ema=False)
+        torch.cuda.synchronize()
+        skipped_t.append(bool(torch.equal(tp.detach(), before_t)))
+        skipped_s.append(bool(torch.equal(p, before_s)))
+        assert torch.allclose(p, tp.detach(), rtol=1e-5, atol=1e-7), k
+    assert skipped_t == skipped_s and [k for k, v in enumerate(skipped_s) if v] == sorted(bad_steps)
+    assert ts.get_scale() == sc.scale
+    rep = sc.report()
+    assert rep["optimizer_steps"] == 40 and rep["skipped"] == len(bad_steps)
+    assert sc.state_dict()["_growth_tracker"] == ts.state_dict()["_growth_tracker"]
+
+
+def test_trainer_refuses_f16_set_after_construction():
+    """compute_dtype is a plain attribute: flipped to float16 after the trainer was built, the disabled scaler would let the gradients
+    underflow silently -- the step raises instead"""
+    from sr_gan_fd_amd import _abi as A
+    from sr_gan_fd_amd.gan import GanTrainer
+    gen, d = _build_gan(torch.float32)
+    tr = GanTrainer(gen, d, None)
+    gen.compute_dtype = d.compute_dtype = torch.float16
+    with pytest.raises(A.SrganfdError, match="loss scaler is disabled"):
+        tr.step(torch.rand(2, 3, 16, 16).cuda(), torch.rand(2, 3, 64, 64).cuda())
 
 
 def test_gan_step_bf16_runs_close():
