@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--workload", default="both", choices=["both", "g_only", "gan", "aesrgan_gan", "esrgan_gan", "realesrgan_gan"],
                     help="both (default) = configs[1] generator-only as the headline + configs[2] full GAN step under \"gan\"")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--esrgan-module-loop", action="store_true", help="esrgan_gan: run the script's own autograd loop over the drop-in modules instead of the fused trainer")
     ap.add_argument("--lr-size", type=int, default=0, help="LR image side (default 128; 192 for aesrgan_gan)")
     ap.add_argument("--num-rrdb", type=int, default=23)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
@@ -223,7 +224,19 @@ def run_workload(args, workload, rank, world, dev, pg):
     if workload == "esrgan_gan":
         if world > 1 or h != 32:
             raise SystemExit("esrgan_gan: single GPU, 32 -> 128 only (the discriminator's classifier fixes the 128x128 input, ESRGAN/model.py:118-122)")
-        step_fn = esrgan_loop(M, g, dev, cdt)
+        if args.esrgan_module_loop:
+            step_fn = esrgan_loop(M, g, dev, cdt)     # round-1/2 form: the script's own autograd loop over the drop-in modules
+        else:
+            # the fused trainer (gan_esrgan.py): every loss, seed and optimizer step a HIP kernel; esrgan_config.py:75-111 hyper-parameters
+            from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+            d = M.discriminator()
+            cl = M.ContentLoss("features.34", MEAN, STD)          # a str node selects ESRGAN's differentiable single-tap loss
+            d.compute_dtype = cl.compute_dtype = cdt
+            d.to(dev).train()
+            cl.to(dev)
+            g.train()
+            trainer = EsrganGanTrainer(g, d, cl)
+            step_fn = trainer.step
     elif workload == "g_only":
         # BSRGAN/bsrnet_config.py:86-96 hyper-parameters
         trainer = GeneratorTrainer(g, lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999, process_group=pg)
@@ -300,7 +313,7 @@ def run_workload(args, workload, rank, world, dev, pg):
                                 "aesrgan_gan": "A-ESRGAN full GAN step (RRDBNet %d RRDB + attention U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "realesrgan_gan": "Real-ESRGAN iteration: on-device second-order degradation of the GT batch + generator-first GAN step "
                                                   "(RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
-                                "esrgan_gan": "ESRGAN relativistic GAN step, the script's own loop over the drop-in modules (RRDBNet %d RRDB + BatchNorm D "
+                                "esrgan_gan": "ESRGAN relativistic GAN step, fused trainer (RRDBNet %d RRDB + BatchNorm D "
                                               "+ differentiable VGG19 content), batch %d/GPU, %d->%d",
                                 }[workload] % (args.num_rrdb, B, h, 4 * h),
                    "global_batch": B * world, "num_rrdb": args.num_rrdb, "parallelism": "dp%d" % world,

@@ -234,6 +234,14 @@ int srganfd_l1_loss_views(srganfd_view a, srganfd_view b, int32_t dtype, int64_t
 int srganfd_bce_logits(const float* logits, int64_t numel, float target, float weight, float* loss_out,
                        int32_t accumulate, float* sigmoid_mean_out /* or NULL */, float* grad /* or NULL */,
                        float grad_scale, const float* grad_scale_dev /* or NULL */, float* workspace, void* stream);
+/* Relativistic-average BCE of ESRGAN (train_esrgan.py:378-380,404,412): *loss_out (+)= weight * mean_i BCEWithLogits(x_i - mean(other), target).
+ * grad_x[i] (+)= g * (sigmoid(x_i - mean(other)) - target) / numel, grad_other[j] (+)= -g * mean_i(sigmoid(x_i - mean(other)) - target) / numel_other
+ * with g = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1); either gradient may be NULL; accumulate_* != 0 adds to what the buffer holds
+ * (the generator's adversarial term reaches sr_output through both of its halves).  Deterministic two-stage reductions. */
+int srganfd_bce_logits_relativistic(const float* x, int64_t numel, const float* other, int64_t numel_other, float target, float weight,
+                                    float* loss_out, int32_t accumulate, float* grad_x /* or NULL */, int32_t accumulate_x,
+                                    float* grad_other /* or NULL */, int32_t accumulate_other, float grad_scale,
+                                    const float* grad_scale_dev /* or NULL */, float* workspace, void* stream);
 /* *out = sigmoid(mean(logits)): the D(x) probability as ESRGAN / Real-ESRGAN log it (train_esrgan.py:430-431,
  * train_realesrgan.py:475-476; BSRGAN logs mean(sigmoid), srganfd_bce_logits' sigmoid_mean_out). */
 int srganfd_sigmoid_of_mean(const float* logits, int64_t numel, float* out, float* workspace, void* stream);

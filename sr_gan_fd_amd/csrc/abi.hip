@@ -45,6 +45,9 @@ int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStr
 int l1_views_impl(srganfd_view a, srganfd_view b, int dtype, size_t npix, int c, int relu, float weight, float* out, int accumulate, float* ws, hipStream_t s);
 int bce_logits_impl(const float* x, size_t n, float target, float weight, float* loss_out, int accumulate, float* sig_mean_out, float* grad,
                     float grad_scale, const float* grad_scale_dev, float* ws, hipStream_t s);
+int bce_logits_relativistic_impl(const float* x, size_t n, const float* other, size_t n_other, float target, float weight, float* loss_out, int accumulate,
+                                 float* grad_x, int accumulate_x, float* grad_other, int accumulate_other, float grad_scale,
+                                 const float* grad_scale_dev, float* ws, hipStream_t s);
 int spectral_norm_grad_batch_impl(const srganfd_sn_grad_job* jobs, int njobs, float beta, hipStream_t s);
 int spectral_norm_batch_impl(const srganfd_sn_job* jobs, int njobs, int training, float eps, hipStream_t s);
 int spectral_norm_impl(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma, float* inv_sigma, float* ws, hipStream_t s);
@@ -190,6 +193,13 @@ int srganfd_bce_logits(const float* logits, int64_t numel, float target, float w
                        float* sigmoid_mean_out, float* grad, float grad_scale, const float* grad_scale_dev, float* workspace, void* stream) {
   return bce_logits_impl(logits, (size_t)numel, target, weight, loss_out, accumulate, sigmoid_mean_out, grad, grad_scale, grad_scale_dev, workspace,
                          (hipStream_t)stream);
+}
+int srganfd_bce_logits_relativistic(const float* x, int64_t numel, const float* other, int64_t numel_other, float target, float weight,
+                                    float* loss_out, int32_t accumulate, float* grad_x, int32_t accumulate_x, float* grad_other,
+                                    int32_t accumulate_other, float grad_scale, const float* grad_scale_dev, float* workspace, void* stream) {
+  return bce_logits_relativistic_impl(x, numel > 0 ? (size_t)numel : 0, other, numel_other > 0 ? (size_t)numel_other : 0, target, weight, loss_out,
+                                      accumulate, grad_x, accumulate_x, grad_other, accumulate_other, grad_scale, grad_scale_dev, workspace,
+                                      (hipStream_t)stream);
 }
 int srganfd_spectral_norm(const float* w_orig, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma_out,
                           float* inv_sigma_out, float* workspace, void* stream) {

@@ -627,6 +627,50 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restric
   const float r = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
+// ---- relativistic-average BCE (ESRGAN/train_esrgan.py:378-380,404,412): mean_i BCE(x_i - mean(other), target) ----
+// stage 0: mean(other) -> ws[2 * kRedBlocks] (sum_partial_kernel + this finish); stage 1: per-element loss, d/dx_i, partial sums of the loss
+// and of (sigmoid - target); stage 2: finishes -- loss, and d/d(other_j) = -(1/n_other) * mean_i(sigmoid_i - target), the same for every j.
+__global__ __launch_bounds__(256) void finish_mean_kernel(const float* __restrict__ partial, int nblk, float inv_n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) *out = r * inv_n;
+}
+__global__ __launch_bounds__(256) void bce_rel_partial_kernel(const float* __restrict__ x, size_t n, const float* __restrict__ other_mean, float target,
+                                                              float gscale, const float* __restrict__ gscale_dev, float* __restrict__ grad_x,
+                                                              int accumulate_x, float* __restrict__ partial, float* __restrict__ partial_d) {
+  __shared__ float sh[4];
+  float s = 0.f, sd = 0.f;
+  const float m = *other_mean;
+  if (gscale_dev) gscale *= *gscale_dev;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = x[i] - m;
+    s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    const float d = 1.f / (1.f + expf(-v)) - target;
+    sd += d;
+    if (grad_x) grad_x[i] = (accumulate_x ? grad_x[i] : 0.f) + d * gscale;
+  }
+  float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  r = block_reduce_sum(sd, sh);
+  if (threadIdx.x == 0) partial_d[blockIdx.x] = r;
+}
+// grad_other[j] (+)= -gscale * sum_d / n_other for every j (gscale already carries weight / n_x)
+__global__ __launch_bounds__(256) void bce_rel_other_kernel(const float* __restrict__ partial_d, int nblk, float gscale, const float* __restrict__ gscale_dev,
+                                                            float* __restrict__ grad_other, size_t n_other, int accumulate) {
+  __shared__ float sh[4];
+  __shared__ float tot;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial_d[i];      // every block re-reduces the (<= 1024) partials: same order, same value
+  const float r = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) tot = r;
+  __syncthreads();
+  if (gscale_dev) gscale *= *gscale_dev;
+  const float g = -gscale * tot / (float)n_other;
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n_other; j += (size_t)gridDim.x * 256)
+    grad_other[j] = (accumulate ? grad_other[j] : 0.f) + g;
+}
 __global__ __launch_bounds__(256) void finish_sigmoid_mean_kernel(const float* __restrict__ partial, int nblk, float inv_n, float* out) {
   __shared__ float sh[4];
   float s = 0.f;
@@ -1522,6 +1566,24 @@ int sigmoid_of_mean_impl(const float* x, size_t n, float* out, float* ws, hipStr
   const unsigned g = grid_for(n, 256, kRedBlocks);
   SRGANFD_LAUNCH(sum_partial_kernel, dim3(g), dim3(256), 0, s, x, n, ws);
   SRGANFD_LAUNCH(finish_sigmoid_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, 1.f / (float)n, out);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+// workspace: 2 * kRedBlocks + 1 floats (SRGANFD_LOSS_WS_FLOATS)
+int bce_logits_relativistic_impl(const float* x, size_t n, const float* other, size_t n_other, float target, float weight, float* loss_out, int accumulate,
+                                 float* grad_x, int accumulate_x, float* grad_other, int accumulate_other, float grad_scale,
+                                 const float* grad_scale_dev, float* ws, hipStream_t s) {
+  if (!x || !other || !loss_out || !ws || n == 0 || n_other == 0) return set_err(SRGANFD_EINVAL, "bce_relativistic: bad args");
+  float* mean = ws + 2 * kRedBlocks;
+  const unsigned go = grid_for(n_other, 256, kRedBlocks), g = grid_for(n, 256, kRedBlocks);
+  SRGANFD_LAUNCH(sum_partial_kernel, dim3(go), dim3(256), 0, s, other, n_other, ws);
+  SRGANFD_LAUNCH(finish_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)go, 1.f / (float)n_other, mean);
+  SRGANFD_LAUNCH(bce_rel_partial_kernel, dim3(g), dim3(256), 0, s, x, n, (const float*)mean, target, grad_scale / (float)n, grad_scale_dev, grad_x,
+                 accumulate_x, ws, ws + kRedBlocks);
+  SRGANFD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)g, weight / (float)n, loss_out, accumulate);
+  if (grad_other)
+    SRGANFD_LAUNCH(bce_rel_other_kernel, dim3(grid_for(n_other, 256, 256)), dim3(256), 0, s, (const float*)(ws + kRedBlocks), (int)g, grad_scale / (float)n,
+                   grad_scale_dev, grad_other, n_other, accumulate_other);
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }

@@ -10,7 +10,7 @@ final relayout that undoes the normalisation's 1/std.  No weight gradients (the 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 from torch import Tensor, nn
@@ -150,15 +150,19 @@ class ContentLossGradEngine:
         self._last = sp
         return loss.view(())
 
-    def backward(self, sp, token, dloss: Tensor) -> Tensor:
+    def backward(self, sp, token, dloss: Optional[Tensor], weight: float = 1.0, upstream_ptr: Optional[int] = None) -> Tensor:
+        """d(weight * loss)/d(sr) times the upstream scalar: ``dloss`` (autograd's 1-element tensor) or, for the fused trainers,
+        ``upstream_ptr`` -- the address of a device float such as the loss scale -- or nothing (1)."""
         if getattr(sp, "token", None) != token:
             raise A.SrganfdError("VGG activations were overwritten by a later ContentLoss forward before backward ran")
         L, st = A.lib(), A.stream_ptr()
         N, dtc = sp.N, sp.dtc
         h, w, c = sp.feat_dims
-        dloss = dloss.detach().contiguous().float()
-        A.check(L.srganfd_l1_grad_views(sp.loss_views[0], sp.loss_views[1], A.view(sp.g_tap), dtc, N * h * w, c, dloss.data_ptr(),
-                                        1.0 / float(N * h * w * c), st), "l1_grad_views")
+        if dloss is not None:
+            dloss = dloss.detach().contiguous().float()
+            upstream_ptr = dloss.data_ptr()
+        A.check(L.srganfd_l1_grad_views(sp.loss_views[0], sp.loss_views[1], A.view(sp.g_tap), dtc, N * h * w, c, upstream_ptr,
+                                        weight / float(N * h * w * c), st), "l1_grad_views")
         rec = profiling.REC
         for kind, item in sp.bw:
             if kind == "conv":

@@ -297,8 +297,9 @@ def bsrgan_x4(**kwargs: Any) -> BSRGAN:
     return BSRGAN(upscale_factor=4, **kwargs)
 
 
-def content_loss(**kwargs: Any) -> ContentLoss:
-    return ContentLoss(**kwargs)
+def content_loss(*args: Any, **kwargs: Any) -> ContentLoss:
+    """BSRGAN/model.py:568-571 (keyword form) and ESRGAN/model.py:325-332, which passes (node, mean, std) positionally"""
+    return ContentLoss(*args, **kwargs)
 
 
 def rrdbnet_x1(**kwargs: Any) -> RRDBNet:

@@ -235,3 +235,123 @@ def test_esrgan_relativistic_iterations_on_dropin_modules(golden_dir):
         assert np.allclose(got, want, rtol=1e-3 if it == 0 else 2e-2, atol=1e-5)
         assert _rel(sr[:, :, ::4, ::4], g[f"it{it}_sr"]) < (1e-3 if it == 0 else 2e-2)
     assert int(d.features[3].num_batches_tracked) == 10          # five training forwards per iteration
+
+
+def _esrgan_pair(dtype):
+    from sr_gan_fd_amd import model as M
+    from tests.util import scaled_init
+    torch.manual_seed(0)
+    d = M.discriminator()
+    gen = M.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_blocks=2)
+    scaled_init(gen, 3.0, 0.5)
+    d.compute_dtype = gen.compute_dtype = dtype
+    return gen.cuda().train(), d.cuda().train()
+
+
+def test_esrgan_fused_relativistic_trainer_vs_reference(golden_dir):
+    """EsrganGanTrainer.step == two iterations of ESRGAN/train_esrgan.py:340-431 run on the reference's own modules (esrgan_gan_steps.npz:
+    generator first, relativistic-average losses, five BatchNorm-advancing discriminator forwards, Adam, EMA; content loss stubbed to 0):
+    logged scalars, SR, every parameter's checksum after both optimizer steps.  Iteration 1 starts from parameters that took sign-like
+    Adam steps (eps 1e-8), hence its looser bound -- the same the module-level loop above and the CPU oracle meet."""
+    from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+    from tests.util import checksum, table
+    g = load_golden(golden_dir, "esrgan_gan_steps.npz")
+    gen, d = _esrgan_pair(torch.float32)
+    tr = EsrganGanTrainer(gen, d, None)
+    for it in range(2):
+        s = tr.step(torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()).cpu().numpy()
+        want = g[f"it{it}_scalars"]                     # d_loss, pixel, adversarial, sigmoid(mean D(gt)), sigmoid(mean D(sr))
+        got = [s[0], s[1], s[3], s[4], s[5]]
+        print(f"ESRGAN fused it{it}: got {got} want {list(want)}")
+        tol = 1e-3 if it == 0 else 2e-2
+        assert np.allclose(got, want, rtol=tol, atol=1e-5)
+        assert _rel(tr.sr[:, :, ::4, ::4], g[f"it{it}_sr"]) < tol
+        if it == 0:
+            for sd, key in ((gen.state_dict(), "it0_wsum_g"), (d.state_dict(), "it0_wsum_d")):
+                for k, want_c in table(g, key).items():
+                    if "num_batches_tracked" in k:
+                        assert int(sd[k]) == int(want_c[0]), k
+                    else:
+                        # Adam with eps 1e-8 moves every element by ~lr * sign(g) = 1e-4: an element whose gradient is within rounding of
+                        # zero lands on the other side (2e-4 in a checksum).  Bound: 5e-3 of the tensor's absolute sum, or four such flips
+                        # (the 32- / 64-element biases start at zero, so their whole content is this step)
+                        assert np.allclose(checksum(sd[k]), want_c, rtol=5e-3, atol=max(5e-3 * abs(want_c[1]), 8e-4)), f"{key} {k}"
+    assert int(d.features[3].num_batches_tracked) == 10          # five training forwards per iteration
+
+
+def test_esrgan_fused_trainer_matches_module_level_loop_with_content_loss():
+    """With the differentiable single-node VGG content loss switched on (seeded random extractor: the ImageNet weights are not in the
+    reference tree), the fused trainer and the script's own autograd loop over the drop-in modules take the same two steps."""
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+    MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    data = []
+    torch.manual_seed(7)
+    for _ in range(2):
+        data.append((torch.rand(2, 3, 32, 32).cuda(), torch.rand(2, 3, 128, 128).cuda()))
+    # fused
+    gen, d = _esrgan_pair(torch.float32)
+    torch.manual_seed(1)
+    cl = M.content_loss("features.34", MEAN, STD)
+    cl.compute_dtype = torch.float32
+    cl.cuda()
+    tr = EsrganGanTrainer(gen, d, cl, ema_decay=None)
+    fused = [tr.step(lr, gt).cpu().numpy().copy() for lr, gt in data]
+    # the script's loop on the modules (torch.optim.Adam, autograd)
+    gen2, d2 = _esrgan_pair(torch.float32)
+    torch.manual_seed(1)
+    cl2 = M.content_loss("features.34", MEAN, STD)
+    cl2.compute_dtype = torch.float32
+    cl2.cuda()
+    d_opt = torch.optim.Adam(d2.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    g_opt = torch.optim.Adam(gen2.parameters(), 1e-4, (0.9, 0.99), 1e-8, 0.0)
+    bce, l1 = torch.nn.BCEWithLogitsLoss(), torch.nn.L1Loss()
+    for it, (lr, gt) in enumerate(data):
+        B = gt.shape[0]
+        real, fake = torch.full([B, 1], 1.0, device="cuda"), torch.full([B, 1], 0.0, device="cuda")
+        for p in d2.parameters():
+            p.requires_grad = False
+        gen2.zero_grad(set_to_none=True)
+        sr = gen2(lr)
+        gt_output = d2(gt.detach().clone())
+        sr_output = d2(sr)
+        pixel, content = 0.01 * l1(sr, gt), 1.0 * cl2(sr, gt)
+        adv = 0.005 * (bce(gt_output - torch.mean(sr_output), fake) * 0.5 + bce(sr_output - torch.mean(gt_output), real) * 0.5)
+        (pixel + content + adv).backward()
+        g_opt.step()
+        for p in d2.parameters():
+            p.requires_grad = True
+        d2.zero_grad(set_to_none=True)
+        gt_output = d2(gt)
+        sr_output = d2(sr.detach().clone())
+        d_loss_gt = bce(gt_output - torch.mean(sr_output), real) * 0.5
+        d_loss_gt.backward(retain_graph=True)
+        sr_output = d2(sr.detach().clone())
+        d_loss_sr = bce(sr_output - torch.mean(gt_output), fake) * 0.5
+        d_loss_sr.backward()
+        d_opt.step()
+        want = [(d_loss_gt + d_loss_sr).item(), pixel.item(), content.item(), adv.item(), torch.sigmoid(torch.mean(gt_output.detach())).item(),
+                torch.sigmoid(torch.mean(sr_output.detach())).item()]
+        print(f"it{it}: fused {list(fused[it][:6])} loop {want}")
+        assert np.allclose(fused[it][:6], want, rtol=1e-3 if it == 0 else 2e-2, atol=1e-5)
+    assert _rel(gen.conv1.weight, gen2.conv1.weight) < 2e-2 and _rel(d.classifier[2].weight, d2.classifier[2].weight) < 2e-2
+
+
+def test_esrgan_fused_trainer_f16_stays_close_to_f32():
+    """The benchmark dtype: f16 activations / loss-scaled gradients against the f32 run of the same two iterations -- scalars within 5e-3
+    relative (BatchNorm statistics over 2 images at 128x128 amplify one f16 rounding of the logits), no skipped optimizer step."""
+    from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+    torch.manual_seed(11)
+    data = [(torch.rand(2, 3, 32, 32).cuda(), torch.rand(2, 3, 128, 128).cuda()) for _ in range(2)]
+    outs = {}
+    for dt in (torch.float32, torch.float16):
+        gen, d = _esrgan_pair(dt)
+        tr = EsrganGanTrainer(gen, d, None)
+        outs[dt] = np.stack([tr.step(lr, gt).cpu().numpy()[:6].copy() for lr, gt in data])
+        if dt == torch.float16:
+            rep = tr.scaler.report()
+            assert rep["enabled"] and rep["optimizer_steps"] == 4 and rep["skipped"] == 0, rep
+    a, b = outs[torch.float32][0], outs[torch.float16][0]
+    err = np.abs(a - b) / np.maximum(np.abs(a), 1e-6)
+    print("f32", a, "f16", b, "rel", err)
+    assert err[[0, 1, 3, 4, 5]].max() < 5e-3
