@@ -412,9 +412,26 @@ def sr_parity(h: int, num_rrdb: int, dev, dtype_name: str = "f16"):
             "within_tolerance": bool(err <= 1e-3)}
 
 
+CPU_WARMUP, CPU_TIMED = 3, 5      # "3 warm-up + >= 5 timed iterations, median"
+
+
+def _cpu_timed(step, what: str):
+    """BASELINE.md 4's protocol: CPU_WARMUP untimed + CPU_TIMED timed iterations of ``step``; returns (median seconds, sample text)."""
+    import statistics
+    times = []
+    for it in range(CPU_WARMUP + CPU_TIMED):
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        log("cpu baseline iteration %d%s: %.1f s" % (it, " (warm-up)" if it < CPU_WARMUP else "", dt))
+        if it >= CPU_WARMUP:
+            times.append(dt)
+    return statistics.median(times), "%s, fp32, %d warm-up + %d timed iterations (median)" % (what, CPU_WARMUP, CPU_TIMED)
+
+
 def cpu_baseline(workload: str, h: int, num_rrdb: int):
-    """The CPU oracle's training iteration (oracle/srgan_oracle.py, torch-CPU fp32) on a bounded sample:
-    batch 1 of the same 128->512 workload, 1 warm-up + 8 timed iterations (about 10 s of CPU work)."""
+    """The CPU oracle's training iteration (oracle/srgan_oracle.py, torch-CPU fp32) on a bounded sample -- batch 1 of the same workload --
+    timed by BASELINE.md 4's protocol (3 warm-up + 5 timed iterations, median)."""
     import torch
     from oracle import srgan_oracle as O
     from sr_gan_fd_amd import model as M
@@ -426,7 +443,6 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
     G = {k: v.detach().clone() for k, v in g.state_dict().items()}
     opt = O.AdamState(G, O.g_param_names(G))
     lr_img, gt = torch.rand(1, 3, h, h), torch.rand(1, 3, 4 * h, 4 * h)
-    n_it = 9
     d_forward, hp = None, dict(g_lr=8e-5, d_lr=2e-4, pixel_weight=20.0, adversarial_weight=0.5)
     if workload == "realesrgan_gan":
         import random as _random
@@ -442,33 +458,24 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
         gt = torch.rand(1, 3, 4 * h, 4 * h)
         k21 = torch.rand(1, 21, 21) ** 4
         k21 = k21 / k21.sum()
-        times, n_it = [], 5
-        for it in range(n_it):
-            t0 = time.perf_counter()
+        def one():
             gt_usm, gt_, lr_ = DO.degradation_process(gt, k21, k21, k21, 4, REALESRGAN_DEGRADATION, usm=(DO.usm_kernel(), 0.5, 10))
             O.realesrgan_gan_step(G, D, opt, d_opt, lr_, gt_, gt_usm, content_fn=lambda sr, gt__: O.content_loss(sr, gt__, VP, NODES, MEAN, STD))
-            times.append(time.perf_counter() - t0)
-            log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
-        return {"value": round(1.0 / min(times[1:]), 4), "unit": "img/s", "cores": cores, "kind": "port",
-                "sample": "batch 1, degradation + GAN step, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (h, 4 * h, n_it - 1)}
+        t, sample = _cpu_timed(one, "batch 1, degradation + GAN step, %d->%d" % (h, 4 * h))
+        return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port", "sample": sample}
     if workload == "esrgan_gan":
-        n_it, bsz = 4, 4
+        bsz = 4
         lr_img, gt = torch.rand(bsz, 3, h, h), torch.rand(bsz, 3, 4 * h, 4 * h)
         d = M.discriminator()
         D = {k: v.detach().clone() for k, v in d.state_dict().items()}
         d_opt = O.AdamState(D, [k for k in D if k.endswith((".weight", ".bias"))])
         cl = M.ContentLoss("features.34", MEAN, STD)
         VP = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
-        times = []
-        for it in range(n_it):
-            t0 = time.perf_counter()
-            O.esrgan_gan_step(G, D, opt, d_opt, lr_img, gt, content_fn=lambda sr, gt_: O.content_loss_single(sr, gt_, VP, "features.34", MEAN, STD))
-            times.append(time.perf_counter() - t0)
-            log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
-        return {"value": round(bsz / min(times[1:]), 4), "unit": "img/s", "cores": cores, "kind": "port",
-                "sample": "batch %d, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (bsz, h, 4 * h, n_it - 1)}
+        t, sample = _cpu_timed(lambda: O.esrgan_gan_step(G, D, opt, d_opt, lr_img, gt,
+                                                         content_fn=lambda sr, gt_: O.content_loss_single(sr, gt_, VP, "features.34", MEAN, STD)),
+                               "batch %d, %d->%d" % (bsz, h, 4 * h))
+        return {"value": round(bsz / t, 4), "unit": "img/s", "cores": cores, "kind": "port", "sample": sample}
     if workload != "g_only":
-        n_it = 4 if workload == "gan" else 3
         if workload == "aesrgan_gan":
             d_forward, hp = O.aesrgan_unet_forward, dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1)
         d = M.uNetDiscriminatorAesrgan() if workload == "aesrgan_gan" else M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
@@ -477,19 +484,14 @@ def cpu_baseline(workload: str, h: int, num_rrdb: int):
         cl = M.ContentLoss(NODES, MEAN, STD)
         VP = {"features." + k: v.detach().clone() for k, v in cl.features.state_dict().items()}
         content_fn = lambda sr, gt_: O.content_loss(sr, gt_, VP, NODES, MEAN, STD)
-    times = []
-    for it in range(n_it):
-        t0 = time.perf_counter()
+    def one():
         if workload == "g_only":
             O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
         else:
             O.gan_step(G, D, opt, d_opt, lr_img, gt, upscale=4, betas=(0.9, 0.999), eps=1e-4, content_weight=1.0,
                        content_fn=content_fn, d_forward=d_forward, **hp)
-        times.append(time.perf_counter() - t0)
-        log("cpu baseline iteration %d: %.1f s" % (it, times[-1]))
-    t = min(times[1:])
-    return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "batch 1, %d->%d, fp32, 1 warm-up + %d timed iterations (min)" % (h, 4 * h, n_it - 1)}
+    t, sample = _cpu_timed(one, "batch 1, %d->%d" % (h, 4 * h))
+    return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": cores, "kind": "port", "sample": sample}
 
 
 if __name__ == "__main__":
