@@ -62,7 +62,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 // TS = tap split: the weight slab of a 32-channel chunk is staged in TS pieces of KS/TS kernel rows (the 4x4 stride-2 kernel: 64 KiB of
 // weights per chunk next to a 42 KiB patch would leave room for ONE workgroup per CU; in halves two fit)
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, int TS = 1>
+// DB = the chunk stage (patch + weight slab) is double-buffered in LDS (see the kernel)
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, int TS = 1, bool DB = false>
 struct ConvCfg {
   static constexpr int NWAVES = WR * WN, NTHR = 64 * NWAVES;
   static constexpr int KT = KS * KS;
@@ -86,7 +87,8 @@ struct ConvCfg {
   static constexpr int STAGE_BYTES = XBYTES + WN * WS_BYTES;
   static constexpr int NB = 32 * WN;                           // output channels per workgroup
   static constexpr int EPI_BYTES = TH * TW * NB * 4;           // fp32 tile for the vectorised epilogue
-  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int STAGES_BYTES = (DB ? 2 : 1) * STAGE_BYTES;
+  static constexpr int LDS_BYTES = STAGES_BYTES > EPI_BYTES ? STAGES_BYTES : EPI_BYTES;
   static constexpr int NROWS = (MR - 1) * STRIDE + KS;         // patch rows one wave touches
   static constexpr int PIX_PER_I = NTHR / CPP;                 // pixels advanced per staging item index
   static_assert(PIX_PER_I % 32 == 0, "swizzle term must not depend on the staging item index");
@@ -139,11 +141,17 @@ template <int MR> struct AccSet<true, MR> {
 // y2, no fp32 / partial-channel output.  A fixed kind carries no loads, address arithmetic, prefetch registers or branches for tensors
 // the launch does not have: the four growth convs of a dense block (kind 0) and their data-gradient twins (kind 4) are 80 % of a
 // generator step's launches.
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
-__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+// DB (16 waves, 64-channel tiles of 16 rows: one workgroup per CU): the stage of chunk c+1 is written into the OTHER LDS buffer by each
+// wave as soon as its own MFMA phase of chunk c is over and its loads have arrived -- one barrier per chunk instead of two, no wave
+// waits at a barrier before it may commit, the weight slab is staged once per 512 pixels instead of once per 256, and the staging
+// registers shrink from 32 to 24 per lane (profiles/r03_conv_timeline.txt: of the 3.45 us a 64-channel tile spends per chunk, 1.45 are
+// the MFMA phase, 0.9 the wait at the barrier in front of the commit and 0.9 the commit).
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
+__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
+  static_assert(!DB || (M16 && TS == 1), "double-buffered stages: 16-bit kernels, one stage per chunk");
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>;
   using Frag = typename FragAB<T>::type;
   constexpr int NTHR = C::NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   };
   // tiles after the first: requested during the previous tile's last MFMA phase (the kinds whose epilogue leaves room for the 32
   // staging registers), else after its epilogue
-  constexpr bool kCross = kPrefetch && EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0;
+  constexpr bool kCross = kPrefetch && EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && !DB;
 
   AccSet<M16, MR> A_;
   auto& acc = A_.a;
@@ -387,6 +395,12 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
   const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
   const char* ldsWn = ldsW + wn * C::WS_BYTES + lane * C::FRAGB;
+  // double-buffered stages: point the staging stores / the fragment reads at buffer b
+  auto set_stage = [&](int b) {
+    ldsX = smem + b * C::STAGE_BYTES;
+    ldsW = ldsX + C::XBYTES;
+    ldsWn = ldsW + wn * C::WS_BYTES + lane * C::FRAGB;
+  };
 
   // 16x16x32 form, stride 1: lane term of the fragment address per kernel column (chunk-invariant)
   int colt[KS];
@@ -468,13 +482,24 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       });
     }
   } else {
+  if constexpr (DB) {
+    __syncthreads();          // (a previous tile's epilogue tile lies over both buffers)
+    set_stage(0);
+    commit(0);
+  }
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
+    if constexpr (DB) {
+      __syncthreads();        // stage `chunk` is published; every wave has left the MFMA phase of chunk - 1, whose buffer takes chunk + 1
+      CONV_STAMP();
+    } else {
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
     CONV_STAMP();   // 2 + 4c: previous MFMA phase of every wave done
     if (!SRGANFD_DBG(a.dbg, 8)) commit(chunk);
     CONV_STAMP();   // 3 + 4c: this wave's loads arrived and are written to LDS
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
     CONV_STAMP();   // 4 + 4c: stage published
+    }
+    if constexpr (DB) set_stage(chunk & 1);
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
     else if (kCross && more) {
       if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(2);
@@ -558,6 +583,13 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
       }
       __builtin_amdgcn_s_setprio(0);
       CONV_STAMP();   // 5 + 4c: MFMA phase done
+      if constexpr (DB) {
+        if (chunk + 1 < a.nChunks) {
+          set_stage((chunk + 1) & 1);
+          commit(chunk + 1);
+          CONV_STAMP();
+        }
+      }
     } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MR == 2) {
       // Software-pipelined fragment reads: the chunk's 42 ds_read_b128 and 36 MFMAs in one fixed issue order, every read kD
       // fragments ahead of the MFMA that consumes it (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> MFMA on two
@@ -861,19 +893,22 @@ static int device_cus() {
   return c;
 }
 #ifdef SRGANFD_EXPERIMENT
+int g_use_db = [] { const char* e = getenv("SRGANFD_USE_DB"); return e ? atoi(e) : 0; }();   // A/B: 16-wave double-buffered 64-channel tiles (srganfd_set_igemm_variant bit 10)
+#endif
+#ifdef SRGANFD_EXPERIMENT
 int g_no_persist = [] { const char* e = getenv("SRGANFD_NO_PERSIST"); return e ? atoi(e) : 0; }();   // A/B: one workgroup per tile (srganfd_set_igemm_variant bit 9)
 #else
 constexpr int g_no_persist = 0;
 #endif
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>;
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, DB>;
   if (g_describe) {
     char ek[8] = "";
     if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
-    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek);
+    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek, DB ? ",DB" : "");
     return SRGANFD_OK;
   }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
@@ -898,7 +933,7 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   // kinds that prefetch across tiles run as persistent workgroups: as many as the chip holds at once (a multiple of 8, so that the
   // virtual blocks v, v + grid, ... of one workgroup keep their XCD class in xcd_remap)
   long long grid = nblk;
-  if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2 && !g_no_persist) {
+  if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2 && !DB && !g_no_persist) {
     const long long slots = (long long)device_cus() * C::WG_PER_CU;
     if (slots >= 8 && nblk > slots) grid = slots / 8 * 8;
   }
@@ -949,6 +984,16 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
         if (ek == 0 && !wide && g_igemm_variant == 1) return launch_conv<T, 3, 1, 2, 4, 1, true, 1, 0>(k, a->cout, s);
         if (ek == 0 && !wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 1, true, 1, 0>(k, a->cout, s);
         if (ek == 0 && wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 2, true, 1, 0>(k, a->cout, s);
+#endif
+#ifdef SRGANFD_EXPERIMENT
+        if (wide && g_use_db && ek >= 0 && ek != 2 && ek <= 4) {
+          // experiment (rejected, profiles/r03_conv_experiments.txt 10): 64-channel tiles of 16 waves, 16 x 32 pixels, double-buffered
+          // stages, one workgroup per CU
+          if (ek == 0) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 0, true>(k, a->cout, s);
+          if (ek == 1) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 1, true>(k, a->cout, s);
+          if (ek == 3) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 3, true>(k, a->cout, s);
+          if (ek == 4) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 4, true>(k, a->cout, s);
+        }
 #endif
         if (wide) {
           if (ek == 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 0>(k, a->cout, s);
