@@ -1,0 +1,115 @@
+"""Two REAL ranks (two processes, gloo collectives on CUDA tensors) sharing the test box's one GPU: the data-parallel schedules with
+world > 1 -- the generator's three bucket all-reduces on a side stream while later weight-gradient kernels write the rest of the flat
+gradient, the discriminator's all-reduce + Adam on its side stream beside the content forwards, the device-resident loss scaler updated
+from the all-reduced gradient on every rank, and (A-ESRGAN) the SyncBatchNorm table exchange between the two phases of every BatchNorm.
+Each rank takes half of a batch of 4; after two iterations the parameters must equal the single-process run on the whole batch
+(losses are means: the sum of the two shard gradients x 1/2 is the full-batch gradient; fp32 summation order differs, nothing else).
+RCCL itself cannot put two ranks on one device; the one-rank RCCL test (test_rccl_world_one_gpu.py) covers its stream / event side."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np, torch, torch.distributed as dist
+    from tests.util import scaled_init
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+
+    rank, world = int(os.environ["RANK"]), 2
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = dist.group.WORLD
+
+    def nets(dtype, aes=False):
+        torch.manual_seed(0)
+        d = M.uNetDiscriminatorAesrgan() if aes else M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+        g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2)
+        scaled_init(g, 3.0, 0.5)
+        d.compute_dtype = g.compute_dtype = dtype
+        return g.cuda().train(), d.cuda().train()
+
+    torch.manual_seed(33)
+    batches = [(torch.rand(4, 3, 16, 16).cuda(), torch.rand(4, 3, 64, 64).cuda()) for _ in range(2)]
+    shard = lambda t: t[2 * rank: 2 * rank + 2].contiguous()
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+    worst = {}
+    for name, dtype, aes, sync_bn in (("gan f32", torch.float32, False, False), ("gan f16", torch.float16, False, False),
+                                      ("aesrgan f32 syncbn", torch.float32, True, True)):
+        # single process, whole batch (same seeds -> same initial weights)
+        g0, d0 = nets(dtype, aes)
+        t0 = GanTrainer(g0, d0, None, **(dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1) if aes else {}))
+        full = [t0.step(x, y).cpu().numpy().copy() for x, y in batches]
+        # two ranks, half a batch each
+        g1, d1 = nets(dtype, aes)
+        kw = dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1, sync_batchnorm=True) if aes else {}
+        t1 = GanTrainer(g1, d1, None, process_group=pg, **kw)
+        assert t1.g_reducer.stream is not None and t1.d_reducer.stream is not None        # the exchanges really run off the main stream
+        part = [t1.step(shard(x), shard(y)).cpu().numpy().copy() for x, y in batches]
+        torch.cuda.synchronize()
+        # every rank must hold the same parameters (they saw the same all-reduced gradients) ...
+        mine = torch.cat([t1.g_opt.flat, t1.d_opt.flat]).clone()
+        other = mine.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(mine, other), name + ": the ranks' parameters diverged"
+        # ... equal to the whole-batch run.  f16: the shards round differently (batch statistics of 2 vs 4 images do not exist here, but
+        # activations of different images share no arithmetic; what differs is the fp32 order of the gradient sums)
+        tol = 2e-5 if dtype == torch.float32 else 2e-3
+        eg, ed = rel(t1.g_opt.flat, t0.g_opt.flat), rel(t1.d_opt.flat, t0.d_opt.flat)
+        worst[name] = (eg, ed)
+        assert eg < tol and ed < tol, (name, eg, ed)
+        if dtype == torch.float16:
+            assert t1.scaler.report() == t0.scaler.report(), (t1.scaler.report(), t0.scaler.report())
+        # logged scalars are means over the local shard: their average over the ranks is the whole-batch value
+        s = torch.tensor(np.stack(part), dtype=torch.float64)
+        dist.all_reduce(s)
+        s = (s / world).numpy()
+        assert np.allclose(s[:, :4], np.stack(full)[:, :4], rtol=5e-3 if dtype == torch.float16 else 1e-4, atol=1e-6), (name, s, full)
+    # generator-only trainer
+    g0, _ = nets(torch.float32)
+    t0 = GeneratorTrainer(g0, lr=1e-4)
+    for x, y in batches:
+        t0.step(x, y)
+    g1, _ = nets(torch.float32)
+    t1 = GeneratorTrainer(g1, lr=1e-4, process_group=pg)
+    for x, y in batches:
+        t1.step(shard(x), shard(y))
+    torch.cuda.synchronize()
+    e = rel(t1.flat, t0.flat)
+    assert e < 2e-5, e
+    dist.barrier()
+    dist.destroy_process_group()
+    print("TWO-RANK-OK rank %%d %%s g-only %%.1e" %% (rank, worst, e))
+""")
+
+
+def test_two_gloo_ranks_on_one_gpu_equal_the_whole_batch_run():
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29683", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0 and "TWO-RANK-OK" in o, o[-2000:] + e[-4000:]
