@@ -115,7 +115,20 @@ def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> di
     """Dominant kernel class (largest total time) against the roof that bounds it: its arithmetic intensity (algorithmic
     FLOP / algorithmic bytes) below the ridge peak_tflops / peak_gbps means HBM-bound, else MFMA-bound.  Both fractions
     are reported; `achieved` / `peak` / `frac` are those of the binding roof."""
-    agg = summary(rec)
+    import re
+    per_label = summary(rec)
+    # the epilogue kinds of one tile shape (",E0" plain, ",E4" masked, ...: conv_igemm_kernel's EK) share the staging and MFMA loop: one class
+    agg: Dict[str, dict] = {}
+    for lab, v in per_label.items():
+        fam = re.sub(r",E\d+", "", lab)
+        d = agg.setdefault(fam, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0, "kinds": {}})
+        d["launches"] += v["launches"]; d["ms"] += v["ms"]; d["flop"] += v["flop"]; d["bytes"] += v["bytes"]
+        d["kinds"][lab] = {"launches": v["launches"], "avg_us": v["avg_us"]}
+    for d in agg.values():
+        d["avg_us"] = round(d["ms"] * 1e3 / d["launches"], 2) if d["launches"] else 0.0
+        d["tflops"] = round(d["flop"] / (d["ms"] * 1e-3) / 1e12, 1) if d["ms"] > 0 else 0.0
+        d["gbps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 else 0.0
+        d["flop_per_byte"] = round(d["flop"] / d["bytes"], 1) if d["bytes"] > 0 else None
     label, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
     ridge = peak_tflops * 1e12 / (peak_gbps * 1e9)
     ai = d["flop_per_byte"]
@@ -125,6 +138,8 @@ def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> di
         out.update(achieved=d["gbps"], peak=peak_gbps, unit="GB/s", frac=round(d["gbps"] / peak_gbps, 4))
     else:
         out.update(achieved=d["tflops"], peak=peak_tflops, unit="TFLOP/s", frac=round(d["tflops"] / peak_tflops, 4))
+    if len(d["kinds"]) > 1:
+        out["kinds"] = d["kinds"]
     out.update(traffic=None, avg_launch_us=d["avg_us"], launches=d["launches"],
                flop_per_launch=float(f"{d['flop'] / d['launches']:.6g}"),
                bytes_per_launch=float(f"{d['bytes'] / d['launches']:.6g}"), flop_per_byte=ai, ridge_flop_per_byte=round(ridge, 1),

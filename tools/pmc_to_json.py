@@ -1,4 +1,4 @@
-"""rocprofv3 outputs of tools/profile_round.sh -> profiles/: per-kernel stats CSVs, a PMC summary, and r02_pmc.json (what bench.py
+"""rocprofv3 outputs of tools/profile_round.sh -> profiles/: per-kernel stats CSVs, a PMC summary, and <tag>_pmc.json (--tag, default r03) (what bench.py
 reads for roofline.traffic / mfma_busy_pmc, stamped with the SHA of the kernel sources it was measured on).
 
     python tools/pmc_to_json.py gpurun_out/prof_r02 [--batch 32 --lr-size 128]
@@ -24,20 +24,22 @@ MTY = {"t": "unsigned short", "DF16_": "_Float16", "f": "float"}
 def demangle(kernel: str) -> str:
     """rocprofv3 leaves names with _Float16 template arguments mangled (_ZN7srganfd17conv_igemm_kernelIDF16_Li3ELi1E...): rebuild
     `name<type, ints...>` so that one parser serves both forms"""
-    m = re.match(r"_ZN7srganfd\d+(\w+?_kernel)I(DF16_|t|f)((?:Li\d+E|Lb[01]E)*)E", kernel)
+    m = re.match(r"_ZN7srganfd\d+(\w+?_kernel)I(DF16_|t|f)((?:Lin?\d+E|Lb[01]E)*)E", kernel)
     if not m:
         return kernel
-    args = [MTY[m.group(2)]] + [a[2:-1] if a.startswith("Li") else ("true" if a[2] == "1" else "false") for a in re.findall(r"Li\d+E|Lb[01]E", m.group(3))]
+    args = [MTY[m.group(2)]] + [(a[2:-1].replace("n", "-") if a.startswith("Li") else ("true" if a[2] == "1" else "false")) for a in re.findall(r"Lin?\d+E|Lb[01]E", m.group(3))]
     return "%s<%s>" % (m.group(1), ", ".join(args))
 
 
 def label(kernel: str):
     """rocprof kernel name -> bench.py class label (profiling.conv_label / WgradPlan.label)"""
     kernel = demangle(kernel)
-    m = re.search(r"conv_igemm_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?(?:, (\d+))?>", kernel)
+    m = re.search(r"conv_igemm_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?(?:, (\d+))?(?:, (-?\d+))?(?:, (true|false))?>", kernel)
     if m:
-        return "conv_igemm_kernel<%s,KS=%s,S=%s,MR=%s,WR=%s,WN=%s%s%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:6], ",M16" if m.group(7) == "true" else "",
-                                                                         ",TS=%s" % m.group(8) if m.group(8) and int(m.group(8)) > 1 else "")
+        return "conv_igemm_kernel<%s,KS=%s,S=%s,MR=%s,WR=%s,WN=%s%s%s%s%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:6], ",M16" if m.group(7) == "true" else "",
+                                                                             ",TS=%s" % m.group(8) if m.group(8) and int(m.group(8)) > 1 else "",
+                                                                             "",      # epilogue kinds (EK) of one tile shape: one class, as profiling.roofline groups them
+                                                                             ",DB" if m.group(10) == "true" else "")
     m = re.search(r"conv3x3_ring_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
     if m:
         return "conv3x3_ring_kernel<%s,MR=%s,WR=%s,NR=%s,SCH=%s,NBUF=%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:])
@@ -58,13 +60,14 @@ def counters(d):
 
 
 src = sys.argv[1]
+TAG = arg("--tag", "r03")
 out = {"csrc_sha": bench.csrc_sha(), "batch": int(arg("--batch", "32")), "lr_size": int(arg("--lr-size", "128")), "workloads": {},
        "how": "tools/profile_round.sh + tools/pmc_to_json.py; traffic = (2*RDREQ + WRREQ)*64 B per launch, mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 1024)"}
 text = []
 for wl in ("g_only", "gan"):
     st = glob.glob(f"{src}/stats_{wl}/**/*kernel_stats.csv", recursive=True)
     if st:
-        shutil.copy(st[0], os.path.join(ROOT, "profiles", f"r02_{wl}_b32_kernel_stats.csv"))
+        shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{TAG}_{wl}_b32_kernel_stats.csv"))
     tcc, ntcc = counters(f"{src}/pmc_tcc_{wl}")
     sq, nsq = counters(f"{src}/pmc_sq_{wl}")
     W = out["workloads"].setdefault(wl, {})
@@ -92,6 +95,6 @@ for wl in ("g_only", "gan"):
                                      "issuing": round(r["SQ_ACTIVE_INST_ANY"] / wc, 3)}
         W[lab] = e
         text.append(f"  {lab}: {json.dumps(e)}")
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc.json"), "w"), indent=1)
-open(os.path.join(ROOT, "profiles", "r02_pmc_summary.txt"), "w").write("\n".join(text) + "\n")
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_pmc.json"), "w"), indent=1)
+open(os.path.join(ROOT, "profiles", f"{TAG}_pmc_summary.txt"), "w").write("\n".join(text) + "\n")
 print("\n".join(text))
