@@ -110,7 +110,7 @@ int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganf
 #ifdef SRGANFD_EXPERIMENT
 void srganfd_set_mfma16(int on) { srganfd::g_mfma16 = on; }
 void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
-void srganfd_set_igemm_variant(int v) { srganfd::g_igemm_variant = v & 255; srganfd::g_no_epi_kinds = (v >> 8) & 1; srganfd::g_no_persist = (v >> 9) & 1; srganfd::g_use_db = (v >> 10) & 1; }   // kbench A/B
+void srganfd_set_igemm_variant(int v) { srganfd::g_igemm_variant = v & 255; srganfd::g_no_epi_kinds = (v >> 8) & 1; srganfd::g_no_persist = (v >> 9) & 1; srganfd::g_use_db = (v >> 10) & 1; srganfd::g_use_stream = (v >> 11) & 1; }   // kbench A/B
 void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
 #endif
 

@@ -1,6 +1,7 @@
 // conv_common.hpp -- launch arguments and MFMA helpers shared by the fused-convolution kernels
 // (conv_igemm.hip: every kernel shape; tools/experiments/conv3x3_ring.hip: the LDS-DMA ring experiment).
 #pragma once
+#include <utility>
 #include "common.hpp"
 
 namespace srganfd {
@@ -77,13 +78,34 @@ inline unsigned div_magic(unsigned d, unsigned long long n_max) {
 bool conv_uses_m16(int dtype, int ksize, int cout);
 extern int g_mfma16;   // 1: the 3x3 16-bit convolutions run on the 16x16x32 form (weights packed in its B-fragment order: srganfd_pack_job.layout)
 
+// compile-time loop (indices as types), for the software-pipelined MFMA phase
+template <int I> struct IC { static constexpr int v = I; };
+template <class Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// last fragment load issued before MFMA i: the fragment it needs (7 loads / 6 MFMAs per column body) plus kD of read-ahead
+// 16x16x32 form, 3x3 stride 1, two rows per wave: fixed issue order of one kernel column's 14 fragment reads and 24 MFMAs.
+// reads:  B00 A00 A01 A10 A11 | B01 | B10 A20 A21 | B11 | B20 A30 A31 | B21      (B[ky][channel half], A[patch row][pixel half])
+// MFMAs:  group (ky, nh) = 4 MFMAs (row m, pixel half ph): acc[m][ph][nh] += A[m + ky][ph] x B[ky][nh]  -- eight independent
+//         accumulators between two uses of the same one.
+__host__ __device__ constexpr int m16_bidx(int ky, int nh) { return ky == 0 ? (nh ? 5 : 0) : ky == 1 ? (nh ? 9 : 6) : (nh ? 13 : 10); }
+__host__ __device__ constexpr int m16_aidx(int rr, int ph) { return (rr == 0 ? 1 : rr == 1 ? 3 : rr == 2 ? 7 : 11) + ph; }
+__host__ __device__ constexpr int m16_need(int j) {
+  const int gq = j / 4, t = j % 4, a = m16_aidx((t >> 1) + (gq >> 1), t & 1), b = m16_bidx(gq >> 1, gq & 1);
+  return a > b ? a : b;
+}
+__host__ __device__ constexpr int m16_pipe_hi(int i, int d, int nl) { const int need = 14 * (i / 24) + m16_need(i % 24); return need + d < nl - 1 ? need + d : nl - 1; }
+__host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need = 7 * (i / 6) + (i % 6) + 1; return need + d < nl - 1 ? need + d : nl - 1; }
+
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
+int conv_device_cus();   // compute units of the current device (conv_igemm.hip)
 #ifdef SRGANFD_EXPERIMENT
+extern int g_use_stream;
+int conv_stream_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);   // tools/experiments/conv_stream.hip
 int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);   // tools/experiments/conv3x3_ring.hip
 #endif
 

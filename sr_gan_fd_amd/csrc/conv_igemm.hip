@@ -29,26 +29,6 @@
 #include "conv_common.hpp"
 #include <stdlib.h>
 #include <utility>
-namespace srganfd {
-// compile-time loop (indices as types), for the software-pipelined MFMA phase
-template <int I> struct IC { static constexpr int v = I; };
-template <class Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
-template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-// last fragment load issued before MFMA i: the fragment it needs (7 loads / 6 MFMAs per column body) plus kD of read-ahead
-// 16x16x32 form, 3x3 stride 1, two rows per wave: fixed issue order of one kernel column's 14 fragment reads and 24 MFMAs.
-// reads:  B00 A00 A01 A10 A11 | B01 | B10 A20 A21 | B11 | B20 A30 A31 | B21      (B[ky][channel half], A[patch row][pixel half])
-// MFMAs:  group (ky, nh) = 4 MFMAs (row m, pixel half ph): acc[m][ph][nh] += A[m + ky][ph] x B[ky][nh]  -- eight independent
-//         accumulators between two uses of the same one.
-__host__ __device__ constexpr int m16_bidx(int ky, int nh) { return ky == 0 ? (nh ? 5 : 0) : ky == 1 ? (nh ? 9 : 6) : (nh ? 13 : 10); }
-__host__ __device__ constexpr int m16_aidx(int rr, int ph) { return (rr == 0 ? 1 : rr == 1 ? 3 : rr == 2 ? 7 : 11) + ph; }
-__host__ __device__ constexpr int m16_need(int j) {
-  const int gq = j / 4, t = j % 4, a = m16_aidx((t >> 1) + (gq >> 1), t & 1), b = m16_bidx(gq >> 1, gq & 1);
-  return a > b ? a : b;
-}
-__host__ __device__ constexpr int m16_pipe_hi(int i, int d, int nl) { const int need = 14 * (i / 24) + m16_need(i % 24); return need + d < nl - 1 ? need + d : nl - 1; }
-__host__ __device__ constexpr int pipe_hi(int i, int d, int nl) { const int need = 7 * (i / 6) + (i % 6) + 1; return need + d < nl - 1 ? need + d : nl - 1; }
-}
-
 // epilogue kinds with any of these operand bits keep one tile per workgroup (0: every fixed kind runs persistent, 7: only kind 0)
 #ifndef SRGANFD_CROSS_MASK
 #define SRGANFD_CROSS_MASK 7
@@ -880,7 +860,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
 }
 
 // compute units of the current device (cached per device id); 256 when nothing can be asked (dry runs on the CPU)
-static int device_cus() {
+int conv_device_cus() {
   static int cus[64] = {0};
   if (g_dry_run) return 256;
   int dev = 0;
@@ -934,7 +914,7 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   // virtual blocks v, v + grid, ... of one workgroup keep their XCD class in xcd_remap)
   long long grid = nblk;
   if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2 && !DB && !g_no_persist) {
-    const long long slots = (long long)device_cus() * C::WG_PER_CU;
+    const long long slots = (long long)conv_device_cus() * C::WG_PER_CU;
     if (slots >= 8 && nblk > slots) grid = slots / 8 * 8;
   }
   SRGANFD_LAUNCH(kern, dim3((unsigned)grid), dim3(C::NTHR), C::LDS_BYTES, stream, kk);
@@ -1105,6 +1085,14 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
     bool handled = false;
     // the LDS-DMA ring kernel (64-channel tiles of large images) reads 32x32x16-order weights: used where that form is selected
     const int rc = conv_uses_m16(a->dtype, a->ksize, a->cout) ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);
+    if (rc != SRGANFD_OK || handled) return rc;
+  }
+#endif
+#ifdef SRGANFD_EXPERIMENT
+  {
+    // experiment (rejected, profiles/r03_conv_experiments.txt 12): every 3x3 stride-1 launch on the LDS-DMA streaming kernel
+    bool handled = false;
+    const int rc = conv_stream_try(a, k, stream, &handled);
     if (rc != SRGANFD_OK || handled) return rc;
   }
 #endif
