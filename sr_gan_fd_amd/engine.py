@@ -439,6 +439,8 @@ class TrunkEngine:
             if self.full and R >= 4 and i == R // 2:      # upper half of the trunk is final: second bucket
                 bw.append(("ready", self._poff(pre + "conv1.weight"), self._poff("conv2.weight")))
             dst = VD(dyb(i - 1)) if i > 0 else V(sp.dx0)
+            if i > 0:
+                bw.append(("fence", i + 3))     # dst is the buffer block i + 3's weight gradient read (side-stream mode, see backward())
             kw = dict(r1=VD(di), r1_scale=s_out)
             if first:
                 kw.update(r2=VD(dyb(i + 2)), r2_scale=1.0)
@@ -510,6 +512,22 @@ class TrunkEngine:
         gptr = flat_grad.data_ptr()
         rec = profiling.REC
         pend_red = []          # dense-block weight-gradient launches whose slabs wait for the batched reduction
+        # SRGANFD_WGRAD_STREAM=1: the dense blocks' weight-gradient launches (and their slab reductions) run on a second stream beside
+        # the data-gradient chain of the following blocks -- they only read what the chain has finished (block i's stacked gradient and
+        # activations); the chain waits ("fence") before it overwrites a gradient buffer a pending weight gradient still reads.
+        side = None
+        if _WGRAD_STREAM and sp.wg_ws4 is not None:
+            side = getattr(sp, "wg_stream", None)
+            if side is None:
+                side = sp.wg_stream = torch.cuda.Stream(device=sp.device)
+            main = torch.cuda.current_stream()
+            wg_done = {}       # dense block -> event behind its weight-gradient launch on the side stream
+
+        def on_side(fn):
+            if side is None:
+                return fn()
+            with torch.cuda.stream(side):
+                return fn()
 
         def flush_reduce():
             if not pend_red:
@@ -518,11 +536,12 @@ class TrunkEngine:
             for j, (plan, goff, ws) in zip(jobs, pend_red):
                 j.plan_host, j.plan_dev = C.addressof(plan.host), plan.dev.data_ptr()
                 j.grads, j.scalars, j.workspace = gptr + 4 * goff, None, ws.data_ptr()
-            run = lambda: A.check(L.srganfd_wgrad_reduce_batch(jobs, len(pend_red), st), "wgrad_reduce_batch")
+            n_jobs = len(pend_red)
+            run = lambda: A.check(L.srganfd_wgrad_reduce_batch(jobs, n_jobs, A.stream_ptr()), "wgrad_reduce_batch")
             if rec is None:
-                run()
+                on_side(run)
             else:
-                rec.bracket("wgrad_reduce_batch", (0.0, float(sum(w.numel() for _, _, w in pend_red))), run)
+                on_side(lambda: rec.bracket("wgrad_reduce_batch", (0.0, float(sum(w.numel() for _, _, w in pend_red))), run))
             pend_red.clear()
         for item in sp.bw:
             kind = item[0]
@@ -540,12 +559,18 @@ class TrunkEngine:
                     # dense block: MFMA kernel now, slabs into one of four workspaces; the slab reduction of up to four blocks is ONE
                     # launch (srganfd_wgrad_reduce_batch: the reduction is latency-bound at ~20 us whatever it reduces)
                     ws = sp.wg_ws4[len(pend_red)]
-                    run = lambda: A.check(L.srganfd_conv2d_wgrad_partial(plan.host, plan.dev.data_ptr(), xv, dyv, ws.data_ptr(), ws.numel(), st),
+                    run = lambda: A.check(L.srganfd_conv2d_wgrad_partial(plan.host, plan.dev.data_ptr(), xv, dyv, ws.data_ptr(), ws.numel(), A.stream_ptr()),
                                           "conv2d_wgrad_partial")
+                    if side is not None:
+                        side.wait_stream(main)          # the block's four data-gradient launches have written its stacked gradient
                     if rec is None:
-                        run()
+                        on_side(run)
                     else:
-                        rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
+                        on_side(lambda: rec.bracket(plan.label, (plan.flops, plan.nbytes), run))
+                    if side is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        wg_done[item[5]] = ev
                     pend_red.append((plan, goff, ws))
                     if len(pend_red) == len(sp.wg_ws4):
                         flush_reduce()
@@ -559,11 +584,18 @@ class TrunkEngine:
                         rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
             elif kind == "ready":
                 flush_reduce()
+                if side is not None:
+                    main.wait_stream(side)
                 if on_ready is not None:
                     on_ready(flat_grad, item[1], item[2])
+            elif kind == "fence":
+                if side is not None and item[1] in wg_done:
+                    main.wait_event(wg_done.pop(item[1]))
             else:
                 item[1]()
         flush_reduce()
+        if side is not None:
+            main.wait_stream(side)
         dx = None
         if need_dx and not self.full:
             dx = torch.empty(N, self.Cc, H, W, dtype=torch.float32, device=sp.device)
@@ -573,6 +605,7 @@ class TrunkEngine:
 
 # dense blocks whose weight-gradient slabs one srganfd_wgrad_reduce_batch launch reduces (<= 8 = SRGANFD's kRedBatch; 0 / 1: every block's own)
 _BATCH_REDUCE = max(0, min(8, int(os.environ.get("SRGANFD_BATCH_REDUCE", "4"))))
+_WGRAD_STREAM = int(os.environ.get("SRGANFD_WGRAD_STREAM", "0"))
 
 
 class _TrunkFn(torch.autograd.Function):
