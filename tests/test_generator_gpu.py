@@ -290,6 +290,30 @@ def test_planar_dense_block_buffers_change_nothing_but_the_addresses(monkeypatch
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
 
 
+def test_weight_gradients_on_a_side_stream_change_nothing(monkeypatch):
+    """engine.backward can run the dense blocks' weight-gradient launches on a second stream beside the data-gradient chain
+    (SRGANFD_WGRAD_STREAM=1; measured slower, off by default).  The fences that keep the chain from overwriting a stacked-gradient buffer a
+    pending launch still reads must hold: three iterations over 6 RRDB (18 dense blocks: the four rotating buffers wrap four times)
+    give bitwise the parameters of the single-stream run."""
+    from sr_gan_fd_amd import engine, model as M
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    lr, gt = torch.rand(2, 3, 40, 48, device="cuda"), torch.rand(2, 3, 160, 192, device="cuda")
+    res = {}
+    for flag in (0, 1):
+        monkeypatch.setattr(engine, "_WGRAD_STREAM", flag)
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(num_rrdb=6)
+        scaled_init(g, 3.0, 0.5)
+        g.compute_dtype = torch.float16
+        tr = GeneratorTrainer(g.cuda().train(), lr=1e-4)
+        losses = [tr.step(lr, gt).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert (getattr(tr.eng._last, "wg_stream", None) is not None) == bool(flag)
+        res[flag] = (losses, tr.opt.flat.clone())
+    assert all(torch.equal(a, b) for a, b in zip(res[0][0], res[1][0]))
+    assert torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("name,fac,kw,B,h,lr,eps", [
     ("esrgan_small", "rrdbnet_x4", dict(num_blocks=2), 2, 16, 2e-4, 1e-8),        # ESRGAN/rrdbnet_config.py:68-78
     ("bsrnet_small", "bsrgan_x4", dict(num_rrdb=2), 2, 16, 1e-4, 1e-4),           # BSRGAN/bsrnet_config.py:86-96
