@@ -16,6 +16,7 @@
 // (no float atomics: results are bitwise reproducible) straight into the NCHW fp32 gradient.
 // f32 mode (parity) uses v_mfma_f32_32x32x2_f32 with plain ds_read_b32 (channels on the lanes).
 #include "conv_common.hpp"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -25,7 +26,9 @@ static constexpr int kWgMagic = 0x57475244;  // 'WGRD'
 
 static constexpr int kMaxWaves = 12;
 struct WgWave { int active, ci_rel, co_rel, ks_idx, ks_n, tap0, slab_base, bias_slab; };
-struct WgGroup { int x_c0, x_units, dy_c0, dy_units; WgWave w[kMaxWaves]; };
+struct WgGroup { int x_c0, x_units, dy_c0, dy_units;
+                 int x_u1, dy_u1;      // the second staged unit sits this many 32-channel groups behind the first (1 = the 64-channel range)
+                 WgWave w[kMaxWaves]; };
 struct WgTask {
   long long dw_off, db_off, alpha_off;
   int co_dst, ci_dst, co_base, ci_base, tap0, ntap, ksize, slab_base, nslabs, bias_slab;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   const int xcb = a.x_c0v + G.x_c0, ycb = a.dy_c0v + G.dy_c0;     // first channel this group stages
   const T* __restrict__ xg = (const T*)a.x + ((xcb >> 5) * (size_t)a.x_gs + (xcb & 31));
   const T* __restrict__ dyg = (const T*)a.dy + ((ycb >> 5) * (size_t)a.dy_gs + (ycb & 31));
+  const int x_gs2 = a.x_gs * G.x_u1, dy_gs2 = a.dy_gs * G.dy_u1;   // distance of the group's two staged units
 
   f32x16 acc[NT];
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
       if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-        v = *(const u32x4*)(xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + ((c16 * E16) >> 5) * a.x_gs + ((c16 * E16) & 31)));   // 64-bit image base + 32-bit offset (host-checked)
+        v = *(const u32x4*)(xg + (size_t)n * a.Hin * a.Win * a.xC + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + ((c16 * E16) >> 5) * x_gs2 + ((c16 * E16) & 31)));   // 64-bit image base + 32-bit offset (host-checked)
     }
     return v;
   };
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
     if (item < yItems && !SRGANFD_DBG(a.dbg, 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + ((c16 * E16) >> 5) * a.dy_gs + ((c16 * E16) & 31)));
+      if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + ((c16 * E16) >> 5) * dy_gs2 + ((c16 * E16) & 31)));
     }
     return v;
   };
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
           const int unit = (c16 >> CPU_SH) ^ swz(xp_sh, pix), w16 = c16 & (CPU - 1);
           const int py = pix / PC, px = pix - py * PC;
           spk[k] = py | (px << 8) | (unit << 16) | (w16 << 20);
-          soff[k] = (py * a.Win + px) * a.x_ps + unit * a.x_gs + w16 * E16;
+          soff[k] = (py * a.Win + px) * a.x_ps + unit * x_gs2 + w16 * E16;
         }
       } else if (piece < NPIECE) {
         const int item = (piece - XPIECES) * 64 + lane;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
           const int pix = item >> YSH, c16 = item & ((CPU << yp_sh) - 1);
           const int unit = (c16 >> CPU_SH) ^ swz(yp_sh, pix), w16 = c16 & (CPU - 1);
           spk[k] = (pix >> 5) | ((pix & 31) << 8) | (unit << 16) | (w16 << 20);
-          soff[k] = ((pix >> 5) * a.Wout + (pix & 31)) * a.dy_ps + unit * a.dy_gs + w16 * E16;
+          soff[k] = ((pix >> 5) * a.Wout + (pix & 31)) * a.dy_ps + unit * dy_gs2 + w16 * E16;
         }
       }
     }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       if (piece < XPIECES) {
         const int gy = gy0 + py, gx = gx0 + px;
         if (gy >= 0 && gy < Hl && gx >= 0 && gx < Wl)
-          glds16(lin ? xt + soff[k] : xi + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * a.x_gs + w16 * E16), lds_addr(bx) + (unsigned)(piece * 1024));
+          glds16(lin ? xt + soff[k] : xi + (((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + unit * x_gs2 + w16 * E16), lds_addr(bx) + (unsigned)(piece * 1024));
         else *(u32x4*)(bx + (piece * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
       } else {
         const int oy = oy0 + py, ox = ox0 + px;
@@ -609,6 +613,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgRedJobs jobs
 // ------------------------------------------------------------------------------------------------
 // host side: plan construction
 // ------------------------------------------------------------------------------------------------
+int g_wgrad_no_merge = [] { const char* e = getenv("SRGANFD_WGRAD_NO_MERGE"); return e ? atoi(e) : 0; }();   // A/B: one workgroup per single-task bucket (the round-2 grouping)
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct PlanBuild {
@@ -669,9 +674,47 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
           bk->tasks.push_back(id); bk->ci_abs.push_back(ca); bk->co_abs.push_back(oa);
         }
   }
-  for (auto& bk : buckets) {
+  // Two buckets that hold ONE task each (a dense block's launch leaves two: conv4's fifth input block and conv2's third) become one
+  // workgroup staging the two tasks' own units -- x units {a, b}, dy units {c, d}, not a 64-channel range -- instead of two workgroups
+  // whose twelve waves share one task: 7 channel groups instead of 8 for the dense block, so 36 pixel splits fit the chip instead of 32
+  // (3x3 stride 1, where a workgroup stages two units a side).
+  struct Merged { int a, b; };
+  std::vector<Merged> merged;
+  std::vector<char> gone(buckets.size(), 0);
+  if (xdiv == 2 && s->ksize == 3 && !g_wgrad_no_merge) {
+    int prev = -1;
+    for (int i = 0; i < (int)buckets.size(); ++i) {
+      if (buckets[i].tasks.size() != 1) continue;
+      if (prev < 0) { prev = i; continue; }
+      const int ca0 = buckets[prev].ci_abs[0], ca1 = buckets[i].ci_abs[0], oa0 = buckets[prev].co_abs[0], oa1 = buckets[i].co_abs[0];
+      if (ca0 != ca1 && oa0 != oa1) { merged.push_back(Merged{prev, i}); gone[prev] = gone[i] = 1; prev = -1; }
+    }
+  }
+  for (const Merged& mg : merged) {
+    const Bucket& p = buckets[mg.a]; const Bucket& q = buckets[mg.b];
+    WgGroup g; memset(&g, 0, sizeof(g));
+    const int ca[2] = {p.ci_abs[0], q.ci_abs[0]}, oa[2] = {p.co_abs[0], q.co_abs[0]}, tk[2] = {p.tasks[0], q.tasks[0]};
+    const int cmin = ca[0] < ca[1] ? ca[0] : ca[1], omin = oa[0] < oa[1] ? oa[0] : oa[1];
+    g.x_c0 = cmin * 32; g.dy_c0 = omin * 32; g.x_units = 2; g.dy_units = 2;
+    g.x_u1 = (ca[0] > ca[1] ? ca[0] - ca[1] : ca[1] - ca[0]); g.dy_u1 = (oa[0] > oa[1] ? oa[0] - oa[1] : oa[1] - oa[0]);
+    int k = 0;
+    for (int t = 0; t < 2; ++t)
+      for (int ky = 0; ky < s->ksize; ++ky)
+        for (int qq = 0; qq < cap / 2; ++qq) {
+          WgWave& w = g.w[k++];
+          w.active = 1; w.ci_rel = ca[t] == cmin ? 0 : 1; w.co_rel = oa[t] == omin ? 0 : 1;
+          w.ks_idx = qq; w.ks_n = cap / 2; w.tap0 = ky * s->ksize; w.slab_base = tk[t];
+          w.bias_slab = ky == 0 ? 0 : -1;
+        }
+    for (; k < kMaxWaves; ++k) { g.w[k].active = 0; g.w[k].ks_n = 1; g.w[k].bias_slab = -1; }
+    pb.groups.push_back(g);
+  }
+  for (size_t bi = 0; bi < buckets.size(); ++bi) {
+    if (gone[bi]) continue;
+    auto& bk = buckets[bi];
     WgGroup g; memset(&g, 0, sizeof(g));
     g.x_c0 = bk.xb * xdiv * 32; g.dy_c0 = bk.yb * 64;
+    g.x_u1 = g.dy_u1 = 1;
     g.x_units = (xdiv == 2 && s->x_channels - g.x_c0 >= 64) ? 2 : 1;
     g.dy_units = (s->dy_channels - g.dy_c0 >= 64) ? 2 : 1;
     const int nt = (int)bk.tasks.size();
@@ -692,7 +735,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.ntasks = (int)pb.tasks.size();
   // pixel-tile splits: aim at ~2 workgroups per CU over the whole launch
   int S = s->splits;
-  if (S <= 0) { S = (256 + H.ngroups - 1) / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, one round
+  if (S <= 0) { S = 256 / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, ONE round: never more workgroups than CUs
   if (S > H.ntiles) S = H.ntiles;
   if (S > 4096) S = 4096;
   H.S = S;
