@@ -20,6 +20,7 @@ int set_err(int code, const char* fmt, ...) {
   return code;
 }
 int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream);
+int conv2d_chain_impl(const srganfd_conv_args* args, int n, void* counters, hipStream_t stream);
 #ifdef SRGANFD_EXPERIMENT
 extern int g_igemm_variant, g_no_epi_kinds, g_no_persist, g_use_db;
 #endif
@@ -112,6 +113,7 @@ void srganfd_set_mfma16(int on) { srganfd::g_mfma16 = on; }
 void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
 void srganfd_set_igemm_variant(int v) { srganfd::g_igemm_variant = v & 255; srganfd::g_no_epi_kinds = (v >> 8) & 1; srganfd::g_no_persist = (v >> 9) & 1; srganfd::g_use_db = (v >> 10) & 1; srganfd::g_use_stream = (v >> 11) & 1; }   // kbench A/B
 void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
+int srganfd_conv2d_chain(const srganfd_conv_args* a, int n, void* counters, void* stream) { return conv2d_chain_impl(a, n, counters, (hipStream_t)stream); }   // tools/r3/chain_bench.py
 #endif
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }

@@ -28,6 +28,7 @@
 //     fp32 fma chain, used as the parity mode against the CPU oracle.
 #include "conv_common.hpp"
 #include <stdlib.h>
+#include <string.h>
 #include <utility>
 // epilogue kinds with any of these operand bits keep one tile per workgroup (0: every fixed kind runs persistent, 7: only kind 0)
 #ifndef SRGANFD_CROSS_MASK
@@ -126,15 +127,20 @@ template <int MR> struct AccSet<true, MR> {
 // waits at a barrier before it may commit, the weight slab is staged once per 512 pixels instead of once per 256, and the staging
 // registers shrink from 32 to 24 per lane (profiles/r03_conv_timeline.txt: of the 3.45 us a 64-channel tile spends per chunk, 1.45 are
 // the MFMA phase, 0.9 the wait at the barrier in front of the commit and 0.9 the commit).
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
-__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+// CHAIN (conv_chain_kernel below): the body runs as one STAGE of a chain of dependent launches inside one kernel.  Tiles are claimed from a
+// per-XCD counter (cc.claim; tile ids cc.tile0 + [0, cc.ntiles) are this XCD's images), the loads of a tile's LAST chunk -- the 32
+// channels the previous stage wrote -- wait until that stage has finished every tile of this XCD (cc.prev_done >= cc.prev_target), and a
+// finished tile is counted in cc.done once its stores have been acknowledged.
+struct ChainCtl { unsigned* claim; unsigned* done; const unsigned* prev_done; unsigned prev_target; int tile0, ntiles; };
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false, bool CHAIN = false>
+__device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem, const ChainCtl cc) {
+  static_assert(!CHAIN || (TS == 1 && !DB && sizeof(T) == 2), "chained stages: the 16-bit single-stage kernels");
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
   static_assert(!DB || (M16 && TS == 1), "double-buffered stages: 16-bit kernels, one stage per chunk");
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>;
   using Frag = typename FragAB<T>::type;
   constexpr int NTHR = C::NTHR;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsX = smem;
   char* ldsW = smem + C::XBYTES;
 
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   // tiles), block-uniform by construction; the readfirstlane tells the compiler so (otherwise every address product downstream
   // stays in quarter-rate vector multiplies).
   auto decode = [&](int vb, int& n_, int& oy_, int& ox_, int& nb_) {
-    const int bid = xcd_remap(vb, a.nblocks);
+    const int bid = CHAIN ? vb : xcd_remap(vb, a.nblocks);
     const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
     nb_ = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
     const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
@@ -392,15 +398,35 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
   if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(2);
-  setup_loads(blockIdx.x);
+  // chained stages: thread 0 claims the next tile of this XCD's range and leaves it in an LDS word behind the kernel's LDS image; the
+  // others read it behind a barrier (the first claim here, later ones behind the first chunk's barriers)
+  volatile int* claim_slot = (volatile int*)(smem + C::LDS_BYTES);
+  unsigned claim_val = 0u;          // thread 0: the claimed index, requested at the top of a tile and published before its first chunk's second barrier
+  auto claim_issue = [&]() { if (CHAIN && tid == 0) claim_val = atomicAdd(cc.claim, 1u); };
+  auto claim_publish = [&]() { if (CHAIN && tid == 0) *claim_slot = cc.tile0 + (int)claim_val; };
+  const int vt_end = CHAIN ? cc.tile0 + cc.ntiles : a.nblocks;
+  int vt = blockIdx.x;
+  if constexpr (CHAIN) {
+    claim_issue();
+    claim_publish();
+    __syncthreads();
+    vt = __builtin_amdgcn_readfirstlane(*claim_slot);
+    __syncthreads();
+    if (vt >= vt_end) return;
+  }
+  bool done_pending = false;        // a finished tile of this workgroup is not yet counted in cc.done
+  bool dep_ok = false;              // the previous stage is known to have finished this XCD's tiles
+  setup_loads(vt);
   if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(0);
   CONV_STAMP();   // 1: prologue done
   first_loads();
-  for (int vt = blockIdx.x;; vt += gridDim.x) {
+  for (;;) {
   // (cin >= 32 is host-checked; without the hint the compiler sees a path from the bias loads below to the epilogue that skips the
   // chunk loop's waits, and guards the epilogue with s_waitcnt vmcnt(0) -- which would also wait for the next tile's staging loads)
   __builtin_assume(a.nChunks >= 1);
-  const bool more = kCross && vt + (int)gridDim.x < a.nblocks;      // this workgroup has another tile after this one (the host gives the other kinds one block per workgroup)
+  claim_issue();
+  int vt_next = vt + (int)gridDim.x;
+  bool more = kCross && vt_next < a.nblocks;      // this workgroup has another tile after this one (the host gives the other kinds one block per workgroup)
   int n, oy0, ox0, nb;
   decode(vt, n, oy0, ox0, nb);
   A_.zero();
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
 #pragma unroll
           for (int i = 0; i < C::WI; ++i) wrg[i] = load_w(i, chunk + 1, 0);
         } else if (kCross && more) {
-          setup_loads(vt + gridDim.x);
+          setup_loads(vt_next);
           first_loads();
         }
         __builtin_amdgcn_s_setprio(1);
@@ -476,14 +502,37 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
     CONV_STAMP();   // 2 + 4c: previous MFMA phase of every wave done
     if (!SRGANFD_DBG(a.dbg, 8)) commit(chunk);
     CONV_STAMP();   // 3 + 4c: this wave's loads arrived and are written to LDS
+    if constexpr (CHAIN) {
+      if (chunk == 0) claim_publish();
+      if (chunk + 2 == a.nChunks && cc.prev_done && !dep_ok) {
+        // the NEXT chunk is what the previous stage wrote: wave 0 waits (once per stage) until that stage has finished this XCD's tiles;
+        // the barrier below holds the others.  (Every wave polling the counter's line queued the tile claims behind the polls.)
+        if (wave == 0) {
+          for (;;) {
+            unsigned v = 0u;
+            if (lane == 0) v = __hip_atomic_load(cc.prev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= cc.prev_target) break;
+            __builtin_amdgcn_s_sleep(16);
+          }
+        }
+        dep_ok = true;
+      }
+    }
     if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
     CONV_STAMP();   // 4 + 4c: stage published
+    }
+    if constexpr (CHAIN) {
+      if (chunk == 0) { vt_next = __builtin_amdgcn_readfirstlane(*claim_slot); more = vt_next < vt_end; }
+      // the previous tile's stores are older than the loads this chunk's commit has just waited for (the loads of chunk 1 where the
+      // tile's first chunk was requested across the previous epilogue): every wave is past that wait here
+      if (done_pending && chunk == (kCross ? 1 : 0)) { if (tid == 0) atomicAdd(cc.done, 1u); done_pending = false; }
+      asm volatile("" ::: "memory");
     }
     if constexpr (DB) set_stage(chunk & 1);
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
     else if (kCross && more) {
       if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(2);
-      setup_loads(vt + gridDim.x);
+      setup_loads(vt_next);
       first_loads();
       if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(0);
     }
@@ -851,12 +900,29 @@ __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, T
   }
   }();
   if (SRGANFD_DBG(a.dbg, 512)) __builtin_amdgcn_s_setprio(0);
+  if constexpr (CHAIN) done_pending = true;
   if (!more) break;
   if constexpr (!kCross) {
-    setup_loads(vt + gridDim.x);
+    setup_loads(vt_next);
     first_loads();
   }
+  vt = vt_next;
   }   // tiles of this workgroup
+  if constexpr (CHAIN) {
+    // the stage's last tile of this workgroup: drain its stores, then count it (and the one before it, if still pending)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma clang diagnostic pop
+    __syncthreads();
+    if (tid == 0) atomicAdd(cc.done, 1u);
+  }
+}
+
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
+__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_igemm_body<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, DB, false>(a, smem, ChainCtl{nullptr, nullptr, nullptr, 0u, 0, 0});
 }
 
 // compute units of the current device (cached per device id); 256 when nothing can be asked (dry runs on the CPU)
@@ -922,6 +988,73 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   return SRGANFD_OK;
 }
 
+
+#ifdef SRGANFD_EXPERIMENT
+// ---- chained launches (experiment, profiles/r03_conv_experiments.txt 14): the 3x3 stride-1 convs of a dense block (BSRGAN/model.py:54-58: each reads what the previous one wrote) as ONE
+// kernel.  Workgroups are persistent (two per CU); every stage's tiles are claimed per XCD -- an XCD works on whole images, so a stage's
+// input is always what a workgroup of the SAME XCD wrote (visible through its L2 once the stores are acknowledged) -- and only the
+// loads of a tile's last 32-channel chunk wait for the previous stage.  The XCD comes from the hardware register, not from the block
+// index, so correctness does not depend on how the dispatcher places workgroups.
+constexpr int kChainMax = 5;
+struct ChainK { ConvK k[kChainMax]; int n; int tiles_per_xcd[kChainMax]; unsigned* ctr; int nodep; };   // ctr[xcd][stage][64]: [0] claimed, [32] done (own 128-byte lines)
+template <typename T, int EK>
+__global__ __launch_bounds__(512, (ConvCfg<T, 3, 1, 2, 8, 1, 1, false>::MIN_WAVES_PER_SIMD)) void conv_chain_kernel(const ChainK c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));     // HW_REG_XCC_ID[3:0]
+  for (int s = 0; s < c.n; ++s) {
+    unsigned* ct = c.ctr + (xcd * kChainMax + s) * 64;
+    const ChainCtl cc{ct, ct + 32, (s && c.nodep != 1) ? ct - 32 : nullptr, s ? (c.nodep >= 2 ? (unsigned)c.nodep : (unsigned)c.tiles_per_xcd[s ? s - 1 : 0]) : 0u, xcd * c.tiles_per_xcd[s], c.tiles_per_xcd[s]};
+    conv_igemm_body<T, 3, 1, 2, 8, 1, true, 1, EK, false, true>(c.k[s], smem, cc);
+    __syncthreads();      // the next stage's first commit overwrites the LDS image this stage's last epilogue read
+  }
+}
+
+int conv_fill_k(const srganfd_conv_args* a, ConvK& k);     // argument checks + ConvK of one launch (conv2d_impl's first half)
+
+int conv2d_chain_impl(const srganfd_conv_args* args, int n, void* counters, hipStream_t stream) {
+  if (!args || n < 1 || n > kChainMax || !counters) return set_err(SRGANFD_EINVAL, "conv2d_chain: 1..%d launches and a counter buffer", kChainMax);
+  using C = ConvCfg<f16_t, 3, 1, 2, 8, 1, 1, false>;
+  ChainK ck;
+  memset(&ck, 0, sizeof(ck));
+  ck.n = n; ck.ctr = (unsigned*)counters;
+  { const char* e = getenv("SRGANFD_CHAIN_NODEP"); ck.nodep = e ? atoi(e) : 0; }     // timing experiments only: results are wrong
+  int ek = -2;
+  for (int i = 0; i < n; ++i) {
+    const srganfd_conv_args* a = args + i;
+    ConvK& k = ck.k[i];
+    const int rc = conv_fill_k(a, k);
+    if (rc != SRGANFD_OK) return rc;
+    const int e = (k.fast_epi && !k.y2 && !k.r1 && !k.r2) ? (k.mask ? 4 : 0) : -1;
+    if (a->dtype != args[0].dtype || a->dtype == SRGANFD_F32 || a->ksize != 3 || a->stride != 1 || a->pad != 1 || a->up || a->out_sy > 1 || a->out_sx > 1 ||
+        a->cout != 32 || e < 0 || (ek != -2 && e != ek) || k.nChunks < 2 || a->n % 8 || a->n != args[0].n || a->h_out != args[0].h_out || a->w_out != args[0].w_out ||
+        !a->x.planar || !a->y.planar)
+      return set_err(SRGANFD_EINVAL, "conv2d_chain: launch %d is not a 16-bit 3x3 stride-1 32-channel conv of one kind on planar views with a batch that is a multiple of 8", i);
+    ek = e;
+    k.nNb = 1;
+    k.tiles_x = ceil_div(k.Wout, C::TW);
+    k.tiles_y = ceil_div(k.Hout, C::TH);
+    const long long nblk = (long long)k.N * k.tiles_x * k.tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d_chain: bad grid %lld", nblk);
+    k.nblocks = (int)nblk;
+    k.m_nNb = 0;
+    k.m_tx = div_magic((unsigned)k.tiles_x, (unsigned long long)nblk);
+    k.m_ty = div_magic((unsigned)k.tiles_y, (unsigned long long)nblk);
+    ck.tiles_per_xcd[i] = (int)(nblk / 8);
+  }
+  if (g_dry_run) return SRGANFD_OK;
+  SRGANFD_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(unsigned) * 8 * kChainMax * 64, stream));
+  const int lds = C::LDS_BYTES + 16;
+  const int grid = conv_device_cus() * C::WG_PER_CU;
+  auto launch = [&](auto kern) -> int {
+    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    SRGANFD_LAUNCH(kern, dim3((unsigned)grid), dim3(512), (size_t)lds, stream, ck);
+    SRGANFD_HIP_CHECK(hipGetLastError());
+    return SRGANFD_OK;
+  };
+  if (args[0].dtype == SRGANFD_F16) return ek == 0 ? launch(conv_chain_kernel<f16_t, 0>) : launch(conv_chain_kernel<f16_t, 4>);
+  return ek == 0 ? launch(conv_chain_kernel<bf16_t, 0>) : launch(conv_chain_kernel<bf16_t, 4>);
+}
+#endif
 
 int g_igemm_variant = 0;
 #ifdef SRGANFD_EXPERIMENT
@@ -1020,7 +1153,7 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
   }
 }
 
-int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
+int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
   if (!a || !a->x.ptr || !a->y.ptr || !a->w_packed) return set_err(SRGANFD_EINVAL, "conv2d: null pointer");
   if (a->cin <= 0 || a->cin % 32 || a->cout <= 0 || a->cout % 32 || a->cout_store <= 0 || a->cout_store > a->cout)
     return set_err(SRGANFD_EINVAL, "conv2d: cin=%d cout=%d cout_store=%d (need multiples of 32)", a->cin, a->cout, a->cout_store);
@@ -1048,7 +1181,6 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   auto fits = [&](const srganfd_view& v) { return !v.ptr || opix * (size_t)v.cstride < 0x7fffffffULL; };
   if (!fits(a->y) || !fits(a->y2) || !fits(a->r1) || !fits(a->r2) || !fits(a->mask))
     return set_err(SRGANFD_EINVAL, "conv2d: one output-side image is too large for 32-bit element offsets");
-  ConvK k;
   k.x = a->x.ptr; k.y = a->y.ptr; k.y2 = a->y2.ptr; k.y2C = a->y2.cstride; k.y2_c0 = a->y2.c0;
   k.r1 = a->r1.ptr; k.r2 = a->r2.ptr; k.mask = a->mask.ptr; k.w = a->w_packed;
   k.bias = a->bias; k.alpha_dev = a->alpha_dev;
@@ -1080,6 +1212,15 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
   k.dbg = g_debug; k.stamps = g_stamp_buf;
 #endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
+  return SRGANFD_OK;
+}
+
+int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
+  ConvK k;
+  {
+    const int rc = conv_fill_k(a, k);
+    if (rc != SRGANFD_OK) return rc;
+  }
 #ifdef SRGANFD_EXPERIMENT
   {
     bool handled = false;
