@@ -66,9 +66,11 @@ constexpr int sr_hi(int i, int d, int NH) {
 }
 }  // namespace
 
-template <int NT> struct StreamCfg {
+template <int NT, int WS = 1> struct StreamCfg {
   static constexpr int TH = 16, TW = 32, PR = 18, PC = 34, NPIX = PR * PC;
-  static constexpr int NWAVES = 8, NTHR = 512, NH = 2 * NT, NB = 32 * NT;
+  static constexpr int NWAVES = 8 * WS, NTHR = 64 * NWAVES, NH = 2 * NT, NB = 32 * NT;
+  static constexpr int NHW = NH / WS;                            // 16-channel halves per wave (WS = 2: sixteen waves, each half the channels)
+  static_assert(NH % WS == 0, "wave split");
   static constexpr int XPIECES = (NPIX * 64 + 1023) / 1024;     // 39 pieces of 1 KiB per patch
   static constexpr int XBYTES = XPIECES * 1024;
   static constexpr int NSLOT = (XPIECES + NWAVES - 1) / NWAVES; // patch pieces per wave and stage
@@ -83,14 +85,15 @@ template <int NT> struct StreamCfg {
 // EK: epilogue operands fixed at compile time -- bit 1 residual r1, 2 residual r2, 4 LeakyReLU'(mask) -- for dense 16-bit outputs; -1 =
 // every operand decided at run time with per-element guards (fp32 output, partial channel blocks, y2).  WRES: the weight block stays in
 // LDS (one output-channel block per launch), else each stage carries its chunk's slab.
-template <typename T, int NT, int EK, bool WRES>
-__global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
-  using C = StreamCfg<NT>;
+template <typename T, int NT, int EK, bool WRES, int WS = 1>
+__global__ __launch_bounds__(512 * WS, 2 * WS) void conv_stream_kernel(const ConvK a) {
+  using C = StreamCfg<NT, WS>;
   using Frag = typename FragAB<T>::type;
-  constexpr int NH = C::NH;
+  constexpr int NH = C::NHW;        // halves this wave owns; its first one is h0
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = wave / WS, h0 = (wave % WS) * NH;
   constexpr int STAGE = WRES ? C::XBYTES : C::XBYTES + C::WCH;
   char* const ldsW = smem;                                          // WRES: [n-tile][chunk][18 KiB]
   char* const ldsS = smem + (WRES ? a.nChunks * C::WCH : 0);        // stage b at + b * STAGE: patch [, the chunk's slabs [n-tile][18 KiB]]
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
   int colt[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) colt[kx] = ((lane & 15) + kx) * 64 + (((lane >> 4) ^ (((((lane & 15) + kx) >> 2) & 1) << 1)) << 4);
-  const int rowoff = wave * 2 * C::PC * 64;
+  const int rowoff = wrow * 2 * C::PC * 64;
 
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
           bv[nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           if (a.bias) {     // (an offset into a flat parameter buffer: 4-byte alignment only)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[nh][i] = a.bias[cob + 16 * nh + 4 * g4 + i];
+            for (int i = 0; i < 4; ++i) bv[nh][i] = a.bias[cob + 16 * (h0 + nh) + 4 * g4 + i];
           }
         }
         if constexpr (kR1 || kR2 || kMk) {
@@ -224,12 +227,12 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-              const int oy = oy0 + 2 * wave + m, ox = ox0 + 16 * ph + l15;
+              const int oy = oy0 + 2 * wrow + m, ox = ox0 + 16 * ph + l15;
               const bool ok = oy < a.Hout && ox < a.Wout;
               const int p = oy * a.WoutF + ox;
 #pragma unroll
               for (int nh = 0; nh < NH; ++nh) {
-                const int e = (m * 2 + ph) * NH + nh, co = cob + 16 * nh + 4 * g4;
+                const int e = (m * 2 + ph) * NH + nh, co = cob + 16 * (h0 + nh) + 4 * g4;
                 auto ld = [&](const void* base, int Cs, int c0, int ps, int gs) -> u32x2 {
                   const int cc = c0 + co;
                   return ok ? *(const u32x2*)((const T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31))) : u32x2{0u, 0u};
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
 
       // MFMA phase: the chunk's fragment reads and MFMAs in a fixed issue order, every read kPipe fragments ahead of its first use
       const char* ldsXw = ldsS + buf * STAGE + rowoff;
-      const char* ldsWn = (WRES ? ldsW + chunk * C::WT : ldsS + buf * STAGE + C::XBYTES) + lane * 16;
       const int wtile = WRES ? a.nChunks * C::WT : C::WT;           // distance of the n-tiles' slabs
+      const char* ldsWn = (WRES ? ldsW + chunk * C::WT : ldsS + buf * STAGE + C::XBYTES) + lane * 16 + (h0 >> 1) * wtile + (NH == 1 ? (h0 & 1) * 1024 : 0);
       __builtin_amdgcn_s_setprio(1);
 #ifdef SRGANFD_STREAM_PLAIN
       if (!SRGANFD_DBG(a.dbg, 2)) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-          const int oy = oy0 + 2 * wave + m, ox = ox0 + 16 * ph + l15;
+          const int oy = oy0 + 2 * wrow + m, ox = ox0 + 16 * ph + l15;
           const bool ok = oy < a.Hout && ox < a.Wout;
           if (__builtin_amdgcn_ballot_w64(!ok) != 0) full = false;
           const int p = oy * a.WoutF + ox;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
             if constexpr (kR2) {
               if constexpr (kPreR2) widen4(o_r2[e], t4);
               else {
-                const int cc = a.r2_c0 + cob + 16 * nh + 4 * g4;
+                const int cc = a.r2_c0 + cob + 16 * (h0 + nh) + 4 * g4;
                 widen4(ok ? *(const u32x2*)((const T*)a.r2 + img * a.r2C + (p * a.r2_ps + (cc >> 5) * a.r2_gs + (cc & 31))) : u32x2{0u, 0u}, t4);
               }
 #pragma unroll
@@ -359,14 +362,14 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
               pk = u32x2{(unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16), (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16)};
             }
             if (ok && !SRGANFD_DBG(a.dbg, 4)) {
-              const int cc = a.y_c0 + cob + 16 * nh + 4 * g4;
+              const int cc = a.y_c0 + cob + 16 * (h0 + nh) + 4 * g4;
               *(u32x2*)((T*)a.y + img * a.yC + (p * a.y_ps + (cc >> 5) * a.y_gs + (cc & 31))) = pk;
             }
           } else {
             // run-time operands, one element at a time (the 3-channel SR output in fp32, the discriminator's 1-channel logits, y2 launches)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int co = cob + 16 * nh + 4 * g4 + i;
+              const int co = cob + 16 * (h0 + nh) + 4 * g4 + i;
               if (ok && co < a.cout_store) {
                 auto at = [&](int Cs, int c0, int ps, int gs) -> size_t { const int cc = c0 + co; return img * Cs + (size_t)(p * ps + (cc >> 5) * gs + (cc & 31)); };
                 float v = v4[i];
@@ -389,14 +392,16 @@ __global__ __launch_bounds__(512, 2) void conv_stream_kernel(const ConvK a) {
 
 int g_use_stream = [] { const char* e = getenv("SRGANFD_USE_STREAM"); return e ? atoi(e) : 0; }();   // A/B: srganfd_set_igemm_variant bit 11
 
-template <typename T, int NT, int EK, bool WRES>
+int g_stream_ws = [] { const char* e = getenv("SRGANFD_STREAM_WS"); return e ? atoi(e) : 1; }();   // 2: sixteen waves per workgroup, each wave half the output channels (f16, fixed kinds)
+
+template <typename T, int NT, int EK, bool WRES, int WS = 1>
 static int launch_stream(const ConvK& k, int cout, hipStream_t stream) {
-  using C = StreamCfg<NT>;
-  auto kern = conv_stream_kernel<T, NT, EK, WRES>;
+  using C = StreamCfg<NT, WS>;
+  auto kern = conv_stream_kernel<T, NT, EK, WRES, WS>;
   if (g_describe) {
     char ek[8] = "";
     if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
-    snprintf(g_describe, g_describe_len, "conv_stream_kernel<%s,N=%d%s%s>", dtype_name<T>(), C::NB, WRES ? ",WR" : "", ek);
+    snprintf(g_describe, g_describe_len, "conv_stream_kernel<%s,N=%d%s%s%s>", dtype_name<T>(), C::NB, WRES ? ",WR" : "", WS == 2 ? ",W16" : "", ek);
     return SRGANFD_OK;
   }
   const int lds = WRES ? C::resident_bytes(k.nChunks) : C::STREAMED_BYTES;
@@ -428,6 +433,17 @@ static int launch_stream(const ConvK& k, int cout, hipStream_t stream) {
 
 template <typename T, int NT, bool WRES>
 static int launch_stream_kind(const ConvK& k, int cout, int ek, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && Elem<T>::kDtype == SRGANFD_F16) {
+    if (g_stream_ws == 2) {
+      switch (ek) {
+        case 0: return launch_stream<T, NT, 0, WRES, 2>(k, cout, stream);
+        case 1: return launch_stream<T, NT, 1, WRES, 2>(k, cout, stream);
+        case 3: return launch_stream<T, NT, 3, WRES, 2>(k, cout, stream);
+        case 4: return launch_stream<T, NT, 4, WRES, 2>(k, cout, stream);
+        default: break;
+      }
+    }
+  }
   switch (ek) {
     case 0: return launch_stream<T, NT, 0, WRES>(k, cout, stream);
     case 1: return launch_stream<T, NT, 1, WRES>(k, cout, stream);
