@@ -34,8 +34,10 @@
 #ifndef SRGANFD_CROSS_MASK
 #define SRGANFD_CROSS_MASK 7
 #endif
+// fragment read-ahead of the 3x3 stride-1 16x16x32 loop (64-channel tiles; 32-channel tiles one less).  4 since the compile-time epilogue
+// kinds freed the registers: no spills, G-only step 59.07 vs 59.34 ms (3), 5: equal with 3 spilled registers in one kind, 6: spills, +3 %; one or two more for the kinds with epilogue operands only: equal
 #ifndef SRGANFD_M16_PIPE
-#define SRGANFD_M16_PIPE 3
+#define SRGANFD_M16_PIPE 4
 #endif
 
 namespace srganfd {
