@@ -32,6 +32,9 @@ extern "C" {
 #define SRGANFD_ACT_RELU 2
 
 const char* srganfd_last_error(void);
+/* Bumped whenever an exported signature or struct changes; the binding (sr_gan_fd_amd/_abi.py) reads this constant from this
+ * header and refuses a library whose srganfd_abi_version() differs (a stale A/B build selected with SRGANFD_LIB, a prebuilt .so). */
+#define SRGANFD_ABI_VERSION 4
 int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
@@ -283,7 +286,7 @@ int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp
                      int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, const float* skip_flag,
                      const float* grad_scale_dev /* or NULL: multiplies grad_scale (1 / loss scale from the scaler state) */, void* stream);
 /* torch.amp.GradScaler.update() on a device-resident state (torch keeps its scale on the device as well, so that neither the host nor a
- * captured graph carries a stale value): state = 8 floats {scale, 1 / scale, growth tracker, optimizer steps, skipped steps, 0, 0, 0}.
+ * captured graph carries a stale value): state = 8 words {float scale, float 1 / scale, int32 growth tracker, int32 optimizer steps, int32 skipped steps, 0, 0, 0}.
  * *found_inf != 0: scale *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth_factor (kept if that
  * would overflow), tracker = 0.  Loss kernels read state[0] as grad_scale_dev, the Adam kernels state[1]; train_bsrgan.py:109,436-437,466-467. */
 int srganfd_loss_scale_update(float* state, const float* found_inf, float growth_factor, float backoff_factor,

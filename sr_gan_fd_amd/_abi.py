@@ -11,6 +11,20 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRGANFD_LIB") or os.path.join(_HERE, "libsrganfd_hip.so")   # SRGANFD_LIB: A/B kernel builds (tools/)
 
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "srganfd.h")
+
+
+def _header_abi_version() -> int:
+    """SRGANFD_ABI_VERSION of include/srganfd.h: the one constant the library and this binding share."""
+    import re
+    with open(HEADER) as f:
+        m = re.search(r"^#define\s+SRGANFD_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise RuntimeError(f"{HEADER}: SRGANFD_ABI_VERSION not found")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 BF16, F32, F16 = 0, 1, 2
 DT_NAME = {BF16: "bf16", F32: "f32", F16: "f16"}
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
@@ -168,6 +182,8 @@ SN_GRAD_WS_FLOATS = 1028               # srganfd_spectral_norm_grad: 1025, kept 
 def sn_ws_floats(rows: int, cols: int) -> int:
     """workspace of one srganfd_spectral_norm job (16-byte aligned)"""
     return ((rows + 31) // 32 * cols + rows + 3) // 4 * 4
+
+
 _lib = None
 
 
@@ -185,6 +201,12 @@ def lib():
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
         import torch  # noqa: F401  (loads the HIP runtime the extension must share)
         l = C.CDLL(LIB_PATH)
+        l.srganfd_abi_version.restype, l.srganfd_abi_version.argtypes = C.c_int, []
+        have = l.srganfd_abi_version()
+        if have != ABI_VERSION:
+            raise SrganfdError(f"{LIB_PATH} implements ABI version {have}, this binding (include/srganfd.h) version {ABI_VERSION}: "
+                               "argument lists differ -- rebuild it (`python __graft_entry__.py --force`, or tools/build_variant.sh for an "
+                               "SRGANFD_LIB variant)")
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)
             fn.restype = res

@@ -104,7 +104,7 @@ using namespace srganfd;
 extern "C" {
 
 const char* srganfd_last_error(void) { return g_err; }
-int srganfd_abi_version(void) { return 3; }
+int srganfd_abi_version(void) { return SRGANFD_ABI_VERSION; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 int srganfd_get_mfma16(void) { return srganfd::g_mfma16; }
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganfd::conv_uses_m16(dtype, ksize, n) ? 1 : 0; }

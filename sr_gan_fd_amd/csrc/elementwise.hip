@@ -1674,22 +1674,25 @@ int adam_ema_impl(float* p, const float* g, float* m, float* v, float* ema, size
 }
 
 // torch.amp.GradScaler.update() (torch/amp/grad_scaler.py, _amp_update_scale_) on a device-resident state, so that neither the host nor a
-// captured graph ever carries a stale scale: state = {scale, 1 / scale, growth tracker, optimizer steps, skipped steps}.
+// captured graph ever carries a stale scale: state = {scale, 1 / scale, growth tracker, optimizer steps, skipped steps}.  The three
+// counters are int32 words of the same 8-word state (a float stops counting at 2^24 steps; torch's tracker is an int32 tensor too).
 __global__ void loss_scale_update_kernel(float* __restrict__ st, const float* __restrict__ found_inf, float growth, float backoff, int interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float scale = st[0], tracker = st[2];
-  st[3] += 1.f;
+  int* sti = reinterpret_cast<int*>(st);
+  float scale = st[0];
+  int tracker = sti[2];
+  sti[3] += 1;
   if (*found_inf != 0.f) {
-    scale *= backoff; tracker = 0.f; st[4] += 1.f;
+    scale *= backoff; tracker = 0; sti[4] += 1;
   } else {
-    tracker += 1.f;
-    if (tracker >= (float)interval) {
+    tracker += 1;
+    if (tracker >= interval) {
       const float grown = scale * growth;
       if (fabsf(grown) <= 3.402823466e38f) scale = grown;       // torch keeps the scale when growing it would overflow
-      tracker = 0.f;
+      tracker = 0;
     }
   }
-  st[0] = scale; st[1] = 1.f / scale; st[2] = tracker;
+  st[0] = scale; st[1] = 1.f / scale; sti[2] = tracker;
 }
 int loss_scale_update_impl(float* state, const float* found_inf, float growth, float backoff, int interval, hipStream_t s) {
   if (!state || !found_inf || interval < 1 || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f)) return set_err(SRGANFD_EINVAL, "loss_scale_update: bad args");

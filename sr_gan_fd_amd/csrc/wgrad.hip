@@ -735,7 +735,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.ntasks = (int)pb.tasks.size();
   // pixel-tile splits: aim at ~2 workgroups per CU over the whole launch
   int S = s->splits;
-  if (S <= 0) { S = 256 / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, ONE round: never more workgroups than CUs
+  if (S <= 0) { S = conv_device_cus() / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, ONE round: never more workgroups than the device has CUs (256 in dry runs)
   if (S > H.ntiles) S = H.ntiles;
   if (S > 4096) S = 4096;
   H.S = S;

@@ -40,8 +40,24 @@ def _require_gpu(x: Tensor) -> None:
     A.lib()
 
 
+def resolve_compute_dtype(module) -> torch.dtype:
+    """The reference's precision contract for its modules: a forward issued inside ``torch.autocast("cuda")`` (the training loops'
+    ``amp.autocast()``, train_bsrgan.py:415-427,450-457; ESRGAN's validation too, train_rrdbnet.py:324-325) computes in the autocast
+    dtype -- float16 by default, what the reference's convs run in on a GPU -- and one issued outside it (``validate()``,
+    train_bsrgan.py:563; inference.py:60-70) in float32.  ``module.compute_dtype`` (None by default) overrides both.  The backward
+    pass always runs in the dtype of the forward whose activations it consumes (the plan's), as autograd does under autocast."""
+    dt = getattr(module, "compute_dtype", None)
+    if dt is not None:
+        return dt
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return torch.float32
+
+
 def _dt(module) -> Tuple[torch.dtype, int]:
-    dt = getattr(module, "compute_dtype", torch.bfloat16)
+    dt = resolve_compute_dtype(module)
+    if dt not in ops.DT:
+        raise A.SrganfdError(f"compute dtype {dt} is not supported (float32, float16, bfloat16)")
     return dt, ops.DT[dt]
 
 

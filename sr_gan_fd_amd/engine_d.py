@@ -393,7 +393,9 @@ class ContentLossEngine:
             sp.xin = torch.empty(2 * N, H, W, 32, dtype=dt, device=dev)
             sp.bufs = {}
             sp.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
+            sp.dt, sp.dtc = dt, dtc
             self.shapes[key] = sp
+        self._last = sp
         mean, std = self.owner.mean, self.owner.std
         for img, half in ((sr, 0), (gt, 1)):
             img = img.detach().contiguous().float()

@@ -21,10 +21,10 @@ from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
 from .parallel import BucketReducer, SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
-from .trainer import FlatAdamEMA, LossScaler, check_loss_scaling, needs_loss_scaling
+from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling
 
 
-class GanTrainer:
+class GanTrainer(GanCheckpointMixin):
     def __init__(self, g_model, d_model, content_criterion=None, *, g_lr: float = 8e-5, d_lr: float = 2e-4, betas=(0.9, 0.999),
                  eps: float = 1e-4, weight_decay: float = 0.0, ema_decay: float = 0.999, pixel_weight: float = 20.0,
                  content_weight=1.0, adversarial_weight: float = 0.5, train_generator: bool = True, process_group=None,
@@ -69,29 +69,6 @@ class GanTrainer:
 
     def _allreduce(self, grad: Tensor) -> float:
         return allreduce_sum_(grad, self.pg)
-
-    def state_dict(self) -> dict:
-        """Trainer-side entries of the reference's two checkpoint files (train_bsrgan.py:203-260: d_*.pth.tar holds the
-        discriminator + its optimizer, g_*.pth.tar the generator + optimizer + EMA), keyed "g" / "d"."""
-        g = {"state_dict": self.g.state_dict(), "optimizer": self.g_opt.state_dict()}
-        if self.g_opt.ema is not None:
-            g["ema_state_dict"] = self.g_opt.ema_state_dict()
-        return {"g": g, "d": {"state_dict": self.d.state_dict(), "optimizer": self.d_opt.state_dict()}}
-
-    def load_state_dict(self, ckpt: dict) -> None:
-        with torch.no_grad():
-            for net, eng, opt, c in ((self.g, self.ge, self.g_opt, ckpt.get("g")), (self.d, self.de, self.d_opt, ckpt.get("d"))):
-                if c is None:
-                    continue
-                own = net.state_dict()
-                for k, v in c["state_dict"].items():        # spectral-norm u / v buffers included
-                    if k in own and tuple(own[k].shape) == tuple(v.shape):
-                        own[k].copy_(v)
-                eng.fp.touch()
-                if "optimizer" in c:
-                    opt.load_state_dict(c["optimizer"])
-                if "ema_state_dict" in c and opt.ema is not None:
-                    opt.load_ema_state_dict(c["ema_state_dict"])
 
     def _bce(self, logits: Tensor, target: float, weight: float, slot: int, prob_slot: Optional[int], dlogits: Tensor) -> None:
         """loss value weighted by ``weight``; its gradient by ``weight`` times the loss scale the device holds when the kernel runs

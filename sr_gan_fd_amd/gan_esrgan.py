@@ -26,10 +26,10 @@ from .engine import _engine, generator_engine
 from .engine_e import esrgan_discriminator_engine
 from .engine_v import ContentLossGradEngine
 from .parallel import BucketReducer, allreduce_sum_
-from .trainer import FlatAdamEMA, LossScaler, check_loss_scaling, needs_loss_scaling
+from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling
 
 
-class EsrganGanTrainer:
+class EsrganGanTrainer(GanCheckpointMixin):
     def __init__(self, g_model, d_model, content_criterion=None, *, g_lr: float = 1e-4, d_lr: float = 1e-4, betas=(0.9, 0.99),
                  eps: float = 1e-8, weight_decay: float = 0.0, ema_decay: Optional[float] = 0.99998, pixel_weight: float = 0.01,
                  content_weight: float = 1.0, adversarial_weight: float = 0.005, process_group=None):
@@ -45,6 +45,8 @@ class EsrganGanTrainer:
         self.d_opt = FlatAdamEMA(self.de.fp.sync(dev), d_lr, betas, eps, weight_decay, None, layout=self.de.fp)
         self.pw, self.cw, self.aw = float(pixel_weight), float(content_weight), float(adversarial_weight)
         self.scaler = LossScaler(dev, enabled=needs_loss_scaling(g_model, d_model, content_criterion))
+        # Under data parallelism the discriminator's BatchNorm layers (ESRGAN/model.py:98-126) use per-rank batch statistics, which is
+        # what the unconverted reference does under DistributedDataParallel; there is no SyncBatchNorm hook for this discriminator.
         self.pg = process_group
         self.g_reducer = BucketReducer(dev, process_group)
         # [d_loss, pixel, content, adversarial, D(gt) prob, D(sr) prob, 0, 0]  (train_esrgan.py:416,430-431)

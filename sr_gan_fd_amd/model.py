@@ -11,9 +11,12 @@ the reference's parameter names, shapes, construction order and therefore the sa
 init.  Their ``forward`` is never called -- ``forward`` here hands the parameters to the HIP engine
 (``engine.py``), which raises if libsrganfd_hip.so or a GPU is missing (no CPU fallback).
 
-Knobs beyond the reference (all optional, defaults keep reference behaviour):
-  ``compute_dtype``  torch.bfloat16 (default on GPU; the reference trains under autocast) or
-                     torch.float32 (exact-fp32 MFMA "parity mode" used against the CPU oracle).
+Precision follows the reference's own contract (``engine.resolve_compute_dtype``): inside ``torch.autocast("cuda")`` -- the
+train loops' ``amp.autocast()``, train_bsrgan.py:415-427,450-457 -- the kernels compute in the autocast dtype (float16 unless
+the caller asked autocast for bfloat16: f16 MFMA, fp32 accumulate, fp32 master weights, fp32 SR / logits); outside it --
+``validate()``, train_bsrgan.py:563, inference.py -- in float32 (exact-fp32 MFMA, the mode every golden vector is met in).
+One knob beyond the reference: ``compute_dtype`` (default ``None`` = follow autocast) pins a module to torch.float32 /
+float16 / bfloat16 whatever the autocast state; the fused trainers and bench.py set it explicitly.
 """
 from __future__ import annotations
 
@@ -51,7 +54,7 @@ class _ResidualDenseBlock(nn.Module):
                     module.weight.data *= 0.1
                     if module.bias is not None:
                         nn.init.constant_(module.bias, 0)
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def forward(self, x: Tensor) -> Tensor:
         from .engine import trunk_apply
@@ -66,7 +69,7 @@ class _ResidualResidualDenseBlock(nn.Module):
         self.rdb1 = _ResidualDenseBlock(channels, growth_channels, self_init)
         self.rdb2 = _ResidualDenseBlock(channels, growth_channels, self_init)
         self.rdb3 = _ResidualDenseBlock(channels, growth_channels, self_init)
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def forward(self, x: Tensor) -> Tensor:
         from .engine import trunk_apply
@@ -98,7 +101,7 @@ class _RRDBGenerator(nn.Module):
                 module.weight.data *= 0.1
                 if module.bias is not None:
                     nn.init.constant_(module.bias, 0)
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def n_upsample(self) -> int:
         return {1: 0, 2: 1, 4: 2, 8: 3}[self.upscale_factor]
@@ -155,7 +158,7 @@ class DiscriminatorUNet(nn.Module):
         self.conv2 = sn(channels, channels, 3, 1)
         self.conv3 = sn(channels, channels, 3, 1)
         self.conv4 = nn.Conv2d(channels, out_channels, (3, 3), (1, 1), (1, 1))
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def forward(self, x: Tensor) -> Tensor:
         return self._forward_impl(x)
@@ -190,7 +193,7 @@ class ContentLoss(nn.Module):
         self.register_buffer("std", torch.tensor(feature_model_normalize_std, dtype=torch.float32))
         for p in self.features.parameters():
             p.requires_grad = False
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def forward(self, sr_tensor: Tensor, gt_tensor: Tensor) -> Tensor:
         assert sr_tensor.size() == gt_tensor.size(), "Two tensor must have the same size"
@@ -244,7 +247,7 @@ class UNetDiscriminatorAesrgan(nn.Module):
         self.conv7 = norm(nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=False))
         self.conv8 = norm(nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=False))
         self.conv9 = nn.Conv2d(num_feat, 1, 3, 1, 1)
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
         self.ly1 = self.ly2 = self.ly3 = None
 
     def forward(self, x: Tensor) -> Tensor:
@@ -269,7 +272,7 @@ class Discriminator(nn.Module):
             cin = cout
         self.features = nn.Sequential(*layers)
         self.classifier = nn.Sequential(nn.Linear(512 * 4 * 4, 100), nn.LeakyReLU(0.2, True), nn.Linear(100, 1))
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None
 
     def forward(self, x: Tensor) -> Tensor:
         from .engine_e import esrgan_discriminator_apply

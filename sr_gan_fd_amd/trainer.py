@@ -42,7 +42,6 @@ class LossScaler:
                  growth_interval: int = 2000):
         self.enabled = enabled
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
-        self._host_scale = float(init_scale) if enabled else 1.0       # only for a disabled scaler / before the first report
         if enabled:
             self.state = torch.zeros(8, dtype=torch.float32, device=device)
             self.state[0] = float(init_scale)
@@ -90,7 +89,8 @@ class LossScaler:
         if not self.enabled:
             return {"enabled": False, "scale": 1.0, "optimizer_steps": 0, "skipped": 0}
         st = self.state.cpu()
-        return {"enabled": True, "scale": float(st[0]), "optimizer_steps": int(st[3]), "skipped": int(st[4])}
+        cnt = st.view(torch.int32)                 # words 2..4 are int32 counters (a float would stop counting at 2^24 steps)
+        return {"enabled": True, "scale": float(st[0]), "optimizer_steps": int(cnt[3]), "skipped": int(cnt[4])}
 
     @property
     def n_steps(self) -> int:
@@ -104,14 +104,18 @@ class LossScaler:
         """torch GradScaler.state_dict() keys (the reference does not checkpoint its scaler; kept for symmetry)."""
         st = self.state.cpu() if self.enabled else None
         return {"scale": float(st[0]) if st is not None else 1.0, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
-                "growth_interval": self.growth_interval, "_growth_tracker": int(st[2]) if st is not None else 0}
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st.view(torch.int32)[2]) if st is not None else 0}
 
     def load_state_dict(self, sd: dict) -> None:
+        """torch GradScaler.load_state_dict: scale, tracker and the three hyper-parameters state_dict() saves"""
+        self.growth_factor = float(sd.get("growth_factor", self.growth_factor))
+        self.backoff_factor = float(sd.get("backoff_factor", self.backoff_factor))
+        self.growth_interval = int(sd.get("growth_interval", self.growth_interval))
         if self.enabled:
             sc = float(sd["scale"])
             self.state[0] = sc
             self.state[1] = 1.0 / sc
-            self.state[2] = float(int(sd.get("_growth_tracker", 0)))
+            self.state.view(torch.int32)[2] = int(sd.get("_growth_tracker", 0))
 
 
 class MultiStepLR:
@@ -155,15 +159,19 @@ class MultiStepLR:
 
 
 def needs_loss_scaling(*modules) -> bool:
-    return any(getattr(m, "compute_dtype", None) == torch.float16 for m in modules if m is not None)
+    """float16 is the one mode that needs GradScaler's part played: an explicit ``compute_dtype`` or -- the default -- the dtype of
+    the autocast region the trainer is built and stepped in (engine.resolve_compute_dtype)."""
+    from .engine import resolve_compute_dtype
+    return any(resolve_compute_dtype(m) == torch.float16 for m in modules if m is not None)
 
 
 def check_loss_scaling(scaler: "LossScaler", *modules) -> None:
-    """``compute_dtype`` is a plain attribute of the modules: switched to float16 AFTER the trainer was built, training would run f16
-    with the scaler disabled and the gradients would silently underflow.  Checked at every step (an attribute read per module)."""
+    """``compute_dtype`` is a plain attribute of the modules (and autocast a thread-local state): switched to float16 AFTER the trainer
+    was built, training would run f16 with the scaler disabled and the gradients would silently underflow.  Checked at every step
+    (an attribute read per module)."""
     if not scaler.enabled and needs_loss_scaling(*modules):
-        raise A.SrganfdError("compute_dtype was set to torch.float16 after the trainer was built: its loss scaler is disabled "
-                             "(gradients would underflow) -- set the dtype first, then build the trainer")
+        raise A.SrganfdError("compute_dtype was set to torch.float16 (or a float16 autocast region entered) after the trainer was built: "
+                             "its loss scaler is disabled (gradients would underflow) -- set the dtype first, then build the trainer")
 
 
 class FlatAdamEMA:
@@ -283,6 +291,36 @@ class FlatAdamEMA:
                                          self.ema.data_ptr() if self.ema is not None else None, self.flat.numel(), self.lr,
                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale,
                                          self.ema_decay or 0.0, mode, None, grad_scale_dev, A.stream_ptr()), "adam_ema")
+
+
+class GanCheckpointMixin:
+    """state_dict() / load_state_dict() of the two-network trainers (gan.GanTrainer, gan_esrgan.EsrganGanTrainer): the trainer-side
+    entries of the reference's two checkpoint files (train_bsrgan.py:203-260, ESRGAN/train_esrgan.py:216-262: d_*.pth.tar holds the
+    discriminator + its optimizer, g_*.pth.tar the generator + optimizer + EMA), keyed "g" / "d"; "scaler" is an addition (the
+    reference does not checkpoint its GradScaler and restarts it at 65536).  Needs self.g / .d / .ge / .de / .g_opt / .d_opt / .scaler."""
+
+    def state_dict(self) -> dict:
+        g = {"state_dict": self.g.state_dict(), "optimizer": self.g_opt.state_dict()}
+        if self.g_opt.ema is not None:
+            g["ema_state_dict"] = self.g_opt.ema_state_dict()
+        return {"g": g, "d": {"state_dict": self.d.state_dict(), "optimizer": self.d_opt.state_dict()}, "scaler": self.scaler.state_dict()}
+
+    def load_state_dict(self, ckpt: dict) -> None:
+        with torch.no_grad():
+            for net, eng, opt, c in ((self.g, self.ge, self.g_opt, ckpt.get("g")), (self.d, self.de, self.d_opt, ckpt.get("d"))):
+                if c is None:
+                    continue
+                own = net.state_dict()
+                for k, v in c["state_dict"].items():        # spectral-norm u / v and BatchNorm running statistics included
+                    if k in own and tuple(own[k].shape) == tuple(v.shape):
+                        own[k].copy_(v)
+                eng.fp.touch()
+                if "optimizer" in c:
+                    opt.load_state_dict(c["optimizer"])
+                if "ema_state_dict" in c and opt.ema is not None:
+                    opt.load_ema_state_dict(c["ema_state_dict"])
+        if "scaler" in ckpt:
+            self.scaler.load_state_dict(ckpt["scaler"])
 
 
 class GeneratorTrainer:

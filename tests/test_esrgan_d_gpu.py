@@ -355,3 +355,38 @@ def test_esrgan_fused_trainer_f16_stays_close_to_f32():
     err = np.abs(a - b) / np.maximum(np.abs(a), 1e-6)
     print("f32", a, "f16", b, "rel", err)
     assert err[[0, 1, 3, 4, 5]].max() < 5e-3
+
+
+def test_esrgan_fused_trainer_checkpoint_resume_is_bitwise():
+    """EsrganGanTrainer.state_dict() / load_state_dict() (ESRGAN/train_esrgan.py:216-262 checkpoints g, d, both optimizers and the EMA
+    model every epoch and resumes from them): a trainer rebuilt from fresh modules + the checkpoint takes bitwise the same third
+    iteration as the one that kept running -- weights, BatchNorm running statistics, Adam moments and step, EMA, loss scale."""
+    from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+    torch.manual_seed(11)
+    data = [(torch.rand(2, 3, 32, 32).cuda(), torch.rand(2, 3, 128, 128).cuda()) for _ in range(3)]
+    gen, d = _esrgan_pair(torch.float16)
+    tr = EsrganGanTrainer(gen, d, None)
+    for lr, gt in data[:2]:
+        tr.step(lr, gt)
+    ckpt = tr.state_dict()
+    assert set(ckpt) == {"g", "d", "scaler"} and set(ckpt["g"]) == {"state_dict", "optimizer", "ema_state_dict"}
+    assert int(ckpt["g"]["ema_state_dict"]["n_averaged"]) == 2 and len(ckpt["d"]["optimizer"]["state"]) == len(list(d.parameters()))
+    ckpt = {k: ({kk: (vv if not torch.is_tensor(vv) else vv.clone()) for kk, vv in v.items()} if k != "scaler" else dict(v)) for k, v in ckpt.items()}
+    ckpt["g"]["state_dict"] = {k: v.clone() for k, v in ckpt["g"]["state_dict"].items()}
+    ckpt["d"]["state_dict"] = {k: v.clone() for k, v in ckpt["d"]["state_dict"].items()}
+    ckpt["scaler"]["scale"] = 4096.0                       # a value the fresh trainer would not start with
+    tr.scaler.scale = 4096.0
+    gen2, d2 = _esrgan_pair(torch.float16)
+    with torch.no_grad():
+        for p in list(gen2.parameters()) + list(d2.parameters()):
+            p.add_(0.01)                                   # the checkpoint, not the seed, must provide the weights
+    tr2 = EsrganGanTrainer(gen2, d2, None)
+    tr2.load_state_dict(ckpt)
+    assert tr2.scaler.scale == 4096.0 and tr2.g_opt.n_averaged == 2
+    a = tr.step(*data[2]).clone()
+    b = tr2.step(*data[2]).clone()
+    assert torch.equal(a, b)
+    assert torch.equal(tr.g_opt.flat, tr2.g_opt.flat) and torch.equal(tr.d_opt.flat, tr2.d_opt.flat)
+    assert torch.equal(tr.g_opt.ema, tr2.g_opt.ema) and torch.equal(tr.g_opt.m, tr2.g_opt.m) and torch.equal(tr.d_opt.v, tr2.d_opt.v)
+    for (k, x), (_, y) in zip(d.state_dict().items(), d2.state_dict().items()):
+        assert torch.equal(x, y), k

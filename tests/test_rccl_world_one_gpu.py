@@ -11,6 +11,8 @@ import textwrap
 
 import pytest
 
+from tests.util import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -68,6 +70,6 @@ CHILD = textwrap.dedent("""
 
 def test_one_rank_rccl_group_leaves_every_step_bit_identical():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "RCCL-WORLD-ONE-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -12,6 +12,8 @@ import textwrap
 
 import pytest
 
+from tests.util import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -97,7 +99,7 @@ CHILD = textwrap.dedent("""
 
 def test_two_gloo_ranks_on_one_gpu_equal_the_whole_batch_run():
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29683", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = []
     for r in range(2):
         env = dict(base, RANK=str(r))

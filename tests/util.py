@@ -38,3 +38,11 @@ def sd_to_params(sd, grad=False, d=False):
             t.requires_grad_(True)
         P[k] = t
     return P
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on right now (bind to 0, read it back): rendezvous ports that do not collide under parallel runs"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
