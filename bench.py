@@ -147,6 +147,10 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
                     help="compute dtype of activations / packed weights / gradients (fp32 master weights and accumulation); f16 is what the "
                          "reference's amp.autocast() computes in and the mode whose SR meets the 1e-3 tolerance (with its GradScaler)")
+    ap.add_argument("--module-loop", action="store_true",
+                    help="g_only / gan: time the reference's own loop statements (torch.optim.Adam, AveragedModel, amp.autocast + GradScaler, "
+                         "autograd) over the drop-in modules instead of the fused trainer; the default run reports both")
+    ap.add_argument("--no-module-loop", action="store_true", help="default run: skip the module-level legs under \"extra\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -184,11 +188,27 @@ def main():
             raise SystemExit("bench.py: all-reduce of ones gave %d, world size %d" % (int(ones.item()), world))
 
     workloads = ["g_only", "gan"] if args.workload == "both" else [args.workload]
-    results = [run_workload(args, wl, rank, world, dev, pg) for wl in workloads]
+    results = [run_workload(args, wl, rank, world, dev, pg, module_loop=args.module_loop) for wl in workloads]
     out = results[0]
     if len(results) > 1 and rank == 0:
-        out["gan"] = {k: results[1][k] for k in ("value", "unit", "ms_per_step", "config", "step_tflops_per_gpu", "loss_scale", "last_step_scalars", "roofline", "kernel_classes")
+        out["gan"] = {k: results[1][k] for k in ("value", "unit", "ms_per_step", "config", "step_tflops_per_gpu", "loss_scale", "last_step_scalars", "roofline", "kernel_classes",
+                                                 "exposed_comm_ms_per_step")
                       if k in results[1]}
+    if args.workload == "both" and world == 1 and not args.module_loop and not args.no_module_loop:
+        # the module-level (drop-in) path next to the fused trainers: the reference's loop statements over the mirror modules, a short
+        # timed region of its own (train_bsrnet.py:244-272, train_bsrgan.py:387-483)
+        import copy
+        margs = copy.copy(args)
+        margs.steps, margs.warmup, margs.no_kernel_events = min(args.steps, 5), min(args.warmup, 2), True
+        extra = {}
+        for wl, fused in zip(workloads, results):
+            r = run_workload(margs, wl, rank, world, dev, pg, module_loop=True)
+            extra[wl] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"], "steps": margs.steps, "warmup": margs.warmup,
+                         "fused_ms_per_step": fused["ms_per_step"], "module_over_fused": round(r["ms_per_step"] / fused["ms_per_step"], 4),
+                         "loss_scale": r.get("loss_scale"), "last_step_scalars": r.get("last_step_scalars")}
+        out["extra"] = {"module_loop": extra,
+                        "what": "the reference's loop statements (amp.autocast + GradScaler, torch.optim.Adam, AveragedModel, autograd) over the drop-in "
+                                "modules with nothing set on them; the headline fields are the fused trainers"}
     if rank == 0:
         h = args.lr_size or BASE_LR_SIZE[workloads[0]]
         if not args.no_cpu_baseline and world == 1:      # host-side legs: rank 0 of the single-GPU run only
@@ -204,7 +224,7 @@ def main():
 DTYPES = {"f16": "float16", "bf16": "bfloat16", "f32": "float32"}
 
 
-def run_workload(args, workload, rank, world, dev, pg):
+def run_workload(args, workload, rank, world, dev, pg, module_loop=False):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks."""
     import torch
     import torch.distributed as dist
@@ -221,7 +241,12 @@ def run_workload(args, workload, rank, world, dev, pg):
     g.compute_dtype = cdt
     g.to(dev)
     trainer = None
-    if workload == "esrgan_gan":
+    if module_loop:
+        if workload not in ("g_only", "gan") or world > 1:
+            raise SystemExit("--module-loop: g_only / gan on one GPU")
+        g.compute_dtype = None                    # the modules follow the loop's own autocast, as in the unchanged scripts
+        step_fn = module_level_loop(workload, M, g, dev, cdt)
+    elif workload == "esrgan_gan":
         if world > 1 or h != 32:
             raise SystemExit("esrgan_gan: single GPU, 32 -> 128 only (the discriminator's classifier fixes the 128x128 input, ESRGAN/model.py:118-122)")
         if args.esrgan_module_loop:
@@ -272,10 +297,13 @@ def run_workload(args, workload, rank, world, dev, pg):
                 gt_usm, gt_, lr_ = imgproc.degradation_process(gt_batch, k21, k21, k21, 4, REALESRGAN_DEGRADATION, jpeg, usm)
                 return trainer.step(lr_, gt_, gt_usm)
 
+    # a fresh batch per step from the seeded generator -- all of them resident in HBM before the timed region starts
+    # (at most 32 distinct batches, 3.4 GB at the default size; longer runs cycle through them)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    lr_img = torch.rand(B, 3, h, h, device=dev, generator=gen)
-    gt = torch.rand(B, 3, 4 * h, 4 * h, device=dev, generator=gen)
+    n_batches = max(1, min(args.steps, 32))
+    batches = [(torch.rand(B, 3, h, h, device=dev, generator=gen), torch.rand(B, 3, 4 * h, 4 * h, device=dev, generator=gen)) for _ in range(n_batches)]
+    lr_img, gt = batches[0]
 
     def barrier():
         if world > 1:
@@ -287,14 +315,18 @@ def run_workload(args, workload, rank, world, dev, pg):
         step_fn(lr_img, gt)
         torch.cuda.synchronize()
         log("warm-up step %d done" % i)
+    from sr_gan_fd_amd import parallel
     barrier()
     rec = None if args.no_kernel_events else profiling.enable()
+    meter = parallel.WaitMeter() if world > 1 else None       # N > 1: how long the main stream stalls for each gradient exchange
+    parallel.METER = meter
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
-        last = step_fn(lr_img, gt)
+    for i in range(args.steps):
+        last = step_fn(*batches[i % n_batches])
     barrier()
     dt = time.perf_counter() - t0
+    parallel.METER = None
     profiling.disable()
     log("%s: timed region done: %.1f ms/step" % (workload, dt / args.steps * 1e3))
     if world > 1:
@@ -307,7 +339,8 @@ def run_workload(args, workload, rank, world, dev, pg):
     out = {
         "metric": "SR training images/sec (%d->%d x4, %s)" % (h, 4 * h, args.dtype), "value": round(value, 3), "unit": "img/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic (%d distinct seeded batches, resident in HBM before the timed region)" % n_batches,
         "config": {"workload": {"g_only": "BSRGAN RRDBNet x4 generator-only (L1), %d RRDB, batch %d/GPU, %d->%d",
                                 "gan": "BSRGAN full GAN step (RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "aesrgan_gan": "A-ESRGAN full GAN step (RRDBNet %d RRDB + attention U-Net D + VGG19 content), batch %d/GPU, %d->%d",
@@ -320,6 +353,19 @@ def run_workload(args, workload, rank, world, dev, pg):
                    "flop_per_image": flop_img},
         "step_tflops_per_gpu": round(value / world * flop_img / 1e12, 2),
     }
+    if meter is not None:
+        # exposed communication: time the main stream waited at BucketReducer.finish() / SideStreamReducer.wait() (HIP event pairs),
+        # max over ranks like the step time
+        exp = meter.report(args.steps)
+        t = torch.tensor([exp.get("g_grad_exchange", 0.0), exp.get("d_grad_exchange_and_adam", 0.0)], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["exposed_comm_ms_per_step"] = {"g_grad_exchange": round(t[0].item(), 4), "d_grad_exchange_and_adam": round(t[1].item(), 4),
+                                           "what": "main-stream stall at the reducers' wait points, max over ranks"}
+    if module_loop:
+        out["config"]["loop"] = "module-level: the reference's statements over the drop-in modules (autocast + GradScaler + torch.optim.Adam + AveragedModel)"
+        sc = getattr(step_fn, "scaler", None)
+        if sc is not None and sc.is_enabled():
+            out["loss_scale"] = {"enabled": True, "scale": sc.get_scale()}
     scaler = getattr(trainer, "scaler", None)
     if scaler is not None:
         out["loss_scale"] = scaler.report()
@@ -339,6 +385,84 @@ def run_workload(args, workload, rank, world, dev, pg):
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def module_level_loop(workload, M, g, dev, cdt):
+    """The reference's loop bodies as written -- BSRGAN/train_bsrnet.py:244-272 (g_only) and train_bsrgan.py:387-483 (gan): amp.autocast
+    around the forwards, ONE GradScaler, torch.optim.Adam, AveragedModel with the scripts' avg_fn, autograd incl. retain_graph -- over
+    the drop-in modules, which take their precision from that autocast (nothing is set on them).  The scripts' five ``.item()`` reads per
+    iteration (train_bsrgan.py:479-483) are deferred: the step returns the device scalars."""
+    import torch
+    from torch import amp
+    from torch.optim.swa_utils import AveragedModel
+    g.train()
+    use_amp = cdt != torch.float32
+    ac = lambda: amp.autocast("cuda", dtype=cdt, enabled=use_amp)
+    scaler = amp.GradScaler("cuda", enabled=cdt == torch.float16)      # bf16 / f32: inert, as on the reference's CPU path
+    ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - 0.999) * a + 0.999 * p)
+    l1 = torch.nn.L1Loss()
+    if workload == "g_only":
+        g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)      # bsrnet_config.py:86-96
+        pw = torch.Tensor([1.0]).to(dev)
+
+        def step(lr, gt):
+            g.zero_grad(set_to_none=True)
+            with ac():
+                sr = g(lr)
+                loss = torch.sum(torch.mul(pw, l1(sr, gt)))
+            scaler.scale(loss).backward()
+            scaler.step(g_opt)
+            scaler.update()
+            ema.update_parameters(g)
+            return loss.detach().reshape(1)
+        step.scaler = scaler
+        return step
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64).to(dev).train()
+    cl = M.ContentLoss(NODES, MEAN, STD).to(dev)
+    d_opt = torch.optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)         # bsrgan_config.py:147-151
+    g_opt = torch.optim.Adam(g.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
+    bce = torch.nn.BCEWithLogitsLoss()
+    pw, cw, aw = (torch.Tensor(w).to(dev) for w in ([20.0], [1.0], [0.5]))          # bsrgan_config.py:137-143
+
+    def step(lr, gt):
+        B, _, H, W = gt.shape
+        real = torch.full([B, 1, H, W], 1.0, dtype=gt.dtype, device=dev)
+        fake = torch.full([B, 1, H, W], 0.0, dtype=gt.dtype, device=dev)
+        for p in d.parameters():
+            p.requires_grad = True
+        d.zero_grad(set_to_none=True)
+        with ac():
+            gt_output = d(gt)
+            d_loss_hr = bce(gt_output, real)
+        scaler.scale(d_loss_hr).backward(retain_graph=True)
+        with ac():
+            sr = g(lr)
+            sr_output = d(sr.detach().clone())
+            d_loss_sr = bce(sr_output, fake)
+        scaler.scale(d_loss_sr).backward()
+        d_loss = d_loss_hr + d_loss_sr
+        scaler.step(d_opt)
+        scaler.update()
+        for p in d.parameters():
+            p.requires_grad = False
+        g.zero_grad(set_to_none=True)
+        with ac():
+            pixel = l1(sr, gt)
+            content = cl(sr, gt)
+            adv = bce(d(sr), real)
+            pixel = torch.sum(torch.mul(pw, pixel))
+            content = torch.sum(torch.mul(cw, content))
+            adv = torch.sum(torch.mul(aw, adv))
+            g_loss = pixel + content + adv
+        scaler.scale(g_loss).backward()
+        scaler.step(g_opt)
+        scaler.update()
+        ema.update_parameters(g)
+        d_gt = torch.mean(torch.sigmoid_(gt_output.detach()))
+        d_sr = torch.mean(torch.sigmoid_(sr_output.detach()))
+        return torch.stack([d_loss.detach(), pixel.detach(), content.detach(), adv.detach(), d_gt, d_sr])
+    step.scaler = scaler
+    return step
 
 
 def esrgan_loop(M, g, dev, cdt):

@@ -301,6 +301,34 @@ int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float*
                          int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode,
                          const float* skip_flag, const float* grad_scale_dev /* or NULL */, void* stream);
 
+/* ---- thin-side 3x3 convolutions (stride 1, pad 1): 1..4 channels against 64 (csrc/conv_thin.hip) ----
+ * The generator's conv1 / conv4 (BSRGAN/model.py:325,355), the discriminators' conv1 / conv4 (:102,135; A-ESRGAN/model.py:287,307;
+ * ESRGAN/model.py:92) and VGG-19 features.0 (:522-524), with their data and weight gradients.  16-bit dtypes only.  The thin tensor
+ * is NHWC with a pitch of 4 channels ("NHWC4", 8 bytes per pixel; channels >= cs must be zero), the 64-channel tensor an ordinary
+ * view.  `weight` is the layer's RAW fp32 parameter (Cout, Cin, 3, 3): no packed copy exists for these layers.
+ *   w_big_is_cout  1: the 64-channel side is the weight's Cout (a 1..4 -> 64 conv), 0: it is its Cin (a 64 -> 1..4 conv)
+ *   flip           1: kernel rotated by 180 degrees (the launch is the DATA GRADIENT of the conv that owns `weight`) */
+typedef struct srganfd_thin_args {
+  int32_t dtype, n, h, w, cs, w_big_is_cout, flip, act;
+  float slope, mask_slope;
+  const float* weight;
+  const float* bias;        /* of the launch's OUTPUT channels (64 for thin_in, cs for thin_out), or NULL */
+  srganfd_view big;         /* thin_in: output; thin_out: input; thin_wgrad: the 64-channel operand (dy of a 1..4 -> 64 conv, x of a 64 -> 1..4 conv) */
+  srganfd_view mask;        /* thin_in only: y *= (mask > 0 ? 1 : mask_slope), or NULL */
+  const void* thin;         /* thin_in: input; thin_wgrad: the thin operand (x resp. dy); NHWC4, 16-bit */
+  float* thin_out;          /* thin_out: fp32 output */
+  int32_t thin_out_pitch;   /* its pixel pitch in floats: 4 (channels >= cs are written as zeros) or, with cs == 1, 1 */
+  int32_t pad_;
+} srganfd_thin_args;
+/* big[p][b] = act(bias[b] + sum_{tap,s} W(b,s,tap) * thin[p + tap][s]) (* mask): one K = 36 MFMA pair per 16 pixels x 16 channels */
+int srganfd_conv2d_thin_in(const srganfd_thin_args* a, void* stream);
+/* thin_out[p][s] = bias[s] + sum_{tap,b} W(b,s,tap) * big[p + tap][b] */
+int srganfd_conv2d_thin_out(const srganfd_thin_args* a, void* stream);
+/* dw (raw layout of `weight`'s tensor) = sum_p big[p][b] * thin[p +- tap][s]; db = the conv's bias gradient (64 values when
+ * w_big_is_cout, else cs) or NULL.  Deterministic (slabs + ordered reduction); workspace >= srganfd_conv2d_thin_wgrad_workspace(). */
+size_t srganfd_conv2d_thin_wgrad_workspace(void);
+int srganfd_conv2d_thin_wgrad(const srganfd_thin_args* a, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
 /* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);
  * bwd=1: a = dy (ho x wo) -> b = dx (hi x wi), deterministic gather. */

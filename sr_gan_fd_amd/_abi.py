@@ -49,6 +49,15 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ThinArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cs", C.c_int32), ("w_big_is_cout", C.c_int32),
+        ("flip", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("mask_slope", C.c_float),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("big", View), ("mask", View), ("thin", C.c_void_p), ("thin_out", C.c_void_p),
+        ("thin_out_pitch", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
 class WgradReduceJob(C.Structure):
     _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("grads", C.c_void_p), ("scalars", C.c_void_p), ("workspace", C.c_void_p)]
 
@@ -103,6 +112,10 @@ SYMBOLS = {
     "srganfd_pack_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_conv2d_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]),
+    "srganfd_conv2d_thin_in": (C.c_int, [C.POINTER(ThinArgs), C.c_void_p]),
+    "srganfd_conv2d_thin_out": (C.c_int, [C.POINTER(ThinArgs), C.c_void_p]),
+    "srganfd_conv2d_thin_wgrad_workspace": (C.c_size_t, []),
+    "srganfd_conv2d_thin_wgrad": (C.c_int, [C.POINTER(ThinArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "srganfd_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srganfd_wgrad_plan_bytes": (C.c_size_t, [C.POINTER(WgradShape), C.POINTER(WgradConv)]),

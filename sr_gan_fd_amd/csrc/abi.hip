@@ -97,6 +97,10 @@ int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dty
                        float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s, int phase = 0,
                        const float* ws_global = nullptr, size_t total_npix = 0);
 long long batchnorm_partial_floats_impl(int c);
+int conv2d_thin_in_impl(const srganfd_thin_args* a, hipStream_t s);
+int conv2d_thin_out_impl(const srganfd_thin_args* a, hipStream_t s);
+size_t conv2d_thin_wgrad_workspace_impl();
+int conv2d_thin_wgrad_impl(const srganfd_thin_args* a, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -124,6 +128,13 @@ int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_le
   const int rc = conv2d_impl(a, nullptr);
   g_describe = nullptr; g_describe_len = 0;
   return rc;
+}
+
+int srganfd_conv2d_thin_in(const srganfd_thin_args* a, void* stream) { return conv2d_thin_in_impl(a, (hipStream_t)stream); }
+int srganfd_conv2d_thin_out(const srganfd_thin_args* a, void* stream) { return conv2d_thin_out_impl(a, (hipStream_t)stream); }
+size_t srganfd_conv2d_thin_wgrad_workspace(void) { return conv2d_thin_wgrad_workspace_impl(); }
+int srganfd_conv2d_thin_wgrad(const srganfd_thin_args* a, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv2d_thin_wgrad_impl(a, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n) {

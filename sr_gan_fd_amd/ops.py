@@ -101,6 +101,56 @@ def conv2d(args: A.ConvArgs) -> None:
     A.check(A.lib().srganfd_conv2d(C.byref(args), A.stream_ptr()), "conv2d")
 
 
+# ---- thin-side convolutions (csrc/conv_thin.hip): 1..4 channels against 64, 3x3 stride 1 pad 1, 16-bit dtypes ----
+THIN_ENABLED = os.environ.get("SRGANFD_THIN", "1") != "0"      # same-box A/B switch: 0 keeps these layers on the 32-channel-padded kernels
+
+
+def thin_ok(dtype: int, big_channels: int, thin_channels: int, ksize: int = 3) -> bool:
+    """does this layer run on the thin kernels?  (16-bit modes, 64 channels against 1..4, 3x3: everything else -- and the exact-fp32
+    parity mode -- stays on srganfd_conv2d with the thin side padded to 32 channels)"""
+    return THIN_ENABLED and dtype != A.F32 and big_channels == 64 and 1 <= thin_channels <= 4 and ksize == 3
+
+
+def _ptr(t):
+    return None if t is None else (t if isinstance(t, int) else t.data_ptr())
+
+
+def thin_args(dtype: int, n: int, h: int, w: int, cs: int, weight, big: A.View, *, w_big_is_cout: bool, flip: bool = False, bias=None,
+              act: int = A.ACT_NONE, slope: float = 0.2, mask: A.View = A.NULL_VIEW, mask_slope: float = 0.2, thin=None, thin_out=None,
+              thin_out_pitch: int = 4) -> A.ThinArgs:
+    """weight: the layer's raw fp32 parameter (Cout, Cin, 3, 3) -- tensor or device address; thin: NHWC4 16-bit tensor / address"""
+    a = A.ThinArgs()
+    a.dtype, a.n, a.h, a.w, a.cs = dtype, n, h, w, cs
+    a.w_big_is_cout, a.flip, a.act, a.slope, a.mask_slope = int(w_big_is_cout), int(flip), act, slope, mask_slope
+    a.weight, a.bias, a.big, a.mask = _ptr(weight), _ptr(bias), big, mask
+    a.thin, a.thin_out, a.thin_out_pitch = _ptr(thin), _ptr(thin_out), thin_out_pitch
+    return a
+
+
+def thin_work(a: A.ThinArgs, kind: str):
+    """(algorithmic FLOP, algorithmic bytes) of one thin launch: 2 * pixels * 9 * 64 * cs; 64-channel tensor (+ mask) once, thin tensor once"""
+    px = float(a.n) * a.h * a.w
+    nbytes = px * (128.0 + (128.0 if a.mask.ptr else 0.0) + (4.0 * a.thin_out_pitch if kind == "thin_out" else 8.0))
+    return 2.0 * px * 9 * 64 * a.cs, nbytes
+
+
+def thin_in(a: A.ThinArgs) -> None:
+    A.check(A.lib().srganfd_conv2d_thin_in(C.byref(a), A.stream_ptr()), "conv2d_thin_in")
+
+
+def thin_out(a: A.ThinArgs) -> None:
+    A.check(A.lib().srganfd_conv2d_thin_out(C.byref(a), A.stream_ptr()), "conv2d_thin_out")
+
+
+def thin_wgrad_workspace_bytes() -> int:
+    return int(A.lib().srganfd_conv2d_thin_wgrad_workspace())
+
+
+def thin_wgrad(a: A.ThinArgs, dw, db, workspace: torch.Tensor) -> None:
+    A.check(A.lib().srganfd_conv2d_thin_wgrad(C.byref(a), _ptr(dw), _ptr(db), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                              A.stream_ptr()), "conv2d_thin_wgrad")
+
+
 class WgradPlan:
     """Host+device plan of one weight-gradient launch (several convs sharing x and dy)."""
 

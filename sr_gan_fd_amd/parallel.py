@@ -61,6 +61,31 @@ class SyncBatchNormReduce:
             dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.pg)
 
 
+class WaitMeter:
+    """Exposed communication as a number: HIP event pairs around the main stream's waits for the reducers' side streams
+    (BucketReducer.finish, SideStreamReducer.wait).  The first event fires when the main stream REACHES the wait point, the second
+    when it gets past it, so their distance is what the exchange cost the critical path (zero when the side stream finished first).
+    Off unless a meter is installed in ``parallel.METER`` (bench.py does, for N > 1)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def bracket(self, name: str, wait_fn) -> None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        wait_fn()
+        e1.record()
+        self.pairs.setdefault(name, []).append((e0, e1))
+
+    def report(self, steps: int) -> dict:
+        """ms per step per wait point (synchronises)"""
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / max(1, steps) for k, v in self.pairs.items()}
+
+
+METER: Optional[WaitMeter] = None
+
+
 class BucketReducer:
     """The generator's gradient exchange in buckets that follow its backward pass: the engine reports a contiguous range of the
     flat gradient as final (tail convs first, then the upper half of the trunk, then the rest -- three ranges of 2 / 32 / 33 MB for
@@ -96,7 +121,11 @@ class BucketReducer:
 
     def finish(self) -> float:
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            wait = lambda: torch.cuda.current_stream().wait_stream(self.stream)
+            if METER is not None:
+                METER.bracket("g_grad_exchange", wait)
+            else:
+                wait()
         return 1.0 / self.world
 
 
@@ -134,7 +163,12 @@ class SideStreamReducer:
 
     def wait(self) -> None:
         if self.event is not None:
-            torch.cuda.current_stream().wait_event(self.event)
+            ev = self.event
+            wait = lambda: torch.cuda.current_stream().wait_event(ev)
+            if METER is not None:
+                METER.bracket("d_grad_exchange_and_adam", wait)
+            else:
+                wait()
             self.event = None
 
 
