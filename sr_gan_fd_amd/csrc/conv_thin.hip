@@ -300,11 +300,13 @@ __global__ __launch_bounds__(256) void thin_out_kernel(const ThinK a) {
       const int oy = pr - 1;
       if (oy >= y0) {            // (oy < y1 holds: pr <= pr1 = y1)
         float o[4];
+        const float c0 = acc0[0], c1 = acc0[1], c2 = acc0[2], c3 = acc0[3];
+        const float cv[4] = {c0, c1, c2, c3};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src1, __builtin_bit_cast(int, acc0[r])));
-          const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src2, __builtin_bit_cast(int, acc0[r])));
-          o[r] = (acc0[r] + v1) + v2 + bs[r];
+          const float v1 = __shfl(cv[r], src1 >> 2, 64);
+          const float v2 = __shfl(cv[r], src2 >> 2, 64);
+          o[r] = (cv[r] + v1) + v2 + bs[r];
         }
         if (st_ok) {
           float* dst = yimg + (size_t)(oy * a.W + ox) * a.thin_pitch;

@@ -406,6 +406,41 @@ __global__ __launch_bounds__(256) void clamp_grad_rgb16_kernel(const float* __re
   }
 }
 
+// the same into a 4-channel pitch ("NHWC4", 8 bytes per pixel): the thin-side kernels' operand (conv_thin.hip)
+template <typename T>
+__global__ __launch_bounds__(256) void clamp_grad_rgb4_kernel(const float* __restrict__ dsr, const f32x4* __restrict__ pre, unsigned long long* __restrict__ dst,
+                                                              size_t npix, size_t hw, int c) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const size_t img = p / hw, pix = p % hw;
+    const f32x4 q = pre[p];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < c && q[k] >= 0.f && q[k] <= 1.f) v[k] = dsr[(img * c + k) * hw + pix];
+    const u32x4 w0 = pack8<T>(v);
+    dst[p] = (unsigned long long)w0[0] | ((unsigned long long)w0[1] << 32);
+  }
+}
+
+// NCHW fp32 (c <= 4 planes) -> NHWC4 16-bit: one thread per pixel, c coalesced plane reads, one 8-byte store
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ src, unsigned long long* __restrict__ dst, size_t npix, size_t hw, int c,
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const size_t img = p / hw, pix = p % hw;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < c) {
+        float t = src[(img * c + k) * hw + pix];
+        if (mean) t = (t - mean[k]) / stdv[k];
+        v[k] = t;
+      }
+    const u32x4 w0 = pack8<T>(v);
+    dst[p] = (unsigned long long)w0[0] | ((unsigned long long)w0[1] << 32);
+  }
+}
+
 // ---- backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:372,374): 2x2 sum ----
 template <typename T>
 __global__ void up2_nearest_bwd_kernel(const void* __restrict__ dy, int yC, int y0, void* dx, int xC, int x0, int n, int h, int w, int c) {
@@ -1390,6 +1425,13 @@ static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 81
 int nchw_to_nhwc_impl(const float* src, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, const float* mean, const float* stdv, hipStream_t s) {
   if (!src || !dst.ptr || n <= 0 || c <= 0 || cpad < c || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "nchw_to_nhwc: bad args");
   const size_t total = (size_t)n * h * w * cpad;
+  if (dtype != SRGANFD_F32 && c <= 4 && cpad == 4 && dst.cstride == 4 && dst.c0 == 0 && ((uintptr_t)dst.ptr & 7) == 0) {
+    const size_t npix = (size_t)n * h * w;
+    if (dtype == SRGANFD_BF16) SRGANFD_LAUNCH(nchw_to_nhwc4_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, src, (unsigned long long*)dst.ptr, npix, (size_t)h * w, c, mean, stdv);
+    else SRGANFD_LAUNCH(nchw_to_nhwc4_kernel<f16_t>, dim3(grid_for(npix)), dim3(256), 0, s, src, (unsigned long long*)dst.ptr, npix, (size_t)h * w, c, mean, stdv);
+    SRGANFD_HIP_CHECK(hipGetLastError());
+    return SRGANFD_OK;
+  }
   {
     const int vn = dtype == SRGANFD_F32 ? 4 : 8;
     if (cpad % vn == 0 && dst.c0 % vn == 0 && dst.cstride % vn == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
@@ -1415,6 +1457,14 @@ int nhwc_to_nchw_impl(srganfd_view src, int dtype, int n, int c, int h, int w, f
 int clamp_grad_impl(const float* dsr, srganfd_view pre, int n, int c, int h, int w, srganfd_view dst, int dtype, int cpad, hipStream_t s) {
   if (!dsr || !pre.ptr || !dst.ptr || dst.c0 + cpad > dst.cstride) return set_err(SRGANFD_EINVAL, "clamp_grad: bad args");
   const size_t total = (size_t)n * h * w * cpad;
+  if (dtype != SRGANFD_F32 && c <= 4 && cpad == 4 && pre.cstride == 4 && pre.c0 == 0 && dst.cstride == 4 && dst.c0 == 0 &&
+      ((uintptr_t)pre.ptr & 15) == 0 && ((uintptr_t)dst.ptr & 7) == 0) {
+    const size_t npix = (size_t)n * h * w;
+    if (dtype == SRGANFD_BF16) SRGANFD_LAUNCH(clamp_grad_rgb4_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (unsigned long long*)dst.ptr, npix, (size_t)h * w, c);
+    else SRGANFD_LAUNCH(clamp_grad_rgb4_kernel<f16_t>, dim3(grid_for(npix)), dim3(256), 0, s, dsr, (const f32x4*)pre.ptr, (unsigned long long*)dst.ptr, npix, (size_t)h * w, c);
+    SRGANFD_HIP_CHECK(hipGetLastError());
+    return SRGANFD_OK;
+  }
   if (dtype != SRGANFD_F32 && c <= 4 && cpad == 32 && pre.cstride == 4 && pre.c0 == 0 && dst.cstride == 32 && dst.c0 == 0 &&
       ((uintptr_t)pre.ptr & 15) == 0 && ((uintptr_t)dst.ptr & 15) == 0) {
     const size_t npix = (size_t)n * h * w;

@@ -316,12 +316,18 @@ class TrunkEngine:
         fw = []   # forward launch list
         if self.full:
             s = 1 << self.n_up
-            sp.xin = new(N, H, W, 32)
+            # thin-side kernels (csrc/conv_thin.hip) for conv1 / conv4 in the 16-bit modes: the image side is NHWC with a 4-channel pitch
+            sp.thin_i, sp.thin_o = ops.thin_ok(dtc, Cc, self.in_ch), ops.thin_ok(dtc, Cc, self.out_ch)
+            sp.xin = new(N, H, W, 4 if sp.thin_i else 32)
             sp.f0 = new(N, H, W, Cc)
             sp.ups = [new(N, H << u, W << u, Cc) for u in range(1, self.n_up + 1)]
             sp.c3 = new(N, H * s, W * s, Cc)
             sp.srp = new(N, H * s, W * s, 4, dtype=torch.float32)
-            fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
+            if sp.thin_i:
+                fw.append(ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, self.in_ch, bias("conv1.weight"), VC(catb(0)), w_big_is_cout=True,
+                                                                  bias=bias("conv1.bias"), thin=sp.xin)))
+            else:
+                fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
         for i, pre in enumerate(self._rdb_prefix):
             ci = catb(i)
             for k in range(1, 5):
@@ -344,8 +350,12 @@ class TrunkEngine:
                 src, h, w = sp.ups[u - 1], h * 2, w * 2
             fw.append(ops.conv_args(dtc, V(src), V(sp.c3), wptr + pk["offs"][("f", "conv3.0")], N, h, w, Cc, Cc, bias=bias("conv3.0.bias"),
                                     act=A.ACT_LRELU, slope=0.2))
-            fw.append(ops.conv_args(dtc, V(sp.c3), V(sp.srp), wptr + pk["offs"][("f", "conv4")], N, h, w, Cc, 32, cout_store=self.out_ch,
-                                    bias=bias("conv4.bias"), y_f32=True))
+            if sp.thin_o:
+                fw.append(ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, h, w, self.out_ch, bias("conv4.weight"), V(sp.c3), w_big_is_cout=False,
+                                                                   bias=bias("conv4.bias"), thin_out=sp.srp, thin_out_pitch=4)))
+            else:
+                fw.append(ops.conv_args(dtc, V(sp.c3), V(sp.srp), wptr + pk["offs"][("f", "conv4")], N, h, w, Cc, 32, cout_store=self.out_ch,
+                                        bias=bias("conv4.bias"), y_f32=True))
             sp.hs, sp.ws = h, w
         sp.fw = fw
         sp.N, sp.H, sp.W, sp.dt, sp.dtc, sp.device = N, H, W, dt, dtc, device
@@ -381,8 +391,11 @@ class TrunkEngine:
         if self.full:
             s = 1 << self.n_up
             hs, ws_ = sp.hs, sp.ws
-            sp.dsrp = new(N, hs, ws_, 32)
+            sp.dsrp = new(N, hs, ws_, 4 if sp.thin_o else 32)
             sp.gA = new(N, hs, ws_, Cc)
+            fptr = self.fp.flat.data_ptr()
+            if sp.thin_i or sp.thin_o:
+                sp.thin_ws = torch.empty(ops.thin_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
             sp.gB = new(N, hs, ws_, Cc)
             sp.glo = [new(N, H << u, W << u, Cc) for u in range(0, self.n_up)]   # grads at the input res of upsampling u+1
 
@@ -390,8 +403,15 @@ class TrunkEngine:
                 return [dict(cin=ops.pad32(cin), cout=ops.pad32(cout), dw_off=self._poff(name + ".weight"), db_off=self._poff(name + ".bias"),
                              co_dst=cout, ci_dst=cin)]
             # conv4
-            bw.append(("wgrad", wplan(N, hs, ws_, Cc, 32, one("conv4", self.out_ch, Cc)), V(sp.c3), V(sp.dsrp), 0))
-            bw.append(("conv", ops.conv_args(dtc, V(sp.dsrp), V(sp.gA), wptr + pk["offs"][("b", "conv4")], N, hs, ws_, 32, Cc, mask=V(sp.c3), mask_slope=0.2)))
+            if sp.thin_o:
+                w4 = fptr + 4 * self._poff("conv4.weight")
+                bw.append(("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, hs, ws_, self.out_ch, w4, V(sp.c3), w_big_is_cout=False, thin=sp.dsrp),
+                                                  dw_off=self._poff("conv4.weight"), db_off=self._poff("conv4.bias"), ws=sp.thin_ws)))
+                bw.append(("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, hs, ws_, self.out_ch, w4, V(sp.gA), w_big_is_cout=False, flip=True,
+                                                                           mask=V(sp.c3), mask_slope=0.2, thin=sp.dsrp))))
+            else:
+                bw.append(("wgrad", wplan(N, hs, ws_, Cc, 32, one("conv4", self.out_ch, Cc)), V(sp.c3), V(sp.dsrp), 0))
+                bw.append(("conv", ops.conv_args(dtc, V(sp.dsrp), V(sp.gA), wptr + pk["offs"][("b", "conv4")], N, hs, ws_, 32, Cc, mask=V(sp.c3), mask_slope=0.2)))
             # conv3
             src3 = sp.ups[-1] if self.n_up else sp.f0
             bw.append(("wgrad", wplan(N, hs, ws_, Cc, Cc, one("conv3.0", Cc, Cc)), V(src3), V(sp.gA), 0))
@@ -464,8 +484,13 @@ class TrunkEngine:
         if self.full:
             bw.append(("call", (lambda x=V(sp.d_f0), y=V(sp.dx0): A.check(
                 A.lib().srganfd_axpby(x, y, dtc, N * H * W, Cc, 1.0, 1.0, A.stream_ptr()), "axpby"))))
-            convs = [dict(cin=32, cout=Cc, dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), co_dst=Cc, ci_dst=self.in_ch)]
-            bw.append(("wgrad", wplan(N, H, W, 32, Cc, convs), V(sp.xin), V(sp.dx0), 0))
+            if sp.thin_i:
+                bw.append(("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, H, W, self.in_ch, self.fp.flat.data_ptr() + 4 * self._poff("conv1.weight"),
+                                                                              V(sp.dx0), w_big_is_cout=True, thin=sp.xin),
+                                                  dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), ws=sp.thin_ws)))
+            else:
+                convs = [dict(cin=32, cout=Cc, dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), co_dst=Cc, ci_dst=self.in_ch)]
+                bw.append(("wgrad", wplan(N, H, W, 32, Cc, convs), V(sp.xin), V(sp.dx0), 0))
         # last bucket: whatever the earlier markers did not cover
         covered = min([it[1] for it in bw if it[0] == "ready"], default=self.fp.total)
         bw.append(("ready", 0, covered))
@@ -487,17 +512,24 @@ class TrunkEngine:
         x = x.contiguous().float()
         L, st = A.lib(), A.stream_ptr()
         if self.full:
-            A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.xin), dtc, 32, None, None, st), "nchw_to_nhwc")
+            A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.xin), dtc, sp.xin.shape[-1], None, None, st), "nchw_to_nhwc")
         else:
             A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.Cc, H, W, A.view(sp.catb(0)), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
         rec = profiling.REC
+        Thin = ops.ThinLaunch
         if rec is None:
             for a in sp.fw:
+                if type(a) is Thin:
+                    a.run()
+                    continue
                 rc = L.srganfd_conv2d(C.byref(a), st)
                 if rc:
                     A.check(rc, "conv2d")
         else:
             for a in sp.fw:
+                if type(a) is Thin:
+                    a.launch(rec)
+                    continue
                 rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d"))
         if self.full:
             out = torch.empty(N, self.out_ch, sp.hs, sp.ws, dtype=torch.float32, device=dev)
@@ -522,7 +554,7 @@ class TrunkEngine:
         dout = dout.contiguous().float()
         flat_grad = self.fp.new_grad(sp.device)
         if self.full:
-            A.check(L.srganfd_clamp_grad_to_nhwc(dout.data_ptr(), A.view(sp.srp), N, self.out_ch, sp.hs, sp.ws, A.view(sp.dsrp), dtc, 32, st), "clamp_grad")
+            A.check(L.srganfd_clamp_grad_to_nhwc(dout.data_ptr(), A.view(sp.srp), N, self.out_ch, sp.hs, sp.ws, A.view(sp.dsrp), dtc, sp.dsrp.shape[-1], st), "clamp_grad")
         else:
             A.check(L.srganfd_nchw_to_nhwc(dout.data_ptr(), N, self.Cc, H, W, A.view(sp.dy[(self.R - 1) % 4]), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
         gptr = flat_grad.data_ptr()
@@ -598,6 +630,9 @@ class TrunkEngine:
                         run()
                     else:
                         rec.bracket(plan.label, (plan.flops, plan.nbytes), run)
+            elif kind == "thin":
+                flush_reduce()                          # (keeps the launch order of the padded path: slot-0 workspace users come after pending slabs)
+                item[1].launch(rec, gptr)
             elif kind == "ready":
                 flush_reduce()
                 if side is not None:

@@ -119,7 +119,9 @@ class DiscriminatorEngine:
         def new(h, w, c, dtype=dt):
             return torch.empty(N, h, w, c, dtype=dtype, device=device)
         H, W = S1, S2
-        sp.xin = new(H, W, 32)
+        # conv1 (in_ch -> 64) and conv4 (64 -> out_ch) on the thin-side kernels in the 16-bit modes (csrc/conv_thin.hip): 4-channel pitch
+        sp.thin_i, sp.thin_o = ops.thin_ok(dtc, 64, self.in_ch), ops.thin_ok(dtc, 64, self.out_ch)
+        sp.xin = new(H, W, 4 if sp.thin_i else 32)
         sp.out1 = new(H, W, 64)
         sp.d1, sp.d2, sp.d3 = new(H // 2, W // 2, 128), new(H // 4, W // 4, 256), new(H // 8, W // 8, 512)
         sp.b3, sp.u1 = new(H // 4, W // 4, 512), new(H // 4, W // 4, 256)
@@ -132,8 +134,10 @@ class DiscriminatorEngine:
         cv = lambda *a, **k: ("conv", ops.conv_args(dtc, *a, **k))
         rs = lambda op, a, b, h, w, c: ("call", lambda: A.check(L.srganfd_resample(op, a, b, dtc, N, h, w, c, A.stream_ptr()), "resample"))
         lre = dict(act=A.ACT_LRELU, slope=0.2)
+        w1, b1 = fptr + 4 * self._poff("conv1.weight"), fptr + 4 * self._poff("conv1.bias")
         fw = [
-            cv(V(sp.xin), V(sp.out1), wptr + O[("f", "conv1")], N, H, W, 32, 64, bias=fptr + 4 * self._poff("conv1.bias")),
+            ("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, self.in_ch, w1, V(sp.out1), w_big_is_cout=True, bias=b1, thin=sp.xin)))
+            if sp.thin_i else cv(V(sp.xin), V(sp.out1), wptr + O[("f", "conv1")], N, H, W, 32, 64, bias=b1),
             cv(V(sp.out1), V(sp.d1), wptr + O[("f", "down_block1")], N, H, W, 64, 128, ksize=4, stride=2, **lre),
             cv(V(sp.d1), V(sp.d2), wptr + O[("f", "down_block2")], N, H // 2, W // 2, 128, 256, ksize=4, stride=2, **lre),
             cv(V(sp.d2), V(sp.d3), wptr + O[("f", "down_block3")], N, H // 4, W // 4, 256, 512, ksize=4, stride=2, **lre),
@@ -150,8 +154,13 @@ class DiscriminatorEngine:
         # locals only: a closure stored on sp that captured `sp` or `self` would be a reference cycle, and the plan's activation
         # buffers would then outlive the module until a cyclic collection (found as an OOM between full-size tests)
         c3_v, out_ch, w4, b4 = V(sp.c3), self.out_ch, wptr + O[("f", "conv4")], fptr + 4 * self._poff("conv4.bias")
-        sp.conv4 = lambda logits: ops.conv_args(dtc, c3_v, A.View(logits.data_ptr(), out_ch, 0), w4, N, H, W, 64, 32,
-                                                 cout_store=out_ch, bias=b4, y_f32=True)
+        if sp.thin_o:
+            w4raw = fptr + 4 * self._poff("conv4.weight")
+            sp.conv4 = lambda logits: ("thin", ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, H, W, out_ch, w4raw, c3_v, w_big_is_cout=False, bias=b4,
+                                                                                        thin_out=logits.data_ptr(), thin_out_pitch=1)))
+        else:
+            sp.conv4 = lambda logits: ("conv", ops.conv_args(dtc, c3_v, A.View(logits.data_ptr(), out_ch, 0), w4, N, H, W, 64, 32,
+                                                             cout_store=out_ch, bias=b4, y_f32=True))
         self._plan_backward(sp, pk)
         self.shapes[key] = sp
         return sp
@@ -164,7 +173,10 @@ class DiscriminatorEngine:
 
         def new(h, w, c, dtype=dt):
             return torch.empty(N, h, w, c, dtype=dtype, device=device)
-        sp.dl = new(H, W, 32)
+        sp.dl = new(H, W, 4 if sp.thin_o else 32)
+        fptr = self.fp.flat.data_ptr()
+        if sp.thin_i or sp.thin_o:
+            sp.thin_ws = torch.empty(ops.thin_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
         gA, gB, gC, gD = new(H, W, 64), new(H, W, 64), new(H, W, 128), new(H, W, 64)
         h1, h2, h3, h4 = new(H // 2, W // 2, 128), new(H // 2, W // 2, 128), new(H // 2, W // 2, 256), new(H // 2, W // 2, 128)
         q1, q2, q3, q4 = new(H // 4, W // 4, 256), new(H // 4, W // 4, 256), new(H // 4, W // 4, 512), new(H // 4, W // 4, 256)
@@ -206,9 +218,16 @@ class DiscriminatorEngine:
             return items
 
         P = N * H * W
-        bw = [
-            wg("conv4", sp.c3, sp.dl, H, W, 64, 32, cout_real=self.out_ch, bias=True),
-            cv(V(sp.dl), V(gA), wptr + O[("b", "conv4")], N, H, W, 32, 64, mask=V(sp.c3), mask_slope=0.2),
+        if sp.thin_o:
+            w4raw = fptr + 4 * self._poff("conv4.weight")
+            head = [("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, H, W, self.out_ch, w4raw, V(sp.c3), w_big_is_cout=False, thin=sp.dl),
+                                            dw_off=self._poff("conv4.weight"), db_off=self._poff("conv4.bias"), ws=sp.thin_ws)),
+                    ("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, self.out_ch, w4raw, V(gA), w_big_is_cout=False, flip=True, mask=V(sp.c3),
+                                                                     mask_slope=0.2, thin=sp.dl)))]
+        else:
+            head = [wg("conv4", sp.c3, sp.dl, H, W, 64, 32, cout_real=self.out_ch, bias=True),
+                    cv(V(sp.dl), V(gA), wptr + O[("b", "conv4")], N, H, W, 32, 64, mask=V(sp.c3), mask_slope=0.2)]
+        bw = head + [
             wg("conv3", sp.c2, gA, H, W, 64, 64, sn_index=7),
             cv(V(gA), V(gB), wptr + O[("b", "conv3")], N, H, W, 64, 64, mask=V(sp.c2), mask_slope=0.2),
             wg("conv2", sp.u3, gB, H, W, 64, 64, sn_index=6),
@@ -231,9 +250,16 @@ class DiscriminatorEngine:
         bw += s2_dgrad("down_block2", q4, h4, H // 4, W // 4, 256, 128, h1, sp.d1)       # h4 = (d d1 + d u2) * lrelu'(d1)
         bw.append(wg("down_block1", sp.out1, h4, H, W, 64, 128, sn_index=0, k=4, s=2))
         bw += s2_dgrad("down_block1", h4, gD, H // 2, W // 2, 128, 64, gA, None)         # gD = d out1 (+ skip d u3)
-        bw.append(wg("conv1", sp.xin, gD, H, W, 32, 64, cin_real=self.in_ch, bias=True))
+        w1raw = fptr + 4 * self._poff("conv1.weight")
+        if sp.thin_i:
+            bw.append(("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, H, W, self.in_ch, w1raw, V(gD), w_big_is_cout=True, thin=sp.xin),
+                                              dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), ws=sp.thin_ws)))
+            sp.dx_conv = ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, H, W, self.in_ch, w1raw, V(gD), w_big_is_cout=True, flip=True, thin_out=sp.dxp,
+                                                                  thin_out_pitch=4))
+        else:
+            bw.append(wg("conv1", sp.xin, gD, H, W, 32, 64, cin_real=self.in_ch, bias=True))
+            sp.dx_conv = ops.conv_args(dtc, V(gD), V(sp.dxp), wptr + O[("b", "conv1")], N, H, W, 64, 32, cout_store=self.in_ch, y_f32=True)
         sp.bw = bw
-        sp.dx_conv = ops.conv_args(dtc, V(gD), V(sp.dxp), wptr + O[("b", "conv1")], N, H, W, 64, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
         sp.sn_ws = torch.empty(len(SN_LAYERS) * A.SN_GRAD_WS_FLOATS, dtype=torch.float32, device=device)
@@ -249,13 +275,15 @@ class DiscriminatorEngine:
         sp = self._plan(N, H, W, dt, dtc, dev, pk)
         L, st = A.lib(), A.stream_ptr()
         x = x.contiguous().float()
-        A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.xin), dtc, 32, None, None, st), "nchw_to_nhwc")
+        A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.xin), dtc, sp.xin.shape[-1], None, None, st), "nchw_to_nhwc")
         logits = torch.empty(N, self.out_ch, H, W, dtype=torch.float32, device=dev)
         if self.out_ch != 1:
             raise A.SrganfdError("DiscriminatorUNet out_channels must be 1 (logits are written NCHW == NHWC)")
         rec = profiling.REC
-        for kind, item in sp.fw + [("conv", sp.conv4(logits))]:
-            if kind == "conv":
+        for kind, item in sp.fw + [sp.conv4(logits)]:
+            if kind == "thin":
+                item.launch(rec)
+            elif kind == "conv":
                 if rec is None:
                     rc = L.srganfd_conv2d(C.byref(item), st)
                     if rc:
@@ -276,7 +304,7 @@ class DiscriminatorEngine:
         L, st = A.lib(), A.stream_ptr()
         N, H, W, dtc = sp.N, sp.H, sp.W, sp.dtc
         dlogits = dlogits.contiguous().float()
-        A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, 32, None, None, st), "nchw_to_nhwc")
+        A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, sp.dl.shape[-1], None, None, st), "nchw_to_nhwc")
         flat = self.fp.flat
         flat_grad = self.fp.new_grad(sp.device) if need_wgrad else None
         rec = profiling.REC
@@ -291,6 +319,10 @@ class DiscriminatorEngine:
                         A.check(rc, "conv2d(dgrad)")
                 else:
                     rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
+            elif kind == "thin":
+                if item[1].is_wgrad and not need_wgrad:
+                    continue
+                item[1].launch(rec, flat_grad.data_ptr() if flat_grad is not None else 0)
             elif kind == "wgrad":
                 if not need_wgrad:
                     continue
@@ -314,7 +346,10 @@ class DiscriminatorEngine:
         ops.spectral_norm_grad_batch(sn_grads, sp.sn_ws)
         dx = None
         if need_dx:
-            A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv1)")
+            if type(sp.dx_conv) is ops.ThinLaunch:
+                sp.dx_conv.launch(rec)
+            else:
+                A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv1)")
             dx = torch.empty(N, self.in_ch, H, W, dtype=torch.float32, device=sp.device)
             A.check(L.srganfd_nhwc_to_nchw(A.view(sp.dxp), A.F32, N, self.in_ch, H, W, dx.data_ptr(), 0, st), "nhwc_to_nchw")
         return flat_grad, dx
@@ -390,17 +425,20 @@ class ContentLossEngine:
         sp = self.shapes.get(key)
         if sp is None:
             sp = _Shape()
-            sp.xin = torch.empty(2 * N, H, W, 32, dtype=dt, device=dev)
+            # features.0 (3 -> 64) on the thin-side kernel in the 16-bit modes: the normalised image is NHWC with a 4-channel pitch
+            sp.thin = ops.thin_ok(dtc, self.owner.features[0].weight.shape[0], Cin)
+            sp.xin = torch.empty(2 * N, H, W, 4 if sp.thin else 32, dtype=dt, device=dev)
             sp.bufs = {}
             sp.ws = torch.empty(A.LOSS_WS_FLOATS, dtype=torch.float32, device=dev)
             sp.dt, sp.dtc = dt, dtc
             self.shapes[key] = sp
         self._last = sp
         mean, std = self.owner.mean, self.owner.std
+        cpad = sp.xin.shape[-1]
         for img, half in ((sr, 0), (gt, 1)):
             img = img.detach().contiguous().float()
-            dst = A.View(sp.xin.data_ptr() + half * N * H * W * 32 * sp.xin.element_size(), 32, 0)
-            A.check(L.srganfd_nchw_to_nhwc(img.data_ptr(), N, Cin, H, W, dst, dtc, 32, mean.data_ptr(), std.data_ptr(), st), "nchw_to_nhwc")
+            dst = A.View(sp.xin.data_ptr() + half * N * H * W * cpad * sp.xin.element_size(), cpad, 0)
+            A.check(L.srganfd_nchw_to_nhwc(img.data_ptr(), N, Cin, H, W, dst, dtc, cpad, mean.data_ptr(), std.data_ptr(), st), "nchw_to_nhwc")
         losses = torch.zeros(len(self.want), dtype=torch.float32, device=dev)
         last = max(self.want)
         post = self.owner.taps_post_relu
@@ -423,10 +461,19 @@ class ContentLossEngine:
                 tap = idx in self.want
                 # taps are observed after the in-place ReLU unless they are the last requested node
                 relu_in_conv = not (tap and (idx == last or not post))
-                a = ops.conv_args(dtc, A.view(cur), A.view(out), pk["buf"].data_ptr() + pk["offs"][idx], 2 * N, h, w, ch, co,
-                                  bias=self.fp.flat.data_ptr() + 4 * self.fp.off(f"features.{idx}.bias"),
-                                  act=A.ACT_RELU if relu_in_conv else A.ACT_NONE)
-                if rec is None:
+                if idx == 0 and sp.thin:
+                    fl = self.fp.flat.data_ptr()
+                    ops.ThinLaunch("thin_in", ops.thin_args(dtc, 2 * N, h, w, Cin, fl + 4 * self.fp.off("features.0.weight"), A.view(out), w_big_is_cout=True,
+                                                            bias=fl + 4 * self.fp.off("features.0.bias"), act=A.ACT_RELU if relu_in_conv else A.ACT_NONE,
+                                                            thin=sp.xin)).launch(rec)
+                    a = None
+                else:
+                    a = ops.conv_args(dtc, A.view(cur), A.view(out), pk["buf"].data_ptr() + pk["offs"][idx], 2 * N, h, w, ch, co,
+                                      bias=self.fp.flat.data_ptr() + 4 * self.fp.off(f"features.{idx}.bias"),
+                                      act=A.ACT_RELU if relu_in_conv else A.ACT_NONE)
+                if a is None:
+                    pass
+                elif rec is None:
                     A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(vgg)")
                 else:
                     rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(vgg)"))

@@ -151,6 +151,36 @@ def thin_wgrad(a: A.ThinArgs, dw, db, workspace: torch.Tensor) -> None:
                                               A.stream_ptr()), "conv2d_thin_wgrad")
 
 
+class ThinLaunch:
+    """One thin-side launch in an engine's launch list.  kind: "thin_in" / "thin_out" / "thin_wgrad" (the latter writes the weight and
+    bias gradient at element offsets ``dw_off`` / ``db_off`` of the flat gradient whose address ``launch`` is given)."""
+
+    def __init__(self, kind: str, args: A.ThinArgs, dw_off: int = -1, db_off: int = -1, ws: Optional[torch.Tensor] = None, keep=()):
+        self.kind, self.args, self.dw_off, self.db_off, self.ws = kind, args, dw_off, db_off, ws
+        self.keep = keep                  # tensors whose addresses the struct holds
+        self.is_wgrad = kind == "thin_wgrad"
+        self.label = "%s_kernel<%s%s>" % (kind, A.DT_NAME[args.dtype], ",mask" if args.mask.ptr else "")
+        self.work = thin_work(args, kind)
+
+    def run(self, grad_ptr: int = 0) -> None:
+        L, st, a = A.lib(), A.stream_ptr(), self.args
+        if self.kind == "thin_in":
+            rc = L.srganfd_conv2d_thin_in(C.byref(a), st)
+        elif self.kind == "thin_out":
+            rc = L.srganfd_conv2d_thin_out(C.byref(a), st)
+        else:
+            rc = L.srganfd_conv2d_thin_wgrad(C.byref(a), grad_ptr + 4 * self.dw_off, (grad_ptr + 4 * self.db_off) if self.db_off >= 0 else None,
+                                             self.ws.data_ptr(), self.ws.numel() * self.ws.element_size(), st)
+        if rc:
+            A.check(rc, self.kind)
+
+    def launch(self, rec=None, grad_ptr: int = 0) -> None:
+        if rec is None:
+            self.run(grad_ptr)
+        else:
+            rec.bracket(self.label, self.work, lambda: self.run(grad_ptr))
+
+
 class WgradPlan:
     """Host+device plan of one weight-gradient launch (several convs sharing x and dy)."""
 
