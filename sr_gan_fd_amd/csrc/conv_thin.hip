@@ -8,7 +8,7 @@
 // here are built around the stream, not around a GEMM tile:
 //
 //   * thin_in  (1..4 -> 64 channels; also the data gradient of a 64 -> 1..4 conv, with the LeakyReLU' mask): all 9 taps x 4 channels
-//     are ONE K: k = 4 * tap + c, 36 products = one v_mfma_f32_16x16x32 (taps 0-7) + one v_mfma_f32_16x16x16 (tap 8) per 16 pixels x
+//     are ONE K: k = 4 * tap + c, 36 products = two v_mfma_f32_16x16x32 steps (taps 0-7, tap 8) per 16 pixels x
 //     16 output channels instead of 9 taps x 32 padded channels.  Operands are swapped (A = weights, B = pixels) so that a lane ends
 //     up with 8 CONSECUTIVE output channels of one pixel: bias (as the accumulator's initial value), activation, mask and the 16-byte
 //     store all happen in registers.  No LDS, no barrier: a wave owns a 16-column strip and walks down the image; its B fragments are
@@ -31,8 +31,6 @@
 
 namespace srganfd {
 
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2v;
 typedef __attribute__((address_space(3))) s16x4 lds_tr_t;
 
@@ -64,11 +62,6 @@ __device__ __forceinline__ float thin_weight(const float* __restrict__ wl, int b
   return big_is_cout ? wl[(b * cs + s) * 9 + tt] : wl[(s * 64 + b) * 9 + tt];
 }
 
-template <typename T> __device__ __forceinline__ f32x4_t mfma16x16x16(s16x4_t a, s16x4_t b, f32x4_t c) {
-  if constexpr (Elem<T>::kDtype == SRGANFD_F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-}
-
 __device__ __forceinline__ void* thin_uniform_ptr(const void* p) {
   const unsigned long long u = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -81,10 +74,14 @@ __device__ __forceinline__ void* thin_uniform_ptr(const void* p) {
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int kThinInRows = 32;
 
+// The 16 x 64 output tile of a wave row goes through a wave-private 2 KiB LDS image and leaves as two stores of 8 WHOLE pixels (1 KiB
+// contiguous each); straight from the accumulator layout a store instruction covers 16 half pixels (64 of a pixel's 128 bytes), which
+// measured 371 vs 326 us (3 -> 64 at 512 x 512, batch 32) and 472 vs 420 us with the mask, which is read in the store layout too.
 template <typename T, bool MASK>
 __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
   using Frag = typename FragAB<T>::type;
   __shared__ float wl[64 * 4 * 9];
+  __shared__ __attribute__((aligned(16))) char tl_all[4 * 2048];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
@@ -95,8 +92,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
   const int n16 = lane & 15, kg = lane >> 4;
   // A fragments: D row m = lane & 15 of tile t is output channel 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3), so that after
   // the MFMA lane (pixel, kg) holds channels 32 u + 8 kg + [0, 8) in tiles 2u, 2u + 1
-  Frag wa[4];
-  s16x4_t wb[4];
+  Frag wa[4], wb[4];
   f32x4_t bv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -107,10 +103,14 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
     const u32x4 pk = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
     wa[t] = __builtin_bit_cast(Frag, pk);
-    s16x4_t q;
+    // tap 8 rides in a second 16x16x32 step (k = 0..3 of lane group 0; the other 28 products are zeros).  NOT a 16x16x16 MFMA: hipcc
+    // (ROCm 7.2) schedules a v_mfma_f32_16x16x16 three instructions behind the v_mfma_f32_16x16x32 whose accumulator it continues, and on
+    // gfx950 that pair loses registers 0-1 of the first result (seen as outputs that equal the bias); two MFMAs of one form chain fine
+    unsigned short e8[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = (short)to_bits16<T>(kg == 0 ? thin_weight(wl, a.big_is_cout, a.cs, a.flip, b, j, 8) : 0.f);
-    wb[t] = q;
+    for (int j = 0; j < 4; ++j) e8[j] = to_bits16<T>(kg == 0 ? thin_weight(wl, a.big_is_cout, a.cs, a.flip, b, j, 8) : 0.f);
+    const u32x4 pk8 = {(unsigned)e8[0] | ((unsigned)e8[1] << 16), (unsigned)e8[2] | ((unsigned)e8[3] << 16), 0u, 0u};
+    wb[t] = __builtin_bit_cast(Frag, pk8);
     // accumulator rows of this lane: channels 32 (t >> 1) + 8 kg + 4 (t & 1) + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[t][r] = a.bias ? a.bias[32 * (t >> 1) + 8 * kg + 4 * (t & 1) + r] : 0.f;
@@ -139,17 +139,15 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
   };
   const T* yimg = (const T*)a.big + (size_t)img * a.H * a.W * a.bigC;
   const T* mimg = MASK ? (const T*)a.mask + (size_t)img * a.H * a.W * a.mC : nullptr;
-  const bool okx = ox < a.W;
-  // channel offsets of this lane's two 16-byte pieces (u = 0, 1): channels c0 + 32 u + 8 kg
-  int yoff[2], moff[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int cy = a.big_c0 + 32 * u + 8 * kg;
-    yoff[u] = (cy >> 5) * a.big_gs + (cy & 31);
-    const int cm = a.m_c0 + 32 * u + 8 * kg;
-    moff[u] = (cm >> 5) * a.m_gs + (cm & 31);
-  }
-  constexpr int D = 2;            // rows of loads in flight ahead of the row being computed
+  // store layout: piece u (0, 1) of a lane is pixel (lane >> 3) + 8 u of the wave's 16, channels c0 + 8 (lane & 7) .. + 7
+  char* tl = tl_all + wave * 2048;
+  const int sp8 = lane >> 3, ss8 = lane & 7;
+  const int ox_t0 = tx * 64 + wave * 16 + sp8;             // image column of piece 0 (piece 1: + 8)
+  const int cy = a.big_c0 + 8 * ss8, cm = a.m_c0 + 8 * ss8;
+  const int yoff = (cy >> 5) * a.big_gs + (cy & 31), moff = (cm >> 5) * a.m_gs + (cm & 31);
+  // rows of loads in flight ahead of the row being computed (4 and 8 measured the same: the kernel is bound by its stores, and 2 leaves
+  // registers for four / three waves per SIMD)
+  constexpr int D = 2;
   u32x2v fa[D], fb[D], fc[D];
   u32x4 mk[D][2];
   auto issue = [&](int slot, int oy) {
@@ -157,10 +155,10 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
     fb[slot] = ldx(oy + dyB, xB, okB);
     fc[slot] = ldx(oy + 1, xC, okC);
     if constexpr (MASK) {
-      if (okx && oy < y1) {
-        const int p = oy * a.W + ox;
+      if (oy < y1) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mk[slot][u] = *(const u32x4*)(mimg + (size_t)p * a.m_ps + moff[u]);
+        for (int u = 0; u < 2; ++u)
+          if (ox_t0 + 8 * u < a.W) mk[slot][u] = *(const u32x4*)(mimg + (size_t)(oy * a.W + ox_t0 + 8 * u) * a.m_ps + moff);
       }
     }
   };
@@ -177,15 +175,13 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
       if (oy >= y1) continue;
       const u32x4 xk = {A0.x, A0.y, B0.x, B0.y};
       const Frag xf = __builtin_bit_cast(Frag, xk);
-      const s16x4_t xs = __builtin_bit_cast(s16x4_t, C0);
+      const Frag xs = __builtin_bit_cast(Frag, u32x4{C0.x, C0.y, 0u, 0u});
       f32x4_t acc[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[t] = mfma16<T>(wa[t], xf, bv[t]);
-        acc[t] = mfma16x16x16<T>(wb[t], xs, acc[t]);
-      }
-      if (okx) {
-        const int p = oy * a.W + ox;
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wa[t], xf, bv[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wb[t], xs, acc[t]);
+      {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float v[8];
@@ -194,14 +190,27 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
             const float t = acc[2 * u + (q >> 2)][q & 3];
             v[q] = t * (t > 0.f ? 1.f : a.neg);
           }
+          // accumulator layout -> LDS image [pixel][8 slots of 16 bytes], slot XOR (pixel & 7): conflict-free 16-byte writes and reads
+          *(u32x4*)(tl + n16 * 128 + (((4 * u + kg) ^ (n16 & 7)) << 4)) = pack8<T>(v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pp = sp8 + 8 * u;
+          u32x4 o = *(const u32x4*)(tl + pp * 128 + ((ss8 ^ (pp & 7)) << 4));
           if constexpr (MASK) {
-            float mv[8];
+            float v[8], mv[8];
+            unpack8<T>(o, v);
             unpack8<T>(u ? m1 : m0, mv);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] *= mv[q] > 0.f ? 1.f : a.mask_slope;
+            o = pack8<T>(v);
           }
-          *(u32x4*)((T*)yimg + (size_t)p * a.big_ps + yoff[u]) = pack8<T>(v);
+          if (ox_t0 + 8 * u < a.W) *(u32x4*)((T*)yimg + (size_t)(oy * a.W + ox_t0 + 8 * u) * a.big_ps + yoff) = o;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }

@@ -150,7 +150,9 @@ class AesrganDiscriminatorEngine:
         R = [(H >> k, W >> k) for k in range(4)]
         Hg, Wg = R[3][0] + 2, R[3][1] + 2
         B = sp.B = {}
-        B["xin"] = new(H, W, 32)
+        # conv0 (in_ch -> nf) and conv9 (nf -> 1) on the thin-side kernels in the 16-bit modes (csrc/conv_thin.hip): 4-channel pitch
+        sp.thin_i, sp.thin_o = ops.thin_ok(dtc, nf, self.in_ch), ops.thin_ok(dtc, nf, 1)
+        B["xin"] = new(H, W, 4 if sp.thin_i else 32)
         B["x0"], B["x1"], B["x2"], B["x3"] = new(*R[0], nf), new(*R[1], 2 * nf), new(*R[2], 4 * nf), new(*R[3], 8 * nf)
         B["gated"] = new(Hg, Wg, 4 * nf)
         B["cat1"], B["cat2"], B["cat3"] = new(*R[2], 8 * nf), new(*R[1], 4 * nf), new(*R[0], 2 * nf)
@@ -164,7 +166,9 @@ class AesrganDiscriminatorEngine:
         st = A.stream_ptr
         rs = lambda op, a, b, h, w, c, dtype=dtc: call(lambda: A.check(L.srganfd_resample(op, a, b, dtype, N, h, w, c, st()), "resample"))
         fw: List[tuple] = [
-            cv(V(B["xin"]), V(B["x0"]), Wp("f", "conv0"), N, H, W, 32, nf, bias=P("conv0.bias"), **lre),
+            ("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, self.in_ch, P("conv0.weight"), V(B["x0"]), w_big_is_cout=True, bias=P("conv0.bias"),
+                                                             thin=B["xin"], **lre)))
+            if sp.thin_i else cv(V(B["xin"]), V(B["x0"]), Wp("f", "conv0"), N, H, W, 32, nf, bias=P("conv0.bias"), **lre),
             cv(V(B["x0"]), V(B["x1"]), Wp("f", "conv1"), N, *R[0], nf, 2 * nf, stride=2, **lre),
             cv(V(B["x1"]), V(B["x2"]), Wp("f", "conv2"), N, *R[1], 2 * nf, 4 * nf, stride=2, **lre),
             cv(V(B["x2"]), V(B["x3"]), Wp("f", "conv3"), N, *R[2], 4 * nf, 8 * nf, stride=2, **lre),
@@ -213,8 +217,12 @@ class AesrganDiscriminatorEngine:
             cv(V(B["c7"]), V(B["c8"]), Wp("f", "conv8"), N, *R[0], nf, nf, **lre),
         ]
         sp.fw = fw
-        sp.conv9 = lambda logits: ops.conv_args(dtc, V(B["c8"]), A.View(logits.data_ptr(), 1, 0), Wp("f", "conv9"), N, H, W, nf, 32,
-                                                 cout_store=1, bias=P("conv9.bias"), y_f32=True)
+        if sp.thin_o:
+            sp.conv9 = lambda logits: ("thin", ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, H, W, 1, P("conv9.weight"), V(B["c8"]), w_big_is_cout=False,
+                                                                                        bias=P("conv9.bias"), thin_out=logits.data_ptr(), thin_out_pitch=1)))
+        else:
+            sp.conv9 = lambda logits: ("conv", ops.conv_args(dtc, V(B["c8"]), A.View(logits.data_ptr(), 1, 0), Wp("f", "conv9"), N, H, W, nf, 32,
+                                                             cout_store=1, bias=P("conv9.bias"), y_f32=True))
         sp.R, sp.Rg = R, (Hg, Wg)
         self._plan_backward(sp, pk)
         self.shapes[key] = sp
@@ -226,6 +234,8 @@ class AesrganDiscriminatorEngine:
         Hg, Wg = sp.Rg
         wptr, O = pk["buf"].data_ptr(), pk["offs"]
         Wp = lambda *key: wptr + O[key]
+        fptr = self.fp.flat.data_ptr()
+        P = lambda name: fptr + 4 * self.fp.off(name)      # (used while the plan is built only, not stored on it)
         st = A.stream_ptr
 
         def new(h, w, c, dtype=dt):
@@ -262,7 +272,9 @@ class AesrganDiscriminatorEngine:
                 items.append(("conv", a))
             return items
 
-        sp.dl = new(H, W, 32)
+        sp.dl = new(H, W, 4 if sp.thin_o else 32)
+        if sp.thin_i or sp.thin_o:
+            sp.thin_ws = torch.empty(ops.thin_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
         G = sp.G = {}
         G["g8"], G["g7"], G["g6"] = new(*R[0], nf), new(*R[0], nf), new(*R[0], nf)
         G["dc3"], G["db5"], G["dx5"] = new(*R[0], 2 * nf), new(*R[0], 2 * nf), new(*R[1], 2 * nf)
@@ -308,9 +320,15 @@ class AesrganDiscriminatorEngine:
             ]
             return items
 
-        bw: List[tuple] = [
-            wg("conv9", B["c8"], sp.dl, H, W, nf, 32, cout_real=1, bias=True),
-            cv(V(sp.dl), V(G["g8"]), Wp("b", "conv9"), N, H, W, 32, nf, mask=V(B["c8"]), mask_slope=0.2),
+        if sp.thin_o:
+            head = [("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, H, W, 1, P("conv9.weight"), V(B["c8"]), w_big_is_cout=False, thin=sp.dl),
+                                            dw_off=self._poff("conv9.weight"), db_off=self._poff("conv9.bias"), ws=sp.thin_ws)),
+                    ("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, 1, P("conv9.weight"), V(G["g8"]), w_big_is_cout=False, flip=True,
+                                                                     mask=V(B["c8"]), mask_slope=0.2, thin=sp.dl)))]
+        else:
+            head = [wg("conv9", B["c8"], sp.dl, H, W, nf, 32, cout_real=1, bias=True),
+                    cv(V(sp.dl), V(G["g8"]), Wp("b", "conv9"), N, H, W, 32, nf, mask=V(B["c8"]), mask_slope=0.2)]
+        bw: List[tuple] = head + [
             wg("conv8", B["c7"], G["g8"], H, W, nf, nf, sn=True),
             cv(V(G["g8"]), V(G["g7"]), Wp("b", "conv8"), N, H, W, nf, nf, mask=V(B["c7"]), mask_slope=0.2),
             wg("conv7", B["x6"], G["g7"], H, W, nf, nf, sn=True),
@@ -358,9 +376,15 @@ class AesrganDiscriminatorEngine:
         bw.append(wg("conv1", B["x0"], G["dx1"], *R[0], nf, 2 * nf, s=2, sn=True))
         bw += strided_dgrad(lambda par: ("b", "conv1", par), 2, G["dx1"], G["dx0"], *R[1], 2 * nf, nf,
                             r1=sp.attn[3]["grad"]["dxg"], r2=sp.attn[3]["grad"]["dxt"], mask=B["x0"])
-        bw.append(wg("conv0", B["xin"], G["dx0"], H, W, 32, nf, cin_real=self.in_ch, bias=True))
+        if sp.thin_i:
+            bw.append(("thin", ops.ThinLaunch("thin_wgrad", ops.thin_args(dtc, N, H, W, self.in_ch, P("conv0.weight"), V(G["dx0"]), w_big_is_cout=True, thin=B["xin"]),
+                                              dw_off=self._poff("conv0.weight"), db_off=self._poff("conv0.bias"), ws=sp.thin_ws)))
+            sp.dx_conv = ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, H, W, self.in_ch, P("conv0.weight"), V(G["dx0"]), w_big_is_cout=True, flip=True,
+                                                                  thin_out=sp.dxp, thin_out_pitch=4))
+        else:
+            bw.append(wg("conv0", B["xin"], G["dx0"], H, W, 32, nf, cin_real=self.in_ch, bias=True))
+            sp.dx_conv = ops.conv_args(dtc, V(G["dx0"]), V(sp.dxp), Wp("b", "conv0"), N, H, W, nf, 32, cout_store=self.in_ch, y_f32=True)
         sp.bw = bw
-        sp.dx_conv = ops.conv_args(dtc, V(G["dx0"]), V(sp.dxp), Wp("b", "conv0"), N, H, W, nf, 32, cout_store=self.in_ch, y_f32=True)
         sp.wg_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         sp.gtmp = torch.zeros(self.fp.total, dtype=torch.float32, device=device)
         sp.sn_ws = torch.empty(len(SN_LAYERS) * A.SN_GRAD_WS_FLOATS, dtype=torch.float32, device=device)
@@ -384,11 +408,13 @@ class AesrganDiscriminatorEngine:
         sp = self._plan(N, H, W, dt, dtc, dev, pk)
         L, st = A.lib(), A.stream_ptr()
         x = x.contiguous().float()
-        A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.B["xin"]), dtc, 32, None, None, st), "nchw_to_nhwc")
+        A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.in_ch, H, W, A.view(sp.B["xin"]), dtc, sp.B["xin"].shape[-1], None, None, st), "nchw_to_nhwc")
         logits = torch.empty(N, 1, H, W, dtype=torch.float32, device=dev)
         rec = profiling.REC
-        for kind, item in sp.fw + [("conv", sp.conv9(logits))]:
-            if kind == "conv":
+        for kind, item in sp.fw + [sp.conv9(logits)]:
+            if kind == "thin":
+                item.launch(rec)
+            elif kind == "conv":
                 self._run_conv(L, st, item, rec, "conv2d")
             elif kind == "bn":
                 k, xv, yv, npix, Ck, gamma, beta, bn, save = item
@@ -426,7 +452,7 @@ class AesrganDiscriminatorEngine:
         L, st = A.lib(), A.stream_ptr()
         N, H, W, dtc = sp.N, sp.H, sp.W, sp.dtc
         dlogits = dlogits.contiguous().float()
-        A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, 32, None, None, st), "nchw_to_nhwc")
+        A.check(L.srganfd_nchw_to_nhwc(dlogits.data_ptr(), N, 1, H, W, A.view(sp.dl), dtc, sp.dl.shape[-1], None, None, st), "nchw_to_nhwc")
         flat = self.fp.flat
         # the flat gradient also receives BatchNorm's dgamma/dbeta; frozen-parameter passes write them to scratch
         flat_grad = self.fp.new_grad(sp.device) if need_wgrad else sp.gtmp
@@ -436,6 +462,10 @@ class AesrganDiscriminatorEngine:
             kind = item[0]
             if kind == "conv":
                 self._run_conv(L, st, item[1], rec, "conv2d(dgrad)")
+            elif kind == "thin":
+                if item[1].is_wgrad and not need_wgrad:
+                    continue
+                item[1].launch(rec, flat_grad.data_ptr())
             elif kind == "wgrad":
                 if not need_wgrad:
                     continue
@@ -478,7 +508,10 @@ class AesrganDiscriminatorEngine:
         ops.spectral_norm_grad_batch(sn_grads, sp.sn_ws)       # dL/d(W/sigma) -> dL/dW_orig for every normalised layer, batched
         dx = None
         if need_dx:
-            A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv0)")
+            if type(sp.dx_conv) is ops.ThinLaunch:
+                sp.dx_conv.launch(rec)
+            else:
+                A.check(L.srganfd_conv2d(C.byref(sp.dx_conv), st), "conv2d(dgrad conv0)")
             dx = torch.empty(N, self.in_ch, H, W, dtype=torch.float32, device=sp.device)
             A.check(L.srganfd_nhwc_to_nchw(A.view(sp.dxp), A.F32, N, self.in_ch, H, W, dx.data_ptr(), 0, st), "nhwc_to_nchw")
         return (flat_grad if need_wgrad else None), dx

@@ -63,7 +63,9 @@ class ContentLossGradEngine:
         sp.N, sp.H, sp.W, sp.dt, sp.dtc, sp.device = N, H, W, dt, dtc, dev
         es = torch.empty(0, dtype=dt).element_size()
         fptr, wptr, O = self.fp.flat.data_ptr(), pk["buf"].data_ptr(), pk["offs"]
-        sp.xin = torch.empty(2 * N, H, W, 32, dtype=dt, device=dev)
+        # features.0 (3 -> 64) and its data gradient on the thin-side kernels in the 16-bit modes (csrc/conv_thin.hip): 4-channel pitch
+        sp.thin = ops.thin_ok(dtc, self.owner.features[0].weight.shape[0], 3)
+        sp.xin = torch.empty(2 * N, H, W, 4 if sp.thin else 32, dtype=dt, device=dev)
         half = lambda t: A.View(t.data_ptr(), t.shape[3], 0)                     # SR half (first N images)
         other = lambda t: A.View(t.data_ptr() + t[:N].numel() * es, t.shape[3], 0)   # GT half
         fw, chain = [], []          # chain: (kind, index, tensor, h, w, c) in forward order
@@ -74,9 +76,14 @@ class ContentLossGradEngine:
             if isinstance(m, nn.Conv2d):
                 co = m.weight.shape[0]
                 out = torch.empty(2 * N, h, w, co, dtype=dt, device=dev)
-                fw.append(("conv", ops.conv_args(dtc, A.view(cur), A.view(out), wptr + O[("f", idx)], 2 * N, h, w, ch, co,
-                                                 bias=fptr + 4 * self.fp.off(f"features.{idx}.bias"),
-                                                 act=A.ACT_NONE if idx == self.last else A.ACT_RELU)))
+                if idx == 0 and sp.thin:
+                    fw.append(("thin", ops.ThinLaunch("thin_in", ops.thin_args(dtc, 2 * N, h, w, 3, fptr + 4 * self.fp.off("features.0.weight"), A.view(out),
+                                                                               w_big_is_cout=True, bias=fptr + 4 * self.fp.off("features.0.bias"),
+                                                                               act=A.ACT_NONE if idx == self.last else A.ACT_RELU, thin=sp.xin))))
+                else:
+                    fw.append(("conv", ops.conv_args(dtc, A.view(cur), A.view(out), wptr + O[("f", idx)], 2 * N, h, w, ch, co,
+                                                     bias=fptr + 4 * self.fp.off(f"features.{idx}.bias"),
+                                                     act=A.ACT_NONE if idx == self.last else A.ACT_RELU)))
                 chain.append(("conv", idx, cur, out, h, w, ch, co))
                 cur, ch = out, co
             elif isinstance(m, nn.MaxPool2d):
@@ -99,7 +106,11 @@ class ContentLossGradEngine:
             kind, idx, tin, tout, hh, ww, cin, cout = chain[j]
             if kind == "conv":
                 if idx == 0:
-                    bw.append(("conv", ops.conv_args(dtc, A.view(g), A.view(sp.dxp), wptr + O[("b", 0)], N, hh, ww, cout, 32, cout_store=3, y_f32=True)))
+                    if sp.thin:
+                        bw.append(("thin", ops.ThinLaunch("thin_out", ops.thin_args(dtc, N, hh, ww, 3, fptr + 4 * self.fp.off("features.0.weight"), A.view(g),
+                                                                                    w_big_is_cout=True, flip=True, thin_out=sp.dxp, thin_out_pitch=4))))
+                    else:
+                        bw.append(("conv", ops.conv_args(dtc, A.view(g), A.view(sp.dxp), wptr + O[("b", 0)], N, hh, ww, cout, 32, cout_store=3, y_f32=True)))
                     break
                 prev_kind = chain[j - 1][0]
                 gin = torch.empty(N, hh, ww, cin, dtype=dt, device=dev)
@@ -130,11 +141,14 @@ class ContentLossGradEngine:
         mean, std = self.owner.mean, self.owner.std
         for img, hf in ((sr, 0), (gt, 1)):
             img = img.detach().contiguous().float()
-            dst = A.View(sp.xin.data_ptr() + hf * N * H * W * 32 * sp.xin.element_size(), 32, 0)
-            A.check(L.srganfd_nchw_to_nhwc(img.data_ptr(), N, 3, H, W, dst, dtc, 32, mean.data_ptr(), std.data_ptr(), st), "nchw_to_nhwc")
+            cpad = sp.xin.shape[-1]
+            dst = A.View(sp.xin.data_ptr() + hf * N * H * W * cpad * sp.xin.element_size(), cpad, 0)
+            A.check(L.srganfd_nchw_to_nhwc(img.data_ptr(), N, 3, H, W, dst, dtc, cpad, mean.data_ptr(), std.data_ptr(), st), "nchw_to_nhwc")
         rec = profiling.REC
         for kind, item in sp.fw:
-            if kind == "conv":
+            if kind == "thin":
+                item.launch(rec)
+            elif kind == "conv":
                 if rec is None:
                     A.check(L.srganfd_conv2d(C.byref(item), st), "conv2d(vgg)")
                 else:
@@ -165,7 +179,9 @@ class ContentLossGradEngine:
                                         weight / float(N * h * w * c), st), "l1_grad_views")
         rec = profiling.REC
         for kind, item in sp.bw:
-            if kind == "conv":
+            if kind == "thin":
+                item.launch(rec)
+            elif kind == "conv":
                 if rec is None:
                     A.check(L.srganfd_conv2d(C.byref(item), st), "conv2d(vgg dgrad)")
                 else:
