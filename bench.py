@@ -205,7 +205,8 @@ def main():
             r = run_workload(margs, wl, rank, world, dev, pg, module_loop=True)
             extra[wl] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"], "steps": margs.steps, "warmup": margs.warmup,
                          "fused_ms_per_step": fused["ms_per_step"], "module_over_fused": round(r["ms_per_step"] / fused["ms_per_step"], 4),
-                         "loss_scale": r.get("loss_scale"), "last_step_scalars": r.get("last_step_scalars")}
+                         "loss_scale": r.get("loss_scale"), "last_step_scalars": r.get("last_step_scalars"),
+                         "sections_ms": r.get("module_loop_sections_ms")}
         out["extra"] = {"module_loop": extra,
                         "what": "the reference's loop statements (amp.autocast + GradScaler, torch.optim.Adam, AveragedModel, autograd) over the drop-in "
                                 "modules with nothing set on them; the headline fields are the fused trainers"}
@@ -363,6 +364,21 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False):
                                            "what": "main-stream stall at the reducers' wait points, max over ranks"}
     if module_loop:
         out["config"]["loop"] = "module-level: the reference's statements over the drop-in modules (autocast + GradScaler + torch.optim.Adam + AveragedModel)"
+        # where the module-level step spends its time: two more steps with an event at each section boundary (outside the timed region)
+        sect = {}
+        for i in range(2):
+            marks = [("start", torch.cuda.Event(enable_timing=True))]
+            marks[0][1].record()
+
+            def mark(name):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+            step_fn(*batches[i % n_batches], mark=mark)
+            torch.cuda.synchronize()
+            for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+                sect[name] = sect.get(name, 0.0) + e0.elapsed_time(e1) / 2
+        out["module_loop_sections_ms"] = {k: round(v, 3) for k, v in sect.items()}
         sc = getattr(step_fn, "scaler", None)
         if sc is not None and sc.is_enabled():
             out["loss_scale"] = {"enabled": True, "scale": sc.get_scale()}
@@ -405,15 +421,18 @@ def module_level_loop(workload, M, g, dev, cdt):
         g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)      # bsrnet_config.py:86-96
         pw = torch.Tensor([1.0]).to(dev)
 
-        def step(lr, gt):
+        def step(lr, gt, mark=lambda name: None):
             g.zero_grad(set_to_none=True)
             with ac():
                 sr = g(lr)
                 loss = torch.sum(torch.mul(pw, l1(sr, gt)))
             scaler.scale(loss).backward()
+            mark("forward_backward")
             scaler.step(g_opt)
             scaler.update()
+            mark("gradscaler_and_torch_adam")
             ema.update_parameters(g)
+            mark("averaged_model_update")
             return loss.detach().reshape(1)
         step.scaler = scaler
         return step
@@ -424,7 +443,7 @@ def module_level_loop(workload, M, g, dev, cdt):
     bce = torch.nn.BCEWithLogitsLoss()
     pw, cw, aw = (torch.Tensor(w).to(dev) for w in ([20.0], [1.0], [0.5]))          # bsrgan_config.py:137-143
 
-    def step(lr, gt):
+    def step(lr, gt, mark=lambda name: None):
         B, _, H, W = gt.shape
         real = torch.full([B, 1, H, W], 1.0, dtype=gt.dtype, device=dev)
         fake = torch.full([B, 1, H, W], 0.0, dtype=gt.dtype, device=dev)
@@ -441,8 +460,10 @@ def module_level_loop(workload, M, g, dev, cdt):
             d_loss_sr = bce(sr_output, fake)
         scaler.scale(d_loss_sr).backward()
         d_loss = d_loss_hr + d_loss_sr
+        mark("forward_backward")
         scaler.step(d_opt)
         scaler.update()
+        mark("gradscaler_and_torch_adam")
         for p in d.parameters():
             p.requires_grad = False
         g.zero_grad(set_to_none=True)
@@ -455,9 +476,12 @@ def module_level_loop(workload, M, g, dev, cdt):
             adv = torch.sum(torch.mul(aw, adv))
             g_loss = pixel + content + adv
         scaler.scale(g_loss).backward()
+        mark("forward_backward")
         scaler.step(g_opt)
         scaler.update()
+        mark("gradscaler_and_torch_adam")
         ema.update_parameters(g)
+        mark("averaged_model_update")
         d_gt = torch.mean(torch.sigmoid_(gt_output.detach()))
         d_sr = torch.mean(torch.sigmoid_(sr_output.detach()))
         return torch.stack([d_loss.detach(), pixel.detach(), content.detach(), adv.detach(), d_gt, d_sr])
