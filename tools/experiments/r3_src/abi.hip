@@ -6,6 +6,10 @@
 namespace srganfd {
 thread_local char g_err[512] = {0};
 int g_dry_run = 0;
+#ifdef SRGANFD_EXPERIMENT
+int g_debug = 0;
+unsigned long long* g_stamp_buf = nullptr;
+#endif
 thread_local char* g_describe = nullptr;
 thread_local size_t g_describe_len = 0;
 int set_err(int code, const char* fmt, ...) {
@@ -17,6 +21,9 @@ int set_err(int code, const char* fmt, ...) {
 }
 int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream);
 int conv2d_chain_impl(const srganfd_conv_args* args, int n, void* counters, hipStream_t stream);
+#ifdef SRGANFD_EXPERIMENT
+extern int g_igemm_variant, g_no_epi_kinds, g_no_persist, g_use_db;
+#endif
 int pack_weights_impl(const srganfd_pack_job* jobs_dev, int njobs, long long max_elems, const float* params,
                       const float* scalars, void* packed, hipStream_t stream);
 size_t wgrad_plan_bytes_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs);
@@ -90,10 +97,6 @@ int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dty
                        float* dgamma, float* dbeta, float acc, float* ws, srganfd_view act, float act_slope, hipStream_t s, int phase = 0,
                        const float* ws_global = nullptr, size_t total_npix = 0);
 long long batchnorm_partial_floats_impl(int c);
-int conv2d_thin_in_impl(const srganfd_thin_args* a, hipStream_t s);
-int conv2d_thin_out_impl(const srganfd_thin_args* a, hipStream_t s);
-size_t conv2d_thin_wgrad_workspace_impl();
-int conv2d_thin_wgrad_impl(const srganfd_thin_args* a, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace srganfd
 
 using namespace srganfd;
@@ -101,10 +104,17 @@ using namespace srganfd;
 extern "C" {
 
 const char* srganfd_last_error(void) { return g_err; }
-int srganfd_abi_version(void) { return SRGANFD_ABI_VERSION; }
+int srganfd_abi_version(void) { return 3; }
 void srganfd_set_dry_run(int on) { g_dry_run = on ? 1 : 0; }
 int srganfd_get_mfma16(void) { return srganfd::g_mfma16; }
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganfd::conv_uses_m16(dtype, ksize, n) ? 1 : 0; }
+#ifdef SRGANFD_EXPERIMENT
+void srganfd_set_mfma16(int on) { srganfd::g_mfma16 = on; }
+void srganfd_set_stamp_buffer(void* p) { srganfd::g_stamp_buf = (unsigned long long*)p; }
+void srganfd_set_igemm_variant(int v) { srganfd::g_igemm_variant = v & 255; srganfd::g_no_epi_kinds = (v >> 8) & 1; srganfd::g_no_persist = (v >> 9) & 1; srganfd::g_use_db = (v >> 10) & 1; srganfd::g_use_stream = (v >> 11) & 1; }   // kbench A/B
+void srganfd_set_debug(int flags) { g_debug = flags; }   // tools/build_variant.sh builds only: kernel timing experiments
+int srganfd_conv2d_chain(const srganfd_conv_args* a, int n, void* counters, void* stream) { return conv2d_chain_impl(a, n, counters, (hipStream_t)stream); }   // tools/r3/chain_bench.py
+#endif
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }
 int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_len) {
@@ -114,13 +124,6 @@ int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_le
   const int rc = conv2d_impl(a, nullptr);
   g_describe = nullptr; g_describe_len = 0;
   return rc;
-}
-
-int srganfd_conv2d_thin_in(const srganfd_thin_args* a, void* stream) { return conv2d_thin_in_impl(a, (hipStream_t)stream); }
-int srganfd_conv2d_thin_out(const srganfd_thin_args* a, void* stream) { return conv2d_thin_out_impl(a, (hipStream_t)stream); }
-size_t srganfd_conv2d_thin_wgrad_workspace(void) { return conv2d_thin_wgrad_workspace_impl(); }
-int srganfd_conv2d_thin_wgrad(const srganfd_thin_args* a, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
-  return conv2d_thin_wgrad_impl(a, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 size_t srganfd_packed_bytes(int32_t dtype, int32_t ksize, int32_t k, int32_t n) {

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "../../include/srganfd.h"
+#include "srganfd.h"   // the round-3 header with the experiment exports
 
 namespace srganfd {
 
@@ -82,6 +82,9 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) {
 }
 
 extern thread_local char g_err[512];
+#ifdef SRGANFD_EXPERIMENT
+extern int g_debug;    // srganfd_set_debug: kernel timing experiments, results are WRONG when non-zero
+#endif
 extern int g_dry_run;  // srganfd_set_dry_run(1): validate arguments, build plans, launch nothing (host-logic tests on CPU)
 int set_err(int code, const char* fmt, ...);
 // srganfd_conv2d_describe: the launch functions write the label of the kernel they would run here instead of launching

@@ -1,11 +1,18 @@
 // conv_common.hpp -- launch arguments and MFMA helpers shared by the fused-convolution kernels
-// (conv_igemm.hip: every kernel shape; conv_thin.hip; wgrad.hip).  The kernel-timing experiment harness of rounds 1-3 (debug ablation
-// switches, s_memrealtime stamps, ring / stream / chain / pair-fusion kernels) lives in tools/experiments/ with its own copy of these sources.
+// (conv_igemm.hip: every kernel shape; tools/experiments/conv3x3_ring.hip: the LDS-DMA ring experiment).
 #pragma once
 #include <utility>
 #include "common.hpp"
 
 namespace srganfd {
+
+// Kernel timing experiments (tools/build_variant.sh builds with -DSRGANFD_EXPERIMENT): the product library neither
+// carries the branches nor exports srganfd_set_debug.
+#ifdef SRGANFD_EXPERIMENT
+#define SRGANFD_DBG(flags, bit) ((flags) & (bit))
+#else
+#define SRGANFD_DBG(flags, bit) 0
+#endif
 
 struct ConvK {
   const void* x; void* y; void* y2; const void* r1; const void* r2; const void* mask; const void* w;
@@ -24,7 +31,14 @@ struct ConvK {
   unsigned m_nNb, m_tx, m_ty;   // ceil(2^32 / d) for the block-index decode (0: divide), see fast_div
   float alpha, slope, post_scale, r1s, r2s, mask_slope;
   int act, y_f32, fast_epi;
+#ifdef SRGANFD_EXPERIMENT
+  int dbg;            // 1 no x loads, 2 no w loads, 4 no epilogue, 8 no LDS commit, 32 no barriers
+  unsigned long long* stamps;   // s_memtime stamps of the first workgroups (tools/stamps.py), else NULL
+#endif
 };
+#ifdef SRGANFD_EXPERIMENT
+extern unsigned long long* g_stamp_buf;
+#endif
 
 template <typename T> struct FragAB;
 template <> struct FragAB<bf16_t> { typedef bf16x8 type; };
@@ -89,5 +103,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 int conv_device_cus();   // compute units of the current device (conv_igemm.hip)
+#ifdef SRGANFD_EXPERIMENT
+extern int g_use_stream;
+int conv_stream_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);   // tools/experiments/conv_stream.hip
+int conv3x3_ring_try(const srganfd_conv_args* a, const ConvK& k, hipStream_t stream, bool* handled);   // tools/experiments/conv3x3_ring.hip
+#endif
 
 }  // namespace srganfd

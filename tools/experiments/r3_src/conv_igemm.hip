@@ -45,7 +45,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 // TS = tap split: the weight slab of a 32-channel chunk is staged in TS pieces of KS/TS kernel rows (the 4x4 stride-2 kernel: 64 KiB of
 // weights per chunk next to a 42 KiB patch would leave room for ONE workgroup per CU; in halves two fit)
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, int TS = 1>
+// DB = the chunk stage (patch + weight slab) is double-buffered in LDS (see the kernel)
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, int TS = 1, bool DB = false>
 struct ConvCfg {
   static constexpr int NWAVES = WR * WN, NTHR = 64 * NWAVES;
   static constexpr int KT = KS * KS;
@@ -69,7 +70,8 @@ struct ConvCfg {
   static constexpr int STAGE_BYTES = XBYTES + WN * WS_BYTES;
   static constexpr int NB = 32 * WN;                           // output channels per workgroup
   static constexpr int EPI_BYTES = TH * TW * NB * 4;           // fp32 tile for the vectorised epilogue
-  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int STAGES_BYTES = (DB ? 2 : 1) * STAGE_BYTES;
+  static constexpr int LDS_BYTES = STAGES_BYTES > EPI_BYTES ? STAGES_BYTES : EPI_BYTES;
   static constexpr int NROWS = (MR - 1) * STRIDE + KS;         // patch rows one wave touches
   static constexpr int PIX_PER_I = NTHR / CPP;                 // pixels advanced per staging item index
   static_assert(PIX_PER_I % 32 == 0, "swizzle term must not depend on the staging item index");
@@ -122,11 +124,23 @@ template <int MR> struct AccSet<true, MR> {
 // y2, no fp32 / partial-channel output.  A fixed kind carries no loads, address arithmetic, prefetch registers or branches for tensors
 // the launch does not have: the four growth convs of a dense block (kind 0) and their data-gradient twins (kind 4) are 80 % of a
 // generator step's launches.
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
-__device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
+// DB (16 waves, 64-channel tiles of 16 rows: one workgroup per CU): the stage of chunk c+1 is written into the OTHER LDS buffer by each
+// wave as soon as its own MFMA phase of chunk c is over and its loads have arrived -- one barrier per chunk instead of two, no wave
+// waits at a barrier before it may commit, the weight slab is staged once per 512 pixels instead of once per 256, and the staging
+// registers shrink from 32 to 24 per lane (profiles/r03_conv_timeline.txt: of the 3.45 us a 64-channel tile spends per chunk, 1.45 are
+// the MFMA phase, 0.9 the wait at the barrier in front of the commit and 0.9 the commit).
+// CHAIN (conv_chain_kernel below): the body runs as one STAGE of a chain of dependent launches inside one kernel.  Tiles are claimed from a
+// per-XCD counter (cc.claim; tile ids cc.tile0 + [0, cc.ntiles) are this XCD's images), the loads of a tile's LAST chunk -- the 32
+// channels the previous stage wrote -- wait until that stage has finished every tile of this XCD (cc.prev_done >= cc.prev_target), and a
+// finished tile is counted in cc.done once its stores have been acknowledged.
+struct ChainCtl { unsigned* claim; unsigned* done; const unsigned* prev_done; unsigned prev_target; int tile0, ntiles; };
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false, bool CHAIN = false>
+__device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem, const ChainCtl cc) {
+  static_assert(!CHAIN || (TS == 1 && !DB && sizeof(T) == 2), "chained stages: the 16-bit single-stage kernels");
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
+  static_assert(!DB || (M16 && TS == 1), "double-buffered stages: 16-bit kernels, one stage per chunk");
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>;
   using Frag = typename FragAB<T>::type;
   constexpr int NTHR = C::NTHR;
   char* ldsX = smem;
@@ -137,7 +151,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
+#ifdef SRGANFD_EXPERIMENT
+  // stagger experiment (dbg bit 128, delay = dbg >> 8 units of s_sleep 127): the workgroup whose wave 0 sits in wave slot >= 2 of its SIMD
+  // (the second resident workgroup of the CU at 4 waves per SIMD) starts late, so that the two workgroups' MFMA phases interleave
+  if ((a.dbg & 128) && wave == 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID: wave slot in bits 3:0
+    if ((hwid & 0xf) >= 2)
+      for (int i = 0; i < (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
+#ifdef SRGANFD_EXPERIMENT
+  // timeline stamps (tools/r3/conv_stamps.py): s_memtime of wave 0 and wave NWAVES-1 of 256 sampled workgroups at fixed points of the tile
+  unsigned long long* stamp_p = (a.stamps && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 256 && (wave == 0 || wave == WR * WN - 1) && lane == 0)
+                                    ? a.stamps + (((size_t)(blockIdx.x >> 2) * 2 + (wave ? 1 : 0)) * 32) : nullptr;
+  int stamp_i = 0;
+#define CONV_STAMP() do { if (stamp_p && stamp_i < 32) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_p[stamp_i++] = t_; } } while (0)
+#else
+#define CONV_STAMP() do { } while (0)
+#endif
+  CONV_STAMP();   // 0: kernel entry
   // Persistent tiles: workgroup b runs the virtual blocks b, b + gridDim.x, ... (the host sizes the grid to the workgroups the chip
   // holds at once for the kernels that prefetch across tiles, and to one block per workgroup otherwise).  A tile's first chunk is
   // requested while the previous tile of the workgroup is still in its last MFMA phase and epilogue: measured per tile (s_memrealtime
@@ -147,7 +180,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   // tiles), block-uniform by construction; the readfirstlane tells the compiler so (otherwise every address product downstream
   // stays in quarter-rate vector multiplies).
   auto decode = [&](int vb, int& n_, int& oy_, int& ox_, int& nb_) {
-    const int bid = xcd_remap(vb, a.nblocks);
+    const int bid = CHAIN ? vb : xcd_remap(vb, a.nblocks);
     const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
     nb_ = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
     const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
@@ -207,7 +240,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
       int py, px, c16;
       item_pos(tid_o, i, py, px, c16);
       const int gy = oy_ * STRIDE - a.pad_y + py, gx = ox_ * STRIDE - a.pad_x + px;
-      const bool ok = tid_o + i * NTHR < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+      const bool ok = tid_o + i * NTHR < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl && !SRGANFD_DBG(a.dbg, 1);
       xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
     }
   };
@@ -258,13 +291,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
     const int nn = item / (C::WS_BYTES / 16), rem = item % (C::WS_BYTES / 16);
     if constexpr (kBuf) {
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned v4u;
-      const bool ok = item < C::NW16;
+      const bool ok = item < C::NW16 && !SRGANFD_DBG(a.dbg, 2);
       const v4u r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? (nn * a.nChunks * (C::WN_BYTES / 16) + rem) * 16 : kOob,
                                                           (chunk * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16)) * 16, 0);
       return __builtin_bit_cast(u32x4, r);
     } else {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (item < C::NW16) v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16) + rem];
+      if (item < C::NW16 && !SRGANFD_DBG(a.dbg, 2)) v = wgp[(nn * a.nChunks + chunk) * (C::WN_BYTES / 16) + th * (C::WS_BYTES / 16) + rem];
       return v;
     }
   };
@@ -342,7 +375,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   };
   // tiles after the first: requested during the previous tile's last MFMA phase (the kinds whose epilogue leaves room for the 32
   // staging registers), else after its epilogue
-  constexpr bool kCross = kPrefetch && EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0;
+  constexpr bool kCross = kPrefetch && EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && !DB;
 
   AccSet<M16, MR> A_;
   auto& acc = A_.a;
@@ -350,6 +383,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   // this lane's A-fragment base: patch pixel (wr*MR*S, r*S), B-fragment base: n-tile wn
   const int pix00 = (wr * MR * STRIDE) * C::PC + r * STRIDE;
   const char* ldsWn = ldsW + wn * C::WS_BYTES + lane * C::FRAGB;
+  // double-buffered stages: point the staging stores / the fragment reads at buffer b
+  auto set_stage = [&](int b) {
+    ldsX = smem + b * C::STAGE_BYTES;
+    ldsW = ldsX + C::XBYTES;
+    ldsWn = ldsW + wn * C::WS_BYTES + lane * C::FRAGB;
+  };
 
   // 16x16x32 form, stride 1: lane term of the fragment address per kernel column (chunk-invariant)
   int colt[KS];
@@ -360,13 +399,34 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   // device-side scale is a scalar load, the two bias values of this lane's channels cost two registers through the loop
   float alpha = a.alpha;
   if (a.alpha_dev) alpha *= *a.alpha_dev;
+  if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(2);
+  // chained stages: thread 0 claims the next tile of this XCD's range and leaves it in an LDS word behind the kernel's LDS image; the
+  // others read it behind a barrier (the first claim here, later ones behind the first chunk's barriers)
+  volatile int* claim_slot = (volatile int*)(smem + C::LDS_BYTES);
+  unsigned claim_val = 0u;          // thread 0: the claimed index, requested at the top of a tile and published before its first chunk's second barrier
+  auto claim_issue = [&]() { if (CHAIN && tid == 0) claim_val = atomicAdd(cc.claim, 1u); };
+  auto claim_publish = [&]() { if (CHAIN && tid == 0) *claim_slot = cc.tile0 + (int)claim_val; };
+  const int vt_end = CHAIN ? cc.tile0 + cc.ntiles : a.nblocks;
   int vt = blockIdx.x;
+  if constexpr (CHAIN) {
+    claim_issue();
+    claim_publish();
+    __syncthreads();
+    vt = __builtin_amdgcn_readfirstlane(*claim_slot);
+    __syncthreads();
+    if (vt >= vt_end) return;
+  }
+  bool done_pending = false;        // a finished tile of this workgroup is not yet counted in cc.done
+  bool dep_ok = false;              // the previous stage is known to have finished this XCD's tiles
   setup_loads(vt);
+  if (SRGANFD_DBG(a.dbg, 1024)) __builtin_amdgcn_s_setprio(0);
+  CONV_STAMP();   // 1: prologue done
   first_loads();
   for (;;) {
   // (cin >= 32 is host-checked; without the hint the compiler sees a path from the bias loads below to the epilogue that skips the
   // chunk loop's waits, and guards the epilogue with s_waitcnt vmcnt(0) -- which would also wait for the next tile's staging loads)
   __builtin_assume(a.nChunks >= 1);
+  claim_issue();
   int vt_next = vt + (int)gridDim.x;
   bool more = kCross && vt_next < a.nblocks;      // this workgroup has another tile after this one (the host gives the other kinds one block per workgroup)
   int n, oy0, ox0, nb;
@@ -430,14 +490,53 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
       });
     }
   } else {
+  if constexpr (DB) {
+    __syncthreads();          // (a previous tile's epilogue tile lies over both buffers)
+    set_stage(0);
+    commit(0);
+  }
   for (int chunk = 0; chunk < a.nChunks; ++chunk) {
-    __syncthreads();
-    commit(chunk);
-    __syncthreads();
+    if constexpr (DB) {
+      __syncthreads();        // stage `chunk` is published; every wave has left the MFMA phase of chunk - 1, whose buffer takes chunk + 1
+      CONV_STAMP();
+    } else {
+    if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
+    CONV_STAMP();   // 2 + 4c: previous MFMA phase of every wave done
+    if (!SRGANFD_DBG(a.dbg, 8)) commit(chunk);
+    CONV_STAMP();   // 3 + 4c: this wave's loads arrived and are written to LDS
+    if constexpr (CHAIN) {
+      if (chunk == 0) claim_publish();
+      if (chunk + 2 == a.nChunks && cc.prev_done && !dep_ok) {
+        // the NEXT chunk is what the previous stage wrote: wave 0 waits (once per stage) until that stage has finished this XCD's tiles;
+        // the barrier below holds the others.  (Every wave polling the counter's line queued the tile claims behind the polls.)
+        if (wave == 0) {
+          for (;;) {
+            unsigned v = 0u;
+            if (lane == 0) v = __hip_atomic_load(cc.prev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= cc.prev_target) break;
+            __builtin_amdgcn_s_sleep(16);
+          }
+        }
+        dep_ok = true;
+      }
+    }
+    if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
+    CONV_STAMP();   // 4 + 4c: stage published
+    }
+    if constexpr (CHAIN) {
+      if (chunk == 0) { vt_next = __builtin_amdgcn_readfirstlane(*claim_slot); more = vt_next < vt_end; }
+      // the previous tile's stores are older than the loads this chunk's commit has just waited for (the loads of chunk 1 where the
+      // tile's first chunk was requested across the previous epilogue): every wave is past that wait here
+      if (done_pending && chunk == (kCross ? 1 : 0)) { if (tid == 0) atomicAdd(cc.done, 1u); done_pending = false; }
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (DB) set_stage(chunk & 1);
     if (chunk + 1 < a.nChunks) prefetch(chunk + 1);
     else if (kCross && more) {
+      if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(2);
       setup_loads(vt_next);
       first_loads();
+      if (SRGANFD_DBG(a.dbg, 256)) __builtin_amdgcn_s_setprio(0);
     }
 
     auto col_body = [&](int kx, int s) {
@@ -514,6 +613,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      CONV_STAMP();   // 5 + 4c: MFMA phase done
+      if constexpr (DB) {
+        if (chunk + 1 < a.nChunks) {
+          set_stage((chunk + 1) & 1);
+          commit(chunk + 1);
+          CONV_STAMP();
+        }
+      }
     } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MR == 2) {
       // Software-pipelined fragment reads: the chunk's 42 ds_read_b128 and 36 MFMAs in one fixed issue order, every read kD
       // fragments ahead of the MFMA that consumes it (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> MFMA on two
@@ -559,7 +666,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   }
 
   // ---- epilogue (see srganfd.h for the formula) ----
+  if (SRGANFD_DBG(a.dbg, 512)) __builtin_amdgcn_s_setprio(2);
   [&]() __attribute__((always_inline)) {
+  if (SRGANFD_DBG(a.dbg, 4)) { if (A_.get(0, 0) == 123.456f) ((float*)a.y)[0] = 1.f; return; }
   if constexpr (EK == 0 && M16 && WN == 1 && sizeof(T) == 2) {
     // Kind 0, 32-channel tiles (the growth convs of a dense block): bias + activation in registers, rounded to T there (the value
     // the fp32 tile path would round after its LDS round trip: same bits), and a 16-bit CHANNEL-major LDS tile per image row --
@@ -618,6 +727,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
           *(u32x4*)(ybase + pp * a.y_ps) = u32x4{lo.x, lo.y, hi.x, hi.y};
         }
       }
+    CONV_STAMP();   // stores issued
+#ifdef SRGANFD_EXPERIMENT
+    if (stamp_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CONV_STAMP(); }   // stores acknowledged
+#endif
     return;
   }
   constexpr bool kR1 = EK < 0 || (EK & 1), kR2 = EK < 0 || (EK & 2), kMk = EK < 0 || (EK & 4);   // operands this instantiation can have
@@ -723,7 +836,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
           const int cc = c0 + cch;
           T* dstp = (T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
-            *(u32x4*)dstp = pack8<T>(vv);
+            if (SRGANFD_DBG(a.dbg, 64)) __builtin_nontemporal_store(pack8<T>(vv), (u32x4*)dstp);
+            else *(u32x4*)dstp = pack8<T>(vv);
           } else {
             f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
             *(f32x4*)dstp = o;
@@ -747,6 +861,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
         store16(a.y, a.yC, a.y_c0, a.y_ps, a.y_gs, v);
       }
     }
+    CONV_STAMP();   // stores issued
+#ifdef SRGANFD_EXPERIMENT
+    if (stamp_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CONV_STAMP(); }   // stores acknowledged
+#endif
     return;
   }
   // generic epilogue (padded channel counts, fp32 output): scalar stores
@@ -783,6 +901,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   }
   }
   }();
+  if (SRGANFD_DBG(a.dbg, 512)) __builtin_amdgcn_s_setprio(0);
+  if constexpr (CHAIN) done_pending = true;
   if (!more) break;
   if constexpr (!kCross) {
     setup_loads(vt_next);
@@ -790,12 +910,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   }
   vt = vt_next;
   }   // tiles of this workgroup
+  if constexpr (CHAIN) {
+    // the stage's last tile of this workgroup: drain its stores, then count it (and the one before it, if still pending)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma clang diagnostic pop
+    __syncthreads();
+    if (tid == 0) atomicAdd(cc.done, 1u);
+  }
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
-__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
+__global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_body<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>(a, smem);
+  conv_igemm_body<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, DB, false>(a, smem, ChainCtl{nullptr, nullptr, nullptr, 0u, 0, 0});
 }
 
 // compute units of the current device (cached per device id); 256 when nothing can be asked (dry runs on the CPU)
@@ -811,15 +940,23 @@ int conv_device_cus() {
   }
   return c;
 }
+#ifdef SRGANFD_EXPERIMENT
+int g_use_db = [] { const char* e = getenv("SRGANFD_USE_DB"); return e ? atoi(e) : 0; }();   // A/B: 16-wave double-buffered 64-channel tiles (srganfd_set_igemm_variant bit 10)
+#endif
+#ifdef SRGANFD_EXPERIMENT
+int g_no_persist = [] { const char* e = getenv("SRGANFD_NO_PERSIST"); return e ? atoi(e) : 0; }();   // A/B: one workgroup per tile (srganfd_set_igemm_variant bit 9)
+#else
+constexpr int g_no_persist = 0;
+#endif
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool DB = false>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
-  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>;
+  using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS, DB>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, DB>;
   if (g_describe) {
     char ek[8] = "";
     if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
-    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek);
+    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek, DB ? ",DB" : "");
     return SRGANFD_OK;
   }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
@@ -844,7 +981,7 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   // kinds that prefetch across tiles run as persistent workgroups: as many as the chip holds at once (a multiple of 8, so that the
   // virtual blocks v, v + grid, ... of one workgroup keep their XCD class in xcd_remap)
   long long grid = nblk;
-  if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2) {
+  if (EK >= 0 && (EK & SRGANFD_CROSS_MASK) == 0 && sizeof(T) == 2 && !DB && !g_no_persist) {
     const long long slots = (long long)conv_device_cus() * C::WG_PER_CU;
     if (slots >= 8 && nblk > slots) grid = slots / 8 * 8;
   }
@@ -854,17 +991,96 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
 }
 
 
+#ifdef SRGANFD_EXPERIMENT
+// ---- chained launches (experiment, profiles/r03_conv_experiments.txt 14): the 3x3 stride-1 convs of a dense block (BSRGAN/model.py:54-58: each reads what the previous one wrote) as ONE
+// kernel.  Workgroups are persistent (two per CU); every stage's tiles are claimed per XCD -- an XCD works on whole images, so a stage's
+// input is always what a workgroup of the SAME XCD wrote (visible through its L2 once the stores are acknowledged) -- and only the
+// loads of a tile's last 32-channel chunk wait for the previous stage.  The XCD comes from the hardware register, not from the block
+// index, so correctness does not depend on how the dispatcher places workgroups.
+constexpr int kChainMax = 5;
+struct ChainK { ConvK k[kChainMax]; int n; int tiles_per_xcd[kChainMax]; unsigned* ctr; int nodep; };   // ctr[xcd][stage][64]: [0] claimed, [32] done (own 128-byte lines)
+template <typename T, int EK>
+__global__ __launch_bounds__(512, (ConvCfg<T, 3, 1, 2, 8, 1, 1, false>::MIN_WAVES_PER_SIMD)) void conv_chain_kernel(const ChainK c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));     // HW_REG_XCC_ID[3:0]
+  for (int s = 0; s < c.n; ++s) {
+    unsigned* ct = c.ctr + (xcd * kChainMax + s) * 64;
+    const ChainCtl cc{ct, ct + 32, (s && c.nodep != 1) ? ct - 32 : nullptr, s ? (c.nodep >= 2 ? (unsigned)c.nodep : (unsigned)c.tiles_per_xcd[s ? s - 1 : 0]) : 0u, xcd * c.tiles_per_xcd[s], c.tiles_per_xcd[s]};
+    conv_igemm_body<T, 3, 1, 2, 8, 1, true, 1, EK, false, true>(c.k[s], smem, cc);
+    __syncthreads();      // the next stage's first commit overwrites the LDS image this stage's last epilogue read
+  }
+}
 
-// MFMA form of the 16-bit kernels: v_mfma_f32_16x16x32 for every kernel shape (srganfd_get_mfma16() == 3).  Same-box A/B of the training
-// steps against the 32x32x16 form (profiles/r02_mfma16_ab.txt): generator-only 78.3 -> 69.4 ms, GAN 179.6 -> 173.1 ms; the chip runs these
-// steps power-limited (1.2 kW, clock at 2.06 of 2.4 GHz) and holds a higher clock on this form.  The 32x32x16 instantiations of the
-// 16-bit kernels and the level switch live in the experiment sources (tools/experiments/r3_src).
+int conv_fill_k(const srganfd_conv_args* a, ConvK& k);     // argument checks + ConvK of one launch (conv2d_impl's first half)
+
+int conv2d_chain_impl(const srganfd_conv_args* args, int n, void* counters, hipStream_t stream) {
+  if (!args || n < 1 || n > kChainMax || !counters) return set_err(SRGANFD_EINVAL, "conv2d_chain: 1..%d launches and a counter buffer", kChainMax);
+  using C = ConvCfg<f16_t, 3, 1, 2, 8, 1, 1, false>;
+  ChainK ck;
+  memset(&ck, 0, sizeof(ck));
+  ck.n = n; ck.ctr = (unsigned*)counters;
+  { const char* e = getenv("SRGANFD_CHAIN_NODEP"); ck.nodep = e ? atoi(e) : 0; }     // timing experiments only: results are wrong
+  int ek = -2;
+  for (int i = 0; i < n; ++i) {
+    const srganfd_conv_args* a = args + i;
+    ConvK& k = ck.k[i];
+    const int rc = conv_fill_k(a, k);
+    if (rc != SRGANFD_OK) return rc;
+    const int e = (k.fast_epi && !k.y2 && !k.r1 && !k.r2) ? (k.mask ? 4 : 0) : -1;
+    if (a->dtype != args[0].dtype || a->dtype == SRGANFD_F32 || a->ksize != 3 || a->stride != 1 || a->pad != 1 || a->up || a->out_sy > 1 || a->out_sx > 1 ||
+        a->cout != 32 || e < 0 || (ek != -2 && e != ek) || k.nChunks < 2 || a->n % 8 || a->n != args[0].n || a->h_out != args[0].h_out || a->w_out != args[0].w_out ||
+        !a->x.planar || !a->y.planar)
+      return set_err(SRGANFD_EINVAL, "conv2d_chain: launch %d is not a 16-bit 3x3 stride-1 32-channel conv of one kind on planar views with a batch that is a multiple of 8", i);
+    ek = e;
+    k.nNb = 1;
+    k.tiles_x = ceil_div(k.Wout, C::TW);
+    k.tiles_y = ceil_div(k.Hout, C::TH);
+    const long long nblk = (long long)k.N * k.tiles_x * k.tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d_chain: bad grid %lld", nblk);
+    k.nblocks = (int)nblk;
+    k.m_nNb = 0;
+    k.m_tx = div_magic((unsigned)k.tiles_x, (unsigned long long)nblk);
+    k.m_ty = div_magic((unsigned)k.tiles_y, (unsigned long long)nblk);
+    ck.tiles_per_xcd[i] = (int)(nblk / 8);
+  }
+  if (g_dry_run) return SRGANFD_OK;
+  SRGANFD_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(unsigned) * 8 * kChainMax * 64, stream));
+  const int lds = C::LDS_BYTES + 16;
+  const int grid = conv_device_cus() * C::WG_PER_CU;
+  auto launch = [&](auto kern) -> int {
+    SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    SRGANFD_LAUNCH(kern, dim3((unsigned)grid), dim3(512), (size_t)lds, stream, ck);
+    SRGANFD_HIP_CHECK(hipGetLastError());
+    return SRGANFD_OK;
+  };
+  if (args[0].dtype == SRGANFD_F16) return ek == 0 ? launch(conv_chain_kernel<f16_t, 0>) : launch(conv_chain_kernel<f16_t, 4>);
+  return ek == 0 ? launch(conv_chain_kernel<bf16_t, 0>) : launch(conv_chain_kernel<bf16_t, 4>);
+}
+#endif
+
+int g_igemm_variant = 0;
+#ifdef SRGANFD_EXPERIMENT
+int g_no_epi_kinds = [] { const char* e = getenv("SRGANFD_NO_EPI_KINDS"); return e ? atoi(e) : 0; }();   // A/B: run-time epilogue for every launch (srganfd_set_igemm_variant bit 8)
+#else
+constexpr int g_no_epi_kinds = 0;
+#endif
+// MFMA form of the 16-bit kernels (srganfd_set_mfma16 / environment SRGANFD_MFMA16 at load): 0 = v_mfma_f32_32x32x16 everywhere,
+// 1 = 16x16x32 for the 3x3 kernels with 32-channel tiles, 2 = for every 3x3 kernel, 3 = for every kernel shape (default).
+// Same-box A/B of the training steps (profiles/r02_mfma16_ab.txt): generator-only 78.3 (0) -> 72.7 (1) -> 69.4 ms (2), GAN 179.6 (1)
+// -> 173.1 ms (2); the chip runs these steps power-limited (1.2 kW, clock at 2.06 of 2.4 GHz) and holds a higher clock on this form.
+// The product library runs level 3 only: the 32x32x16 instantiations of the 16-bit kernels, the level switch and the LDS-DMA ring /
+// stream kernels (conv3x3_ring.hip) exist in -DSRGANFD_EXPERIMENT builds, where the A/B tools select them at run time.
+#ifdef SRGANFD_EXPERIMENT
+int g_mfma16 = [] { const char* e = getenv("SRGANFD_MFMA16"); return e ? atoi(e) : 3; }();
+#else
 int g_mfma16 = 3;
+#endif
 
 // does the kernel that consumes a packed operand of this kernel size / output width read 16x16x32 B fragments?  (pack.hip asks too)
 bool conv_uses_m16(int dtype, int ksize, int cout) {
-  (void)ksize; (void)cout;
-  return dtype != SRGANFD_F32;
+  if (dtype == SRGANFD_F32 || g_mfma16 <= 0) return false;
+  if (g_mfma16 >= 3) return true;
+  return ksize == 3 && (g_mfma16 == 2 || (cout % 64) != 0);
 }
 
 template <typename T>
@@ -875,7 +1091,25 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
     if (conv_uses_m16(a->dtype, a->ksize, a->cout)) {
       if (a->ksize == 3 && a->stride == 1) {
         // epilogue kind fixed at compile time where the launch has the vectorised epilogue and no y2 (see the kernel's EK)
-        const int ek = (k.fast_epi && !k.y2) ? ((k.r1 ? 1 : 0) | (k.r2 ? 2 : 0) | (k.mask ? 4 : 0)) : -1;
+        const int ek = (k.fast_epi && !k.y2 && !g_no_epi_kinds) ? ((k.r1 ? 1 : 0) | (k.r2 ? 2 : 0) | (k.mask ? 4 : 0)) : -1;
+#ifdef SRGANFD_EXPERIMENT
+        // tile-shape experiments on the plain kind (srganfd_set_igemm_variant low byte): 1 = 8-row tiles of 4 waves (40 KB of LDS: four
+        // workgroups per CU, four independent latency chains instead of two); 2 = 4 rows per wave (16-row tiles of 4 waves, two
+        // workgroups per CU at 256 registers)
+        if (ek == 0 && !wide && g_igemm_variant == 1) return launch_conv<T, 3, 1, 2, 4, 1, true, 1, 0>(k, a->cout, s);
+        if (ek == 0 && !wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 1, true, 1, 0>(k, a->cout, s);
+        if (ek == 0 && wide && g_igemm_variant == 2) return launch_conv<T, 3, 1, 4, 4, 2, true, 1, 0>(k, a->cout, s);
+#endif
+#ifdef SRGANFD_EXPERIMENT
+        if (wide && g_use_db && ek >= 0 && ek != 2 && ek <= 4) {
+          // experiment (rejected, profiles/r03_conv_experiments.txt 10): 64-channel tiles of 16 waves, 16 x 32 pixels, double-buffered
+          // stages, one workgroup per CU
+          if (ek == 0) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 0, true>(k, a->cout, s);
+          if (ek == 1) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 1, true>(k, a->cout, s);
+          if (ek == 3) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 3, true>(k, a->cout, s);
+          if (ek == 4) return launch_conv<T, 3, 1, 2, 8, 2, true, 1, 4, true>(k, a->cout, s);
+        }
+#endif
         if (wide) {
           if (ek == 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 0>(k, a->cout, s);
           if (ek == 1) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 1>(k, a->cout, s);
@@ -896,18 +1130,28 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
       return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
     }
   }
-  if constexpr (bf) {
-    return set_err(SRGANFD_EINVAL, "conv2d: the 16-bit kernels run on v_mfma_f32_16x16x32 (ksize %d stride %d has no kernel)", a->ksize, a->stride);
-  } else {
-    // f32 (parity mode): v_mfma_f32_32x32x2_f32, an exact fp32 fma chain
-    if (a->ksize == 3 && a->stride == 1) return wide ? launch_conv<T, 3, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1>(k, a->cout, s);
-    if (a->ksize == 2 && a->stride == 1) return wide ? launch_conv<T, 2, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1>(k, a->cout, s);
-    // the stride-2 patch is 4x larger per output row: f32 fits a 4-row x 32-channel tile
-    if (a->ksize == 4 && a->stride == 2) return launch_conv<T, 4, 2, 1, 4, 1>(k, a->cout, s);
-    if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1>(k, a->cout, s);
-    if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1>(k, a->cout, s);
-    if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1>(k, a->cout, s);
-    return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
+#ifndef SRGANFD_EXPERIMENT
+  if constexpr (bf) return set_err(SRGANFD_EINVAL, "conv2d: the 16-bit kernels run on v_mfma_f32_16x16x32 (ksize %d stride %d has no kernel)", a->ksize, a->stride);
+  else
+#endif
+  {
+  if ((a->ksize == 3 || a->ksize == 2) && a->stride == 1) {
+    if constexpr (bf) {
+      if (a->ksize == 3 && g_igemm_variant == 7)   // experiment: 4 rows per wave (0.75 fragment reads per MFMA), register staging
+        return wide ? launch_conv<T, 3, 1, 4, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 4, 4, 1>(k, a->cout, s);
+    }
+    if (a->ksize == 3) return wide ? launch_conv<T, 3, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 1, 2, 8, 1>(k, a->cout, s);
+    return wide ? launch_conv<T, 2, 1, 2, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 1, 2, 8, 1>(k, a->cout, s);
+  }
+  if (a->ksize == 4 && a->stride == 2) {
+    // the stride-2 patch is 4x larger per output row: bf16 fits a 4-row x 64-channel tile, f32 a 4-row x 32-channel one
+    if constexpr (bf) { if (wide) return launch_conv<T, 4, 2, 1, 4, 2>(k, a->cout, s); }
+    return launch_conv<T, 4, 2, 1, 4, 1>(k, a->cout, s);
+  }
+  if (a->ksize == 3 && a->stride == 2) return wide ? launch_conv<T, 3, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 3, 2, 1, 4, 1>(k, a->cout, s);
+  if (a->ksize == 2 && a->stride == 2) return wide ? launch_conv<T, 2, 2, 1, 4, 2>(k, a->cout, s) : launch_conv<T, 2, 2, 1, 4, 1>(k, a->cout, s);
+  if (a->ksize == 1 && a->stride == 1) return launch_conv<T, 1, 1, 2, 4, 1>(k, a->cout, s);
+  return set_err(SRGANFD_EINVAL, "conv2d: unsupported ksize=%d stride=%d", a->ksize, a->stride);
   }
 }
 
@@ -966,6 +1210,9 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;
   auto aligned = [&](const srganfd_view& v) { return !v.ptr || (v.cstride % align == 0 && v.c0 % align == 0 && ((uintptr_t)v.ptr & 15) == 0); };
+#ifdef SRGANFD_EXPERIMENT
+  k.dbg = g_debug; k.stamps = g_stamp_buf;
+#endif
   k.fast_epi = (!a->y_f32 && a->cout_store == a->cout && aligned(a->y) && aligned(a->y2) && aligned(a->r1) && aligned(a->r2) && aligned(a->mask)) ? 1 : 0;
   return SRGANFD_OK;
 }
@@ -976,6 +1223,22 @@ int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream) {
     const int rc = conv_fill_k(a, k);
     if (rc != SRGANFD_OK) return rc;
   }
+#ifdef SRGANFD_EXPERIMENT
+  {
+    bool handled = false;
+    // the LDS-DMA ring kernel (64-channel tiles of large images) reads 32x32x16-order weights: used where that form is selected
+    const int rc = conv_uses_m16(a->dtype, a->ksize, a->cout) ? SRGANFD_OK : conv3x3_ring_try(a, k, stream, &handled);
+    if (rc != SRGANFD_OK || handled) return rc;
+  }
+#endif
+#ifdef SRGANFD_EXPERIMENT
+  {
+    // experiment (rejected, profiles/r03_conv_experiments.txt 12): every 3x3 stride-1 launch on the LDS-DMA streaming kernel
+    bool handled = false;
+    const int rc = conv_stream_try(a, k, stream, &handled);
+    if (rc != SRGANFD_OK || handled) return rc;
+  }
+#endif
   if (a->dtype == SRGANFD_BF16) return dispatch_conv<bf16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F16) return dispatch_conv<f16_t>(a, k, stream);
   if (a->dtype == SRGANFD_F32) return dispatch_conv<float>(a, k, stream);

@@ -32,13 +32,21 @@ extern "C" {
 #define SRGANFD_ACT_RELU 2
 
 const char* srganfd_last_error(void);
-/* Bumped whenever an exported signature or struct changes; the binding (sr_gan_fd_amd/_abi.py) reads this constant from this
- * header and refuses a library whose srganfd_abi_version() differs (a stale A/B build selected with SRGANFD_LIB, a prebuilt .so). */
-#define SRGANFD_ABI_VERSION 4
 int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
 void srganfd_set_dry_run(int on);
+#ifdef SRGANFD_EXPERIMENT
+/* kernel timing experiments (tools/build_variant.sh builds only; the product library does not export it): bit 0 skip
+ * activation loads, bit 1 skip weight loads, bit 2 skip the epilogue of the conv kernels -- results are wrong when non-zero. */
+void srganfd_set_debug(int flags);
+/* A/B switches of the kernel experiments (tools/kbench.py, tools/wgbench.py): which kernel serves the 3x3 stride-1 16-bit
+ * convolutions (0 = conv_igemm tiles only, 1.. = LDS-DMA ring / stream configurations; bit 0x1000 selects a weight-gradient loop
+ * variant instead), and the MFMA form of the 16-bit convolutions (0 = v_mfma_f32_32x32x16 everywhere ... 3 = v_mfma_f32_16x16x32
+ * everywhere; weights must be packed under the level they are consumed with). */
+void srganfd_set_ring_mode(int mode);
+void srganfd_set_mfma16(int level);
+#endif
 
 /* A channel-slice view of an NHWC activation buffer: element (n,y,x,c) lives at
  * ptr[((n*H + y)*W + x)*cstride + c0 + c]. */
@@ -275,7 +283,7 @@ int srganfd_adam_ema(float* param, const float* grad, float* exp_avg, float* exp
                      int32_t step, float grad_scale, float ema_decay, int32_t ema_mode, const float* skip_flag,
                      const float* grad_scale_dev /* or NULL: multiplies grad_scale (1 / loss scale from the scaler state) */, void* stream);
 /* torch.amp.GradScaler.update() on a device-resident state (torch keeps its scale on the device as well, so that neither the host nor a
- * captured graph carries a stale value): state = 8 words {float scale, float 1 / scale, int32 growth tracker, int32 optimizer steps, int32 skipped steps, 0, 0, 0}.
+ * captured graph carries a stale value): state = 8 floats {scale, 1 / scale, growth tracker, optimizer steps, skipped steps, 0, 0, 0}.
  * *found_inf != 0: scale *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth_factor (kept if that
  * would overflow), tracker = 0.  Loss kernels read state[0] as grad_scale_dev, the Adam kernels state[1]; train_bsrgan.py:109,436-437,466-467. */
 int srganfd_loss_scale_update(float* state, const float* found_inf, float growth_factor, float backoff_factor,
@@ -289,34 +297,6 @@ int srganfd_adam_ema_dev(float* param, const float* grad, float* exp_avg, float*
                          int64_t numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int32_t* step_dev, float* bc_dev, float grad_scale, float ema_decay, int32_t ema_mode,
                          const float* skip_flag, const float* grad_scale_dev /* or NULL */, void* stream);
-
-/* ---- thin-side 3x3 convolutions (stride 1, pad 1): 1..4 channels against 64 (csrc/conv_thin.hip) ----
- * The generator's conv1 / conv4 (BSRGAN/model.py:325,355), the discriminators' conv1 / conv4 (:102,135; A-ESRGAN/model.py:287,307;
- * ESRGAN/model.py:92) and VGG-19 features.0 (:522-524), with their data and weight gradients.  16-bit dtypes only.  The thin tensor
- * is NHWC with a pitch of 4 channels ("NHWC4", 8 bytes per pixel; channels >= cs must be zero), the 64-channel tensor an ordinary
- * view.  `weight` is the layer's RAW fp32 parameter (Cout, Cin, 3, 3): no packed copy exists for these layers.
- *   w_big_is_cout  1: the 64-channel side is the weight's Cout (a 1..4 -> 64 conv), 0: it is its Cin (a 64 -> 1..4 conv)
- *   flip           1: kernel rotated by 180 degrees (the launch is the DATA GRADIENT of the conv that owns `weight`) */
-typedef struct srganfd_thin_args {
-  int32_t dtype, n, h, w, cs, w_big_is_cout, flip, act;
-  float slope, mask_slope;
-  const float* weight;
-  const float* bias;        /* of the launch's OUTPUT channels (64 for thin_in, cs for thin_out), or NULL */
-  srganfd_view big;         /* thin_in: output; thin_out: input; thin_wgrad: the 64-channel operand (dy of a 1..4 -> 64 conv, x of a 64 -> 1..4 conv) */
-  srganfd_view mask;        /* thin_in only: y *= (mask > 0 ? 1 : mask_slope), or NULL */
-  const void* thin;         /* thin_in: input; thin_wgrad: the thin operand (x resp. dy); NHWC4, 16-bit */
-  float* thin_out;          /* thin_out: fp32 output */
-  int32_t thin_out_pitch;   /* its pixel pitch in floats: 4 (channels >= cs are written as zeros) or, with cs == 1, 1 */
-  int32_t pad_;
-} srganfd_thin_args;
-/* big[p][b] = act(bias[b] + sum_{tap,s} W(b,s,tap) * thin[p + tap][s]) (* mask): one K = 36 MFMA pair per 16 pixels x 16 channels */
-int srganfd_conv2d_thin_in(const srganfd_thin_args* a, void* stream);
-/* thin_out[p][s] = bias[s] + sum_{tap,b} W(b,s,tap) * big[p + tap][b] */
-int srganfd_conv2d_thin_out(const srganfd_thin_args* a, void* stream);
-/* dw (raw layout of `weight`'s tensor) = sum_p big[p][b] * thin[p +- tap][s]; db = the conv's bias gradient (64 values when
- * w_big_is_cout, else cs) or NULL.  Deterministic (slabs + ordered reduction); workspace >= srganfd_conv2d_thin_wgrad_workspace(). */
-size_t srganfd_conv2d_thin_wgrad_workspace(void);
-int srganfd_conv2d_thin_wgrad(const srganfd_thin_args* a, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- A-ESRGAN attention U-Net discriminator (A-ESRGAN/model.py:228-345) ---- */
 /* F.interpolate(size=..., mode="bilinear", align_corners=False) (model.py:245,250): bwd=0: a (hi x wi) -> b (ho x wo);

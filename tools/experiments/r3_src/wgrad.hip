@@ -48,6 +48,9 @@ struct WgK {
   int xC, x_c0v, dyC, dy_c0v;
   int x_ps, x_gs, dy_ps, dy_gs;   // pixel / 32-channel-group strides in elements: NHWC (C, 32) or planar groups (32, H*W*32), see srganfd_view
   int N, Hin, Win, up, pad, Hout, Wout, S, x_upad, dy_upad, ntiles, tiles_x, tiles_y, ngroups;
+#ifdef SRGANFD_EXPERIMENT
+  int dbg;   // timing experiments (srganfd_set_debug): 1 no global loads, 4 no slab store, 8 no LDS commit, 16 no LDS reads, 32 no barriers
+#endif
 };
 
 
@@ -98,9 +101,9 @@ static constexpr int kLoaderWaves = 4;
 // (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, so the LDS image is lane-linear and the 64-byte-unit swizzle
 // is applied to the per-lane SOURCE address); tile t+1 lands while tile t is in the MFMA phase, one barrier per tile,
 // no staging registers.  DMA = 0: global -> register -> LDS staging through one buffer.
-// VAR: 0 = v_mfma_f32_32x32x16, one pair of transposed x reads per kernel column (every shape but the next); 3 = the 3x3 stride-1 16-bit
-// DMA kernel: v_mfma_f32_16x16x32 on three transposed x reads per half row whose register shifts give the three kernel columns (the
-// intermediate variants 1 / 2 of profiles/r02_wgrad_variants.txt live in tools/experiments/r3_src).
+// VAR (3x3 stride-1 16-bit only; srganfd_set_ring_mode bits 9-10 pick it for A/B runs): 0 = six transposed x reads per half row
+// (one pair per kernel column); 1 = three reads + register shifts (see the loop); 2 = variant 1 software-pipelined one half row ahead;
+// 3 = v_mfma_f32_16x16x32 with the shifted fragments.
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
 __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) void wgrad_kernel(const WgK a) {
   constexpr int TH = WgTile<KS, STRIDE>::TH;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   auto load_x = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < xItems) {
+    if (item < xItems && !SRGANFD_DBG(a.dbg, 1)) {
       const int pix = item >> (CPU_SH + xu_sh), c16 = item & ((CPU << xu_sh) - 1);
       const int py = pix / PC, px = pix - py * PC;
       const int gy = oy0 * STRIDE - a.pad + py, gx = ox0 * STRIDE - a.pad + px;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
   auto load_y = [&](int i, int n, int oy0, int ox0) -> u32x4 {
     const int item = tid + i * NTHR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (item < yItems) {
+    if (item < yItems && !SRGANFD_DBG(a.dbg, 1)) {
       const int pix = item >> (CPU_SH + yu_sh), c16 = item & ((CPU << yu_sh) - 1);
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (oy < a.Hout && ox < a.Wout) v = *(const u32x4*)(dyg + (size_t)n * a.Hout * a.Wout * a.dyC + ((oy * a.Wout + ox) * a.dy_ps + ((c16 * E16) >> 5) * dy_gs2 + ((c16 * E16) & 31)));
@@ -341,13 +344,13 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
         dma_slots(n, oy0, ox0, buf);
       };
       __builtin_amdgcn_s_setprio(3);   // the copy must not wait behind the compute waves' issue slots (334 -> 317 us)
-      if (tile < a.ntiles) fill(tile, 0);
+      if (tile < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) fill(tile, 0);
       for (; tile < a.ntiles; tile += a.S) {
         // own DMAs landed (vmcnt) and zero fills written (lgkmcnt in the barrier's fence); past the barrier the buffer
         // is published and nobody reads buffer cur^1 any more (its MFMA phase precedes this barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + a.S < a.ntiles) fill(tile + a.S, cur ^ 1);
+        if (tile + a.S < a.ntiles && !SRGANFD_DBG(a.dbg, 1)) fill(tile + a.S, cur ^ 1);
         cur ^= 1;
       }
       return;
@@ -360,12 +363,12 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       ldsY = ldsX + PR * PC * xRowB;
       cur ^= 1;
     } else {
-      __syncthreads();  // previous tile's LDS reads done
-      commit(tile);
-      __syncthreads();
+      if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();  // previous tile's LDS reads done
+      if (!SRGANFD_DBG(a.dbg, 8)) commit(tile);
+      if (!SRGANFD_DBG(a.dbg, 32)) __syncthreads();
       if (tile + a.S < a.ntiles) prefetch(tile + a.S);
     }
-    if (W.active) {
+    if (W.active && !SRGANFD_DBG(a.dbg, 16)) {
       if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 3) {
         // v_mfma_f32_16x16x32: K = the 32 pixels of one tile row.  A (16 input channels x 32 pixels) and B (32 pixels x 16 output
         // channels): lane group g = lane>>4 supplies / receives pixels 8g..8g+7, so each 16-lane group of a transposed read takes its
@@ -411,6 +414,52 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
             }
           }
         }
+      } else if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && VAR == 2) {
+        // software-pipelined form of the shifted-fragment loop: the five transposed reads of half row i+1 are issued before the
+        // three MFMAs of half row i (two named register sets, every index compile-time)
+        using Fr = typename FragAB<T>::type;
+        struct HalfRow { u32x2 lo, hi, nx, blo, bhi; };
+        auto rd = [&](int rr, int hh) __attribute__((always_inline)) -> HalfRow {
+          const int ro = W.ks_idx * rows_per + rr, prow = ro + ky;
+          const char* xb = ldsX + ((prow & 1) ? tabX[1][0] : tabX[0][0]) + prow * PC * xRowB + hh * 16 * xRowB;
+          const char* yb = ldsY + tabY + ro * 32 * dyRowB + hh * 16 * dyRowB;
+          HalfRow r;
+          r.blo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb)));
+          r.bhi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yb + 4 * dyRowB)));
+          r.lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb)));
+          r.hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * xRowB)));
+          r.nx = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 8 * xRowB)));
+          return r;
+        };
+        auto fm = [&](const HalfRow& r) __attribute__((always_inline)) {
+          const u32x4 bq = {r.blo.x, r.blo.y, r.bhi.x, r.bhi.y};
+          if (W.bias_slab >= 0) {
+            float f8[8];
+            unpack8<T>(bq, f8);
+            bsum += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
+          }
+          const Fr bfrag = __builtin_bit_cast(Fr, bq);
+          const u32x4 f0 = {r.lo.x, r.lo.y, r.hi.x, r.hi.y};
+          const u32x4 f1 = {__builtin_amdgcn_alignbit(r.lo.y, r.lo.x, 16), __builtin_amdgcn_alignbit(r.hi.x, r.lo.y, 16),
+                            __builtin_amdgcn_alignbit(r.hi.y, r.hi.x, 16), __builtin_amdgcn_alignbit(r.nx.x, r.hi.y, 16)};
+          const u32x4 f2 = {r.lo.y, r.hi.x, r.hi.y, r.nx.x};
+          acc[0] = mfma32<T>(__builtin_bit_cast(Fr, f0), bfrag, acc[0]);
+          acc[1] = mfma32<T>(__builtin_bit_cast(Fr, f1), bfrag, acc[1]);
+          acc[2] = mfma32<T>(__builtin_bit_cast(Fr, f2), bfrag, acc[2]);
+        };
+        if (rows_per > 0) {
+          HalfRow ra = rd(0, 0);
+          for (int rr = 0; rr < rows_per; ++rr) {
+            const HalfRow rb = rd(rr, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rr + 1 < rows_per) ra = rd(rr + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(rb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       } else
       for (int rr = 0; rr < rows_per; ++rr) {
         const int ro = W.ks_idx * rows_per + rr;
@@ -435,12 +484,31 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
               unpack8<T>(u32x4{l.x, l.y, h2.x, h2.y}, f8);
               bsum += ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
             }
+            if constexpr (KS == 3 && STRIDE == 1 && VAR >= 1) {
+              // The three kernel columns read the SAME channel at pixels p, p+1, p+2: a lane's fragment for column dx is its
+              // 8-pixel run shifted by dx elements.  Three transposed reads (pixels p0..p0+11 of the lane's channel) replace six:
+              // dx = 2 is a whole-dword shift (register renaming), dx = 1 four v_alignbit_b32 -- 5 instead of 8 LDS reads per
+              // 3 MFMAs (the loop was LDS-read bound: 67 % of the LDS cycles at full MFMA rate, before the DMA fills).
+              const char* xb = ldsX + ax[0] + hh * 16 * xRowB;
+              const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb)));
+              const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * xRowB)));
+              const u32x2 nx = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 8 * xRowB)));
+              using Fr = typename FragAB<T>::type;
+              const u32x4 f0 = {lo.x, lo.y, hi.x, hi.y};
+              const u32x4 f1 = {__builtin_amdgcn_alignbit(lo.y, lo.x, 16), __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                                __builtin_amdgcn_alignbit(hi.y, hi.x, 16), __builtin_amdgcn_alignbit(nx.x, hi.y, 16)};
+              const u32x4 f2 = {lo.y, hi.x, hi.y, nx.x};
+              acc[0] = mfma32<T>(__builtin_bit_cast(Fr, f0), bfrag, acc[0]);
+              acc[1] = mfma32<T>(__builtin_bit_cast(Fr, f1), bfrag, acc[1]);
+              acc[2] = mfma32<T>(__builtin_bit_cast(Fr, f2), bfrag, acc[2]);
+            } else {
 #pragma unroll
-            for (int dx = 0; dx < KS; ++dx) {
-              const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
-              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
-              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
-              acc[dx] = mfma32<T>(cat_frag<T>(lo, hi), bfrag, acc[dx]);
+              for (int dx = 0; dx < KS; ++dx) {
+                const char* xb = ldsX + ax[dx] + hh * 16 * STRIDE * xRowB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xb + 4 * STRIDE * xRowB));
+                acc[dx] = mfma32<T>(cat_frag<T>(lo, hi), bfrag, acc[dx]);
+              }
             }
           }
         } else {
@@ -460,7 +528,7 @@ __global__ __launch_bounds__(64 * (WgWaves<KS>::NW + (DMA ? kLoaderWaves : 0))) 
       }
     }
   }
-  if (W.active) {
+  if (W.active && !SRGANFD_DBG(a.dbg, 4)) {
     float* slab = a.slabs + (size_t)(W.slab_base + split * W.ks_n + W.ks_idx) * (KS * KS * 1024) + W.tap0 * 1024;
     if constexpr (VAR == 3) {
       // D of 16x16x32: column = lane & 15 (output channel inside its half), row = 4 * (lane >> 4) + register (input channel)
@@ -545,6 +613,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgRedJobs jobs
 // ------------------------------------------------------------------------------------------------
 // host side: plan construction
 // ------------------------------------------------------------------------------------------------
+int g_wgrad_no_merge = [] { const char* e = getenv("SRGANFD_WGRAD_NO_MERGE"); return e ? atoi(e) : 0; }();   // A/B: one workgroup per single-task bucket (the round-2 grouping)
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct PlanBuild {
@@ -612,7 +681,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   struct Merged { int a, b; };
   std::vector<Merged> merged;
   std::vector<char> gone(buckets.size(), 0);
-  if (xdiv == 2 && s->ksize == 3) {
+  if (xdiv == 2 && s->ksize == 3 && !g_wgrad_no_merge) {
     int prev = -1;
     for (int i = 0; i < (int)buckets.size(); ++i) {
       if (buckets[i].tasks.size() != 1) continue;
@@ -666,7 +735,7 @@ static int build_plan(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* co
   H.ntasks = (int)pb.tasks.size();
   // pixel-tile splits: aim at ~2 workgroups per CU over the whole launch
   int S = s->splits;
-  if (S <= 0) { S = conv_device_cus() / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, ONE round: never more workgroups than the device has CUs (256 in dry runs)
+  if (S <= 0) { S = 256 / H.ngroups; if (S < 1) S = 1; }   // one workgroup (12 waves) per CU, ONE round: never more workgroups than CUs
   if (S > H.ntiles) S = H.ntiles;
   if (S > 4096) S = 4096;
   H.S = S;
@@ -728,6 +797,7 @@ int wgrad_plan_build_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv
   return SRGANFD_OK;
 }
 
+int g_wgrad_variant = 3;   // same-box A/B (profiles/r02_wgrad_variants.txt): 336.6 / 329.9 / 336.0 us for variants 0 / 1 / 2; 343.4 -> 314.9 us for 1 -> 3
 
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA, int VAR>
 static int launch_wgrad4(const WgHeader& H, const WgK& k, hipStream_t stream) {
@@ -749,6 +819,11 @@ static int launch_wgrad4(const WgHeader& H, const WgK& k, hipStream_t stream) {
 template <typename T, int KS, int STRIDE, int XP, int YP, bool DMA>
 static int launch_wgrad3(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DMA) {
+#ifdef SRGANFD_EXPERIMENT
+    if (g_wgrad_variant == 1) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 1>(H, k, stream);
+    if (g_wgrad_variant == 2) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 2>(H, k, stream);
+    if (g_wgrad_variant == 0) return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
+#endif
     return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 3>(H, k, stream);
   } else {
     return launch_wgrad4<T, KS, STRIDE, XP, YP, DMA, 0>(H, k, stream);
@@ -758,7 +833,7 @@ template <typename T, int KS, int STRIDE, int XP, int YP>
 static int launch_wgrad2(const WgHeader& H, const WgK& k, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (!(KS == 3 && STRIDE == 2))
-      if (H.dma_ok) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
+      if (H.dma_ok && !SRGANFD_DBG(g_debug, 64)) return launch_wgrad3<T, KS, STRIDE, XP, YP, true>(H, k, stream);
   }
   return launch_wgrad3<T, KS, STRIDE, XP, YP, false>(H, k, stream);
 }
@@ -787,6 +862,9 @@ int wgrad_impl(const void* plan_host, const void* plan_dev, srganfd_view x, srga
   k.x_ps = x.planar ? 32 : x.cstride; k.x_gs = x.planar ? H.Hin * H.Win * 32 : 32;
   k.dy_ps = dy.planar ? 32 : dy.cstride; k.dy_gs = dy.planar ? H.Hout * H.Wout * 32 : 32;
   k.N = H.N; k.Hin = H.Hin; k.Win = H.Win; k.up = H.up; k.pad = H.pad; k.Hout = H.Hout; k.Wout = H.Wout; k.S = H.S;
+#ifdef SRGANFD_EXPERIMENT
+  k.dbg = g_debug;
+#endif
   k.ngroups = H.ngroups; k.x_upad = H.x_upad; k.dy_upad = H.dy_upad; k.ntiles = H.ntiles; k.tiles_x = H.tiles_x; k.tiles_y = H.tiles_y;
   int rc;
 #define WG_BY_TYPE(KS_, S_) (H.dtype == SRGANFD_BF16 ? launch_wgrad<bf16_t, KS_, S_>(H, k, stream) : H.dtype == SRGANFD_F16 ? launch_wgrad<f16_t, KS_, S_>(H, k, stream) : launch_wgrad<float, KS_, S_>(H, k, stream))
