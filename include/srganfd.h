@@ -385,6 +385,11 @@ int srganfd_nhwc_to_nchw_scaled(srganfd_view src_f32, int32_t n, int32_t c, int3
  * random_crop (imgproc.py:846-886): the batch's common window (top, left, ph x pw) of NCHW fp32 images in one copy. */
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left,
                       int32_t ph, int32_t pw, void* stream);
+/* uint8 ingest (dataset.py:64-96 + imgproc.py:331-358 per batch on the device): decoded HWC uint8 images (n, h, w, 3) -> the window
+ * (top, left, ph x pw) as NCHW fp32 = value / scale (255 for the reference's [0, 1] range), channels swapped 0 <-> 2 when swap_rb
+ * (cv2's BGR -> RGB, dataset.py:81). */
+int srganfd_u8hwc_to_nchw(const unsigned char* src, float* dst, int32_t n, int32_t h, int32_t w, int32_t top, int32_t left,
+                          int32_t ph, int32_t pw, int32_t swap_rb, float scale, void* stream);
 /* PSNR per image (image_quality_assessment.py:361-395): NCHW fp32 in [0,1], crop_border pixels dropped on every side,
  * y_only = BT.601 luma of RGB first (imgproc.py:757-767); out: n doubles (dB); workspace: n * 64 doubles. */
 int srganfd_psnr(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border,

@@ -60,6 +60,7 @@ int adam_ema_dev_impl(float* p, const float* g, float* m, float* v, float* ema, 
                       int* step_dev, float* bc_dev, float grad_scale, float ema_decay, int ema_mode, const float* skip_flag,
                       const float* grad_scale_dev, hipStream_t s);
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s);
+int u8hwc_to_nchw_impl(const unsigned char* src, float* dst, int n, int h, int w, int top, int left, int ph, int pw, int swap_rb, float scale, hipStream_t s);
 int psnr_impl(const float* a, const float* b, int n, int c, int h, int w, int crop_border, int y_only, double* out, double* ws, hipStream_t s);
 int filter2d_impl(const float* src, const float* kernels, int kernel_batch, int b, int c, int h, int w, int k, int mode, const float* x_in,
                   const float* res_in, float weight, float threshold, float* out, float* out2, hipStream_t s, bool separable = false);
@@ -251,6 +252,10 @@ int srganfd_nhwc_to_nchw_scaled(srganfd_view src_f32, int32_t n, int32_t c, int3
 int srganfd_crop_nchw(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t top, int32_t left, int32_t ph, int32_t pw,
                       void* stream) {
   return crop_nchw_impl(src, dst, n, c, h, w, top, left, ph, pw, (hipStream_t)stream);
+}
+int srganfd_u8hwc_to_nchw(const unsigned char* src, float* dst, int32_t n, int32_t h, int32_t w, int32_t top, int32_t left, int32_t ph, int32_t pw,
+                          int32_t swap_rb, float scale, void* stream) {
+  return u8hwc_to_nchw_impl(src, dst, n, h, w, top, left, ph, pw, swap_rb, scale, (hipStream_t)stream);
 }
 int srganfd_psnr(const float* a, const float* b, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_border, int32_t y_only, double* out,
                  double* workspace, void* stream) {

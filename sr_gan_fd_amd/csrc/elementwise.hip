@@ -1883,6 +1883,35 @@ int batchnorm_bwd_impl(srganfd_view x, srganfd_view dy, srganfd_view dx, int dty
   return SRGANFD_OK;
 }
 
+// ---- uint8 ingest (dataset.py:64-96): what the reference does per image on the host -- cv2.imread(...).astype(float32) / 255,
+// crop, BGR -> RGB, image_to_tensor's HWC -> CHW (imgproc.py:331-358) -- for a whole batch of decoded uint8 HWC images on the device:
+// a quarter of the host-to-device bytes, and the float batch never exists in host memory.  One thread per output pixel: three byte reads
+// of one pixel (a wave reads 192 contiguous bytes), three coalesced plane stores.
+__global__ __launch_bounds__(256) void u8hwc_to_nchw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int top, int left,
+                                                            int ph, int pw, int swap_rb, float scale) {
+  const size_t total = (size_t)n * ph * pw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % pw);
+    const size_t t = i / pw;
+    const int y = (int)(t % ph);
+    const size_t img = t / ph;
+    const unsigned char* p = src + ((img * h + top + y) * (size_t)w + left + x) * 3;
+    const float c0 = (float)p[0] / scale, c1 = (float)p[1] / scale, c2 = (float)p[2] / scale;
+    float* d = dst + (img * 3 * ph + y) * (size_t)pw + x;
+    const size_t plane = (size_t)ph * pw;
+    d[0] = swap_rb ? c2 : c0;
+    d[plane] = c1;
+    d[2 * plane] = swap_rb ? c0 : c2;
+  }
+}
+int u8hwc_to_nchw_impl(const unsigned char* src, float* dst, int n, int h, int w, int top, int left, int ph, int pw, int swap_rb, float scale, hipStream_t s) {
+  if (!src || !dst || n <= 0 || ph <= 0 || pw <= 0 || top < 0 || left < 0 || top + ph > h || left + pw > w || !(scale > 0.f))
+    return set_err(SRGANFD_EINVAL, "u8hwc_to_nchw: bad args / window outside the image");
+  SRGANFD_LAUNCH(u8hwc_to_nchw_kernel, dim3(grid_for((size_t)n * ph * pw)), dim3(256), 0, s, src, dst, n, h, w, top, left, ph, pw, swap_rb, scale);
+  SRGANFD_HIP_CHECK(hipGetLastError());
+  return SRGANFD_OK;
+}
+
 static constexpr int kPsnrBlocks = 64;   // workspace: n * kPsnrBlocks doubles
 int crop_nchw_impl(const float* src, float* dst, int n, int c, int h, int w, int top, int left, int ph, int pw, hipStream_t s) {
   if (!src || !dst || n <= 0 || c <= 0 || top < 0 || left < 0 || ph <= 0 || pw <= 0 || top + ph > h || left + pw > w)

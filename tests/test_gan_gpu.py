@@ -284,8 +284,9 @@ def test_gan_steps_f16_trainer_vs_reference(golden_dir):
         got = [s[0] + s[1], s[2], 0.0, s[3], s[4], s[5]]
         err = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want) if b != 0.0)
         print(f"f16 GAN it{it}: got {got} want {list(want)} worst rel {err:.2e}, SR err {_rel(tr.sr, g[f'it{it}_sr']):.2e}")
-        assert err < 2e-3
+        assert err < 1e-3
         assert _rel(tr.sr, g[f"it{it}_sr"]) < 1e-3
+        print(f"   parameter probes: G conv4.bias {_rel(gen.conv4.bias, g[f'it{it}_g_conv4_bias']):.2e}, D conv4.weight {_rel(d.conv4.weight, g[f'it{it}_d_probe']):.2e}")
         assert _rel(gen.conv4.bias, g[f"it{it}_g_conv4_bias"]) < 5e-3
         assert _rel(d.conv4.weight, g[f"it{it}_d_probe"]) < 5e-3
     rep = tr.scaler.report()

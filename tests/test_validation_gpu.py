@@ -149,3 +149,31 @@ def test_cuda_prefetcher_feeds_the_hip_path():
             batch = pf.next()
         assert seen == 4
         pf.reset()
+
+
+def test_u8_ingest_equals_the_references_host_path():
+    """imgproc.image_to_tensor_u8 == the reference's per-image host ingest (dataset.py:66,81,90 + imgproc.py:331-358): uint8 HWC BGR ->
+    astype(float32) / 255 -> crop -> BGR2RGB -> image_to_tensor(range_norm, half=False), restated with numpy / torch on the CPU; bitwise,
+    at a ragged window of odd-sized images, with and without the [-1, 1] range; the prefetcher's ingest_u8 mode hands out the same batch."""
+    from sr_gan_fd_amd.dataset import CUDAPrefetcher
+    from sr_gan_fd_amd.imgproc import image_to_tensor_u8
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, size=(3, 37, 53, 3), dtype=np.uint8)
+    top, left, ph, pw = 5, 9, 24, 40
+
+    def host(image_u8, range_norm):
+        im = image_u8.astype(np.float32) / 255.                       # dataset.py:66
+        im = im[top:top + ph, left:left + pw, ...]                    # imgproc.random_crop_np's slicing
+        im = im[..., ::-1]                                            # cv2.COLOR_BGR2RGB
+        t = torch.from_numpy(np.ascontiguousarray(im)).permute(2, 0, 1).float()      # imgproc.py:348
+        return t.mul(2.0).sub(1.0) if range_norm else t               # :351-352
+    dev = torch.tensor(imgs).cuda()
+    for rn in (False, True):
+        want = torch.stack([host(im, rn) for im in imgs])
+        got = image_to_tensor_u8(dev, top, left, (ph, pw), bgr=True, range_norm=rn)
+        assert got.shape == (3, 3, ph, pw) and torch.equal(got.cpu(), want)
+    full = image_to_tensor_u8(dev, bgr=False)
+    assert torch.equal(full.cpu(), torch.tensor(imgs).permute(0, 3, 1, 2).float() / 255.)
+    batches = [{"gt": torch.tensor(imgs).pin_memory(), "name": "b0"}]
+    b = CUDAPrefetcher(batches, torch.device("cuda", 0), ingest_u8=True).next()
+    assert b["gt"].dtype == torch.float32 and torch.equal(b["gt"].cpu(), torch.tensor(np.ascontiguousarray(imgs[..., ::-1])).permute(0, 3, 1, 2).float() / 255.)
