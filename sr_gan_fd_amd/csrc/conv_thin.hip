@@ -45,6 +45,7 @@ struct ThinK {
   int cs, big_is_cout, flip;
   int N, H, W;
   float neg, mask_slope;    // activation as one select: v * (v > 0 ? 1 : neg)
+  int nt;                   // non-temporal output stores (large outputs)
   int tiles_x, tiles_y;
 };
 
@@ -207,7 +208,11 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
             for (int q = 0; q < 8; ++q) v[q] *= mv[q] > 0.f ? 1.f : a.mask_slope;
             o = pack8<T>(v);
           }
-          if (ox_t0 + 8 * u < a.W) *(u32x4*)((T*)yimg + (size_t)(oy * a.W + ox_t0 + 8 * u) * a.big_ps + yoff) = o;
+          if (ox_t0 + 8 * u < a.W) {
+            u32x4* dst = (u32x4*)((T*)yimg + (size_t)(oy * a.W + ox_t0 + 8 * u) * a.big_ps + yoff);
+            if (a.nt) __builtin_nontemporal_store(o, dst);
+            else *dst = o;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -576,6 +581,10 @@ static void thin_fill(const srganfd_thin_args* a, ThinK& k) {
   k.N = a->n; k.H = a->h; k.W = a->w;
   k.neg = a->act == SRGANFD_ACT_LRELU ? a->slope : (a->act == SRGANFD_ACT_RELU ? 0.f : 1.f);
   k.mask_slope = a->mask_slope;
+  // Non-temporal stores for outputs that one pass cannot keep in the caches anyway (> the 256 MiB Infinity Cache): the write-only
+  // 3 -> 64 launch at 512 x 512, batch 32 (1.07 GB) ran 321 -> 240 us with them, the masked launch unchanged (same-box, alternating).
+  // (The same switch in conv_igemm's epilogue moved neither training step: 58.8 / 141.0 ms with and without.)
+  k.nt = (long long)a->n * ipix * a->big.cstride * 2 >= (192LL << 20) ? 1 : 0;
 }
 
 int conv2d_thin_in_impl(const srganfd_thin_args* a, hipStream_t s) {
