@@ -78,7 +78,7 @@ constexpr int kThinInRows = 32;
 // The 16 x 64 output tile of a wave row goes through a wave-private 2 KiB LDS image and leaves as two stores of 8 WHOLE pixels (1 KiB
 // contiguous each); straight from the accumulator layout a store instruction covers 16 half pixels (64 of a pixel's 128 bytes), which
 // measured 371 vs 326 us (3 -> 64 at 512 x 512, batch 32) and 472 vs 420 us with the mask, which is read in the store layout too.
-template <typename T, bool MASK>
+template <typename T, bool MASK, bool NT>
 __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
   using Frag = typename FragAB<T>::type;
   __shared__ float wl[64 * 4 * 9];
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinK a) {
           }
           if (ox_t0 + 8 * u < a.W) {
             u32x4* dst = (u32x4*)((T*)yimg + (size_t)(oy * a.W + ox_t0 + 8 * u) * a.big_ps + yoff);
-            if (a.nt) __builtin_nontemporal_store(o, dst);
+            // (NT is a template parameter: behind a run-time `if` the two stores are merged into one plain store)
+            if constexpr (NT) __builtin_nontemporal_store(o, dst);
             else *dst = o;
           }
         }
@@ -412,7 +413,9 @@ __global__ __launch_bounds__(64 * kTwWaves) void thin_wgrad_kernel(const ThinWgK
       const int px = c0 + 8 * j + bpix;
       const int c = a.big_c0 + 8 * bslot;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (px < a.W) v = *(const u32x4*)(bimg + (size_t)(row * a.W + px) * a.big_ps + (c >> 5) * a.big_gs + (c & 31));
+      // (non-temporal: read once, 229 -> 218 us; the same hint on thin_out's ring loads cost 254 -> 321 us -- its strips re-read 2 of 16 columns
+      // and 2 of 34 rows from the caches -- and on thin_in's mask loads 410 -> 423)
+      if (px < a.W) v = __builtin_nontemporal_load((const u32x4*)(bimg + (size_t)(row * a.W + px) * a.big_ps + (c >> 5) * a.big_gs + (c & 31)));
       rb[j] = v;
     }
 #pragma unroll
@@ -596,13 +599,14 @@ int conv2d_thin_in_impl(const srganfd_thin_args* a, hipStream_t s) {
   const long long grid = (long long)a->n * k.tiles_x * k.tiles_y;
   if (grid > 0x7fffffffLL) return set_err(SRGANFD_EINVAL, "conv2d_thin_in: grid too large");
   if (g_describe) { snprintf(g_describe, g_describe_len, "thin_in_kernel<%s%s>", a->dtype == SRGANFD_F16 ? "f16" : "bf16", a->mask.ptr ? ",mask" : ""); return SRGANFD_OK; }
+#define THIN_IN_LAUNCH(TT, MK) do { if (k.nt) SRGANFD_LAUNCH((thin_in_kernel<TT, MK, true>), dim3((unsigned)grid), dim3(256), 0, s, k); \
+                                    else SRGANFD_LAUNCH((thin_in_kernel<TT, MK, false>), dim3((unsigned)grid), dim3(256), 0, s, k); } while (0)
   if (a->dtype == SRGANFD_F16) {
-    if (a->mask.ptr) SRGANFD_LAUNCH((thin_in_kernel<f16_t, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
-    else SRGANFD_LAUNCH((thin_in_kernel<f16_t, false>), dim3((unsigned)grid), dim3(256), 0, s, k);
+    if (a->mask.ptr) THIN_IN_LAUNCH(f16_t, true); else THIN_IN_LAUNCH(f16_t, false);
   } else {
-    if (a->mask.ptr) SRGANFD_LAUNCH((thin_in_kernel<bf16_t, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
-    else SRGANFD_LAUNCH((thin_in_kernel<bf16_t, false>), dim3((unsigned)grid), dim3(256), 0, s, k);
+    if (a->mask.ptr) THIN_IN_LAUNCH(bf16_t, true); else THIN_IN_LAUNCH(bf16_t, false);
   }
+#undef THIN_IN_LAUNCH
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
