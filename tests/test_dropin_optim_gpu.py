@@ -1,0 +1,123 @@
+"""Drop-in ``optim.Adam`` and ``swa_utils.AveragedModel`` (the reference scripts' ``optim.Adam(model.parameters(), ...)`` and
+``AveragedModel(g_model, avg_fn=ema_avg)``: train_bsrgan.py:290-291,311-323,436,466-470) against torch's own classes on the same loop:
+same parameters, moments, EMA copy and state_dict after several iterations under ``amp.autocast`` + ``GradScaler``, with the
+whole-network kernels actually taken (flat_steps / flat_updates), and torch's code on anything that is not laid out flat."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from torch import amp
+
+from tests.util import scaled_init
+
+pytestmark = pytest.mark.gpu
+EMA = lambda a, p, n: (1 - 0.999) * a + 0.999 * p          # noqa: E731  (train_bsrgan.py:290)
+
+
+def _close(a, b, rtol=2e-5, atol=1e-7):
+    return torch.allclose(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def _gen():
+    from sr_gan_fd_amd import model as M
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(num_rrdb=2)
+    scaled_init(g, 3.0, 0.5)
+    return g.cuda().train()
+
+
+def test_generator_loop_with_dropin_adam_and_ema_equals_torchs():
+    from sr_gan_fd_amd import optim as O, swa_utils as S
+    from torch.optim.swa_utils import AveragedModel as TorchAveraged
+    data = [(torch.rand(2, 3, 16, 16, device="cuda"), torch.rand(2, 3, 64, 64, device="cuda")) for _ in range(4)]
+    runs = {}
+    for kind in ("torch", "ours"):
+        g = _gen()
+        opt = (torch.optim.Adam if kind == "torch" else O.Adam)(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+        ema = (TorchAveraged if kind == "torch" else S.AveragedModel)(g, avg_fn=EMA)
+        scaler = amp.GradScaler("cuda")
+        for x, gt in data:
+            g.zero_grad(set_to_none=True)
+            with amp.autocast("cuda"):
+                loss = torch.nn.functional.l1_loss(g(x), gt)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            ema.update_parameters(g)
+        with torch.no_grad():
+            sr_ema = ema(data[0][0])                     # the EMA copy's own forward (its engine must see the averaged weights)
+        runs[kind] = (g, opt, ema, loss.item(), sr_ema)
+    (gt_, ot, et, lt, srt), (go, oo, eo, lo, sro) = runs["torch"], runs["ours"]
+    assert oo.flat_steps == 4 and eo.flat_updates == 4, (oo.flat_steps, eo.flat_updates)
+    assert abs(lt - lo) < 1e-6
+    for (k, a), (_, b) in zip(gt_.state_dict().items(), go.state_dict().items()):
+        assert _close(a, b), k
+    for (k, a), (_, b) in zip(et.state_dict().items(), eo.state_dict().items()):
+        assert _close(a, b), k
+    assert int(eo.n_averaged) == 4 and _close(srt, sro, rtol=1e-4, atol=1e-5)
+    # state_dict interchange: ours -> torch's class and back
+    sd = oo.state_dict()
+    assert set(sd["state"].keys()) == set(ot.state_dict()["state"].keys())
+    for i in sd["state"]:
+        assert float(sd["state"][i]["step"]) == 4.0
+        assert _close(sd["state"][i]["exp_avg"], ot.state_dict()["state"][i]["exp_avg"], rtol=1e-4, atol=1e-9)
+        assert _close(sd["state"][i]["exp_avg_sq"], ot.state_dict()["state"][i]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    fresh = torch.optim.Adam(gt_.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+    fresh.load_state_dict(copy.deepcopy(sd))
+    back = O.Adam(go.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)
+    back.load_state_dict(copy.deepcopy(ot.state_dict()))
+    # one more identical iteration through both restored optimizers
+    x, gt = data[0]
+    for g, opt in ((gt_, fresh), (go, back)):
+        g.zero_grad(set_to_none=True)
+        torch.nn.functional.l1_loss(g(x), gt).backward()        # outside autocast: f32 mode
+        opt.step()
+    assert back.flat_steps == 1
+    for (k, a), (_, b) in zip(gt_.state_dict().items(), go.state_dict().items()):
+        assert _close(a, b), k
+
+
+def test_discriminator_accumulated_backwards_stay_on_the_fused_path():
+    """train_bsrgan.py:415-437: two backward passes accumulate into the discriminator's gradients before its optimizer step"""
+    from sr_gan_fd_amd import model as M, optim as O
+    runs = {}
+    x1, x2 = torch.rand(2, 3, 64, 64, device="cuda"), torch.rand(2, 3, 64, 64, device="cuda")
+    for kind in ("torch", "ours"):
+        torch.manual_seed(0)
+        d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64).cuda().train()
+        opt = (torch.optim.Adam if kind == "torch" else O.Adam)(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)
+        bce = torch.nn.BCEWithLogitsLoss()
+        for _ in range(2):
+            d.zero_grad(set_to_none=True)
+            bce(d(x1), torch.ones(2, 1, 64, 64, device="cuda")).backward(retain_graph=True)
+            bce(d(x2), torch.zeros(2, 1, 64, 64, device="cuda")).backward()
+            opt.step()
+        runs[kind] = (d, opt)
+    assert runs["ours"][1].flat_steps == 2
+    for (k, a), (_, b) in zip(runs["torch"][0].state_dict().items(), runs["ours"][0].state_dict().items()):
+        assert _close(a, b, rtol=1e-4, atol=1e-6), k
+
+
+def test_other_modules_and_layouts_take_torchs_path():
+    from sr_gan_fd_amd import optim as O, swa_utils as S
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(8, 4).cuda(), torch.nn.Linear(8, 4).cuda()
+    b.load_state_dict(a.state_dict())
+    oa, ob = torch.optim.Adam(a.parameters(), 1e-2), O.Adam(b.parameters(), 1e-2)
+    ea, eb = torch.optim.swa_utils.AveragedModel(a, avg_fn=EMA), S.AveragedModel(b, avg_fn=EMA)
+    x = torch.randn(5, 8, device="cuda")
+    for _ in range(3):
+        for m, o, e in ((a, oa, ea), (b, ob, eb)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+            e.update_parameters(m)
+    assert ob.flat_steps == 0 and eb.flat_updates == 0
+    assert torch.equal(a.weight, b.weight) and torch.equal(ea.module.weight, eb.module.weight)
+    # amsgrad is not a fused mode
+    g = _gen()
+    o = O.Adam(g.parameters(), 1e-4, amsgrad=True)
+    torch.nn.functional.l1_loss(g(torch.rand(1, 3, 16, 16, device="cuda")), torch.rand(1, 3, 64, 64, device="cuda")).backward()
+    o.step()
+    assert o.flat_steps == 0

@@ -43,9 +43,15 @@ def label(kernel: str):
     m = re.search(r"conv3x3_ring_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
     if m:
         return "conv3x3_ring_kernel<%s,MR=%s,WR=%s,NR=%s,SCH=%s,NBUF=%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:])
-    m = re.search(r"wgrad_kernel<([^,]+), (\d+), (\d+),", kernel)
+    m = re.search(r"(?<!thin_)wgrad_kernel<([^,]+), (\d+), (\d+),", kernel)
     if m:
         return "wgrad_kernel<%s,KS=%s,S=%s>+reduce" % (TY.get(m.group(1), m.group(1)), m.group(2), m.group(3))
+    m = re.search(r"thin_in_kernel<([^,]+), (true|false)", kernel)          # ops.ThinLaunch.label
+    if m:
+        return "thin_in_kernel<%s%s>" % (TY.get(m.group(1), m.group(1)), ",mask" if m.group(2) == "true" else "")
+    m = re.search(r"(thin_out|thin_wgrad)_kernel<([^,>]+)>", kernel)
+    if m:
+        return "%s_kernel<%s>" % (m.group(1), TY.get(m.group(2), m.group(2)))
     return None
 
 
@@ -60,7 +66,7 @@ def counters(d):
 
 
 src = sys.argv[1]
-TAG = arg("--tag", "r03")
+TAG = arg("--tag", "r04")
 out = {"csrc_sha": bench.csrc_sha(), "batch": int(arg("--batch", "32")), "lr_size": int(arg("--lr-size", "128")), "workloads": {},
        "how": "tools/profile_round.sh + tools/pmc_to_json.py; traffic = (2*RDREQ + WRREQ)*64 B per launch, mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 1024)"}
 text = []
