@@ -151,6 +151,7 @@ def main():
                     help="g_only / gan: time the reference's own loop statements (torch.optim.Adam, AveragedModel, amp.autocast + GradScaler, "
                          "autograd) over the drop-in modules instead of the fused trainer; the default run reports both")
     ap.add_argument("--no-module-loop", action="store_true", help="default run: skip the module-level legs under \"extra\"")
+    ap.add_argument("--dropin-optim", action="store_true", help="--module-loop with sr_gan_fd_amd.optim.Adam / swa_utils.AveragedModel behind the scripts' names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -188,7 +189,7 @@ def main():
             raise SystemExit("bench.py: all-reduce of ones gave %d, world size %d" % (int(ones.item()), world))
 
     workloads = ["g_only", "gan"] if args.workload == "both" else [args.workload]
-    results = [run_workload(args, wl, rank, world, dev, pg, module_loop=args.module_loop) for wl in workloads]
+    results = [run_workload(args, wl, rank, world, dev, pg, module_loop=args.module_loop, dropin_optim=args.dropin_optim) for wl in workloads]
     out = results[0]
     if len(results) > 1 and rank == 0:
         out["gan"] = {k: results[1][k] for k in ("value", "unit", "ms_per_step", "config", "step_tflops_per_gpu", "loss_scale", "last_step_scalars", "roofline", "kernel_classes",
@@ -203,13 +204,18 @@ def main():
         extra = {}
         for wl, fused in zip(workloads, results):
             r = run_workload(margs, wl, rank, world, dev, pg, module_loop=True)
+            r2 = run_workload(margs, wl, rank, world, dev, pg, module_loop=True, dropin_optim=True)
             extra[wl] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"], "steps": margs.steps, "warmup": margs.warmup,
                          "fused_ms_per_step": fused["ms_per_step"], "module_over_fused": round(r["ms_per_step"] / fused["ms_per_step"], 4),
                          "loss_scale": r.get("loss_scale"), "last_step_scalars": r.get("last_step_scalars"),
-                         "sections_ms": r.get("module_loop_sections_ms")}
+                         "sections_ms": r.get("module_loop_sections_ms"),
+                         "with_dropin_optim_and_ema": {"ms_per_step": r2["ms_per_step"], "value": r2["value"],
+                                                       "module_over_fused": round(r2["ms_per_step"] / fused["ms_per_step"], 4),
+                                                       "sections_ms": r2.get("module_loop_sections_ms"), "last_step_scalars": r2.get("last_step_scalars")}}
         out["extra"] = {"module_loop": extra,
                         "what": "the reference's loop statements (amp.autocast + GradScaler, torch.optim.Adam, AveragedModel, autograd) over the drop-in "
-                                "modules with nothing set on them; the headline fields are the fused trainers"}
+                                "modules with nothing set on them; with_dropin_optim_and_ema = the same statements with sr_gan_fd_amd.optim.Adam / "
+                                "sr_gan_fd_amd.swa_utils.AveragedModel behind the scripts' names; the headline fields are the fused trainers"}
     if rank == 0:
         h = args.lr_size or BASE_LR_SIZE[workloads[0]]
         if not args.no_cpu_baseline and world == 1:      # host-side legs: rank 0 of the single-GPU run only
@@ -225,7 +231,7 @@ def main():
 DTYPES = {"f16": "float16", "bf16": "bfloat16", "f32": "float32"}
 
 
-def run_workload(args, workload, rank, world, dev, pg, module_loop=False):
+def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin_optim=False):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks."""
     import torch
     import torch.distributed as dist
@@ -246,7 +252,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False):
         if workload not in ("g_only", "gan") or world > 1:
             raise SystemExit("--module-loop: g_only / gan on one GPU")
         g.compute_dtype = None                    # the modules follow the loop's own autocast, as in the unchanged scripts
-        step_fn = module_level_loop(workload, M, g, dev, cdt)
+        step_fn = module_level_loop(workload, M, g, dev, cdt, dropin_optim)
     elif workload == "esrgan_gan":
         if world > 1 or h != 32:
             raise SystemExit("esrgan_gan: single GPU, 32 -> 128 only (the discriminator's classifier fixes the 128x128 input, ESRGAN/model.py:118-122)")
@@ -403,14 +409,21 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False):
     return out
 
 
-def module_level_loop(workload, M, g, dev, cdt):
+def module_level_loop(workload, M, g, dev, cdt, dropin_optim=False):
     """The reference's loop bodies as written -- BSRGAN/train_bsrnet.py:244-272 (g_only) and train_bsrgan.py:387-483 (gan): amp.autocast
     around the forwards, ONE GradScaler, torch.optim.Adam, AveragedModel with the scripts' avg_fn, autograd incl. retain_graph -- over
     the drop-in modules, which take their precision from that autocast (nothing is set on them).  The scripts' five ``.item()`` reads per
     iteration (train_bsrgan.py:479-483) are deferred: the step returns the device scalars."""
     import torch
     from torch import amp
-    from torch.optim.swa_utils import AveragedModel
+    if dropin_optim:
+        # the same statements with the package's drop-in classes behind the scripts' names: optim.Adam and AveragedModel run one kernel
+        # over a network's flat parameter buffer where torch's run one (or several) per tensor
+        from sr_gan_fd_amd import optim
+        from sr_gan_fd_amd.swa_utils import AveragedModel
+    else:
+        from torch import optim
+        from torch.optim.swa_utils import AveragedModel
     g.train()
     use_amp = cdt != torch.float32
     ac = lambda: amp.autocast("cuda", dtype=cdt, enabled=use_amp)
@@ -418,7 +431,7 @@ def module_level_loop(workload, M, g, dev, cdt):
     ema = AveragedModel(g, avg_fn=lambda a, p, n: (1 - 0.999) * a + 0.999 * p)
     l1 = torch.nn.L1Loss()
     if workload == "g_only":
-        g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)      # bsrnet_config.py:86-96
+        g_opt = optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), 1e-4, 0.0)      # bsrnet_config.py:86-96
         pw = torch.Tensor([1.0]).to(dev)
 
         def step(lr, gt, mark=lambda name: None):
@@ -438,8 +451,8 @@ def module_level_loop(workload, M, g, dev, cdt):
         return step
     d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64).to(dev).train()
     cl = M.ContentLoss(NODES, MEAN, STD).to(dev)
-    d_opt = torch.optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)         # bsrgan_config.py:147-151
-    g_opt = torch.optim.Adam(g.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
+    d_opt = optim.Adam(d.parameters(), 2e-4, (0.9, 0.999), 1e-4, 0.0)         # bsrgan_config.py:147-151
+    g_opt = optim.Adam(g.parameters(), 8e-5, (0.9, 0.999), 1e-4, 0.0)
     bce = torch.nn.BCEWithLogitsLoss()
     pw, cw, aw = (torch.Tensor(w).to(dev) for w in ([20.0], [1.0], [0.5]))          # bsrgan_config.py:137-143
 

@@ -36,7 +36,7 @@ def main():
     profiling.Recorder.bracket = bracket_shaped
 
     args = argparse.Namespace(gpus=1, steps=o.steps, warmup=2, workload=o.workload, batch=o.batch, esrgan_module_loop=False, lr_size=0, num_rrdb=23,
-                              dtype="f16", no_cpu_baseline=True, no_kernel_events=False, dist_backend="nccl", module_loop=False, no_module_loop=True)
+                              dtype="f16", no_cpu_baseline=True, no_kernel_events=False, dist_backend="nccl", module_loop=False, no_module_loop=True, dropin_optim=False)
     enable = profiling.enable
     profiling.enable = lambda every=7: enable(1)
     dev = torch.device("cuda", 0)
