@@ -82,7 +82,7 @@ MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
 def conv_flops(a) -> float:
     """algorithmic FLOP of one fused-conv launch: 2 * pixels_out * k*k * cin * cout_store"""
-    return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
+    return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store * (4 if a.out_classes == 4 else 1)
 
 
 def log(msg):
@@ -109,12 +109,34 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def visible_gpus() -> int:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent must not initialise a GPU before it starts its ranks):
+    KFD topology nodes that have SIMDs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  Falls back to
+    torch.cuda.device_count() (which does not initialise the GPU on this image) where the topology is not readable."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            props = dict(line.split(None, 1) for line in open(f).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        n = 0
+    if n == 0:
+        import torch
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args) -> int:
     """``--gpus N`` without torchrun's environment: start the N ranks as fresh child processes (torch.distributed.run) BEFORE this
     process initialises any GPU, pass rank 0's JSON line through, return the children's exit status."""
     import subprocess
-    import torch
-    n_vis = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    n_vis = visible_gpus()
     if args.dist_backend == "nccl" and n_vis < args.gpus:
         print("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, n_vis), file=sys.stderr)
         return 2

@@ -34,7 +34,7 @@ extern "C" {
 const char* srganfd_last_error(void);
 /* Bumped whenever an exported signature or struct changes; the binding (sr_gan_fd_amd/_abi.py) reads this constant from this
  * header and refuses a library whose srganfd_abi_version() differs (a stale A/B build selected with SRGANFD_LIB, a prebuilt .so). */
-#define SRGANFD_ABI_VERSION 4
+#define SRGANFD_ABI_VERSION 5
 int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
@@ -90,6 +90,12 @@ typedef struct {
   /* optional second output: post_scale * act(alpha*conv + bias) BEFORE the residual adds (the U-Net skip
    * adds of model.py:153,157,161 keep the LeakyReLU output so its derivative's sign is exact in backward) */
   srganfd_view y2;
+  /* 0 / 1: one parity class per launch (out_oy, out_ox, pad_y, pad_x say which).  4: ALL FOUR classes of a 2x2 output stride in this
+   * launch (16-bit dtypes, ksize 2, stride 1, out_sy = out_sx = 2): class (py,px) = (c >> 1, c & 1) uses out_oy = py, out_ox = px,
+   * pad_y = 1 - py, pad_x = 1 - px and the packed operand at w_packed + c * srganfd_packed_bytes(dtype, 2, cin, cout) -- the four
+   * packs follow each other; out_oy / out_ox / pad_y / pad_x are ignored.  The four workgroups that read one patch of x are
+   * neighbours on one XCD, so x comes from HBM once instead of four times. */
+  int32_t out_classes;
 } srganfd_conv_args;
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream);

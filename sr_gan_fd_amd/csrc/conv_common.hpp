@@ -17,7 +17,8 @@ struct ConvK {
   int N, Hin, Win, up, pad_y, pad_x, Hout, Wout;
   int osy, osx, ooy, oox, HoutF, WoutF;  // output pixel (oy,ox) is stored at (oy*osy+ooy, ox*osx+oox) of a HoutF x WoutF image
   int nChunks;        // cin / 32
-  int nNb;            // cout / (output channels per workgroup)
+  int nNb;            // cout / (output channels per workgroup); x 4 in a class launch
+  int cls_sh;         // -1, or log2(channel blocks per class) of a launch that runs all four output-parity classes (out_classes == 4)
   int cout_store;
   int tiles_x, tiles_y;
   int nblocks;        // N * tiles_y * tiles_x * nNb virtual blocks; the grid may be smaller (persistent workgroups, see the kernel)

@@ -146,10 +146,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   // Virtual block -> tile: XCD-aware bijective remap (blocks v and v+8 share an XCD and its L2; each XCD gets a contiguous range of
   // tiles), block-uniform by construction; the readfirstlane tells the compiler so (otherwise every address product downstream
   // stays in quarter-rate vector multiplies).
+  constexpr bool kCls = KS == 2 && STRIDE == 1;
+  int cls = 0;                                                            // output-parity class of this workgroup (kCls launches)
   auto decode = [&](int vb, int& n_, int& oy_, int& ox_, int& nb_) {
     const int bid = xcd_remap(vb, a.nblocks);
     const int t0 = (int)fast_div((unsigned)bid, (unsigned)a.nNb, a.m_nNb);
     nb_ = __builtin_amdgcn_readfirstlane(bid - t0 * a.nNb);
+    if constexpr (kCls) {
+      // all four output-parity classes of a stride-2 data gradient in one launch (srganfd_conv_args.out_classes): the class is the
+      // slow half of the tile's channel-block index, so the 4 x nNb workgroups that read one dy patch are consecutive blocks of one
+      // XCD and three of the four reads hit its L2
+      if (a.cls_sh >= 0) { cls = nb_ >> a.cls_sh; nb_ &= (1 << a.cls_sh) - 1; }
+    }
     const int t1 = (int)fast_div((unsigned)t0, (unsigned)a.tiles_x, a.m_tx);
     const int tx = __builtin_amdgcn_readfirstlane(t0 - t1 * a.tiles_x);
     const int t2 = (int)fast_div((unsigned)t1, (unsigned)a.tiles_y, a.m_ty);
@@ -159,6 +167,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   };
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
+  // a class launch derives the class's padding and output offset from its index: class (py, px) produces the output pixels
+  // (2 oy + py, 2 ox + px) from the 2 x 2 window of dy that starts at (oy + py - 1, ox + px - 1)
+  auto pad_y = [&]() { return kCls && a.cls_sh >= 0 ? 1 - (cls >> 1) : a.pad_y; };
+  auto pad_x = [&]() { return kCls && a.cls_sh >= 0 ? 1 - (cls & 1) : a.pad_x; };
+  auto ooy = [&]() { return kCls && a.cls_sh >= 0 ? (cls >> 1) : a.ooy; };
+  auto oox = [&]() { return kCls && a.cls_sh >= 0 ? (cls & 1) : a.oox; };
   // load side of the tile being staged (may run one tile ahead of the tile being computed): 64-bit per-image base (block-uniform,
   // scalar registers) + 32-bit offsets inside the image (host-checked)
   const T* __restrict__ xg = nullptr;
@@ -206,7 +220,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
     for (int i = 0; i < C::XI; ++i) {
       int py, px, c16;
       item_pos(tid_o, i, py, px, c16);
-      const int gy = oy_ * STRIDE - a.pad_y + py, gx = ox_ * STRIDE - a.pad_x + px;
+      const int gy = oy_ * STRIDE - pad_y() + py, gx = ox_ * STRIDE - pad_x() + px;
       const bool ok = tid_o + i * NTHR < C::NX && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
       xoff[i] = ok ? ((gy >> a.up) * a.Win + (gx >> a.up)) * a.x_ps + a.x_base + c16 * C::E16 : -1;
     }
@@ -316,7 +330,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
     int n_, oy_, ox_, nb_;
     decode(vb, n_, oy_, ox_, nb_);
     xg = (const T*)a.x + (size_t)n_ * a.Hin * a.Win * a.xC;
-    wgp = (const u32x4*)a.w + (size_t)nb_ * WN * a.nChunks * (C::WN_BYTES / 16);
+    const int wb_ = kCls && a.cls_sh >= 0 ? nb_ + (cls << a.cls_sh) : nb_;      // the classes' packs follow each other (host-checked)
+    wgp = (const u32x4*)a.w + (size_t)wb_ * WN * a.nChunks * (C::WN_BYTES / 16);
     if constexpr (kBuf) {
       xrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(xg), (short)0, (int)((unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.xC * (unsigned)sizeof(T)), 0x00020000);
       wrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wgp), (short)0, (int)((unsigned)WN * (unsigned)a.nChunks * (unsigned)C::WN_BYTES), 0x00020000);
@@ -614,7 +629,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
         const u32x2_t hi = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(rowt + m * 2048 + (r1 ^ (pb << 5)))));
         const int oy = oy0 + wr * MR + m, ox = ox0 + 16 * pb + cl;
         if (oy < a.Hout && ox < a.Wout) {
-          const int pp = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+          const int pp = (oy * a.osy + ooy()) * a.WoutF + ox * a.osx + oox();
           *(u32x4*)(ybase + pp * a.y_ps) = u32x4{lo.x, lo.y, hi.x, hi.y};
         }
       }
@@ -651,7 +666,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
         if constexpr (kR2) pre_r2[e] = u32x4{0u, 0u, 0u, 0u};
         if constexpr (kMk) pre_m[e] = u32x4{0u, 0u, 0u, 0u};
         if (item < ITEMSq && oy < a.Hout && ox < a.Wout) {
-          const int p = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;
+          const int p = (oy * a.osy + ooy()) * a.WoutF + ox * a.osx + oox();
           const int cch = nb * C::NB + ck * C::E16;
           auto ld = [&](const void* base, int Cs, int c0, int ps, int gs) -> u32x4 {
             const int cc = c0 + cch;
@@ -697,7 +712,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
       const int pix = item / CP, ck = item % CP;
       const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
       if (item < ITEMS && oy < a.Hout && ox < a.Wout) {
-        const int p = (oy * a.osy + a.ooy) * a.WoutF + ox * a.osx + a.oox;   // pixel inside the image: 32-bit offsets (host-checked)
+        const int p = (oy * a.osy + ooy()) * a.WoutF + ox * a.osx + oox();   // pixel inside the image: 32-bit offsets (host-checked)
         float v[C::E16];
         const f32x4* tp = (const f32x4*)(tile + pix * C::NB + ck * C::E16);
         {
@@ -760,7 +775,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
     const int oy = oy0 + wr * MR + m;
     if (oy >= a.Hout) continue;
     const size_t imgp = (size_t)n * a.HoutF * a.WoutF;                       // pixels before this image
-    const int prow = (oy * a.osy + a.ooy) * a.WoutF + a.oox;                   // pixel inside the image
+    const int prow = (oy * a.osy + ooy()) * a.WoutF + oox();                   // pixel inside the image
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ox = ox0 + A_.pixel(i, lane);
@@ -819,7 +834,8 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   if (g_describe) {
     char ek[8] = "";
     if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
-    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s>", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek);
+    snprintf(g_describe, g_describe_len, "conv_igemm_kernel<%s,KS=%d,S=%d,MR=%d,WR=%d,WN=%d%s%s%s>%s", dtype_name<T>(), KS, STRIDE, MR, WR, WN, M16 ? ",M16" : "", TS > 1 ? ",TS=2" : "", ek,
+             k.cls_sh >= 0 ? "[4 classes]" : "");
     return SRGANFD_OK;
   }
   static unsigned long long attr_done = 0;   // one bit per device: the attribute belongs to the device's code object
@@ -833,6 +849,12 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   }
   ConvK kk = k;
   kk.nNb = cout / C::NB;
+  if (k.cls_sh >= 0) {
+    // class launch: 4 * nNb blocks per tile, class-major (see the kernel's decode); the shift needs a power-of-two block count
+    if (KS != 2 || STRIDE != 1 || (kk.nNb & (kk.nNb - 1))) return set_err(SRGANFD_EINVAL, "conv2d: out_classes needs ksize 2, stride 1 and cout / %d a power of two", C::NB);
+    kk.cls_sh = __builtin_ctz((unsigned)kk.nNb);
+    kk.nNb *= 4;
+  }
   kk.tiles_x = ceil_div(k.Wout, C::TW);
   kk.tiles_y = ceil_div(k.Hout, C::TH);
   const long long nblk = (long long)k.N * kk.tiles_x * kk.tiles_y * kk.nNb;
@@ -919,11 +941,15 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
     return set_err(SRGANFD_EINVAL, "conv2d: bad dims");
   const int hl = a->h_in << (a->up ? 1 : 0), wl = a->w_in << (a->up ? 1 : 0);
   const bool sub = a->out_sy > 1 || a->out_sx > 1;  // parity-class launch of a stride-2 transposed conv
+  const bool allcls = a->out_classes == 4;          // ... all four classes in this one launch
+  if (a->out_classes != 0 && a->out_classes != 1 && !allcls) return set_err(SRGANFD_EINVAL, "conv2d: out_classes is 0, 1 or 4");
+  if (allcls && (a->out_sy != 2 || a->out_sx != 2 || a->ksize != 2 || a->stride != 1 || a->dtype == SRGANFD_F32 || a->up))
+    return set_err(SRGANFD_EINVAL, "conv2d: out_classes = 4 is the 16-bit data gradient of a 4x4 stride-2 conv (ksize 2, stride 1, out_sy = out_sx = 2)");
   if (!sub) {
     const int ho = (hl + 2 * a->pad - a->ksize) / a->stride + 1, wo = (wl + 2 * a->pad - a->ksize) / a->stride + 1;
     if (ho != a->h_out || wo != a->w_out)
       return set_err(SRGANFD_EINVAL, "conv2d: h_out/w_out %dx%d inconsistent with input (expect %dx%d)", a->h_out, a->w_out, ho, wo);
-  } else if (a->out_h_full < (a->h_out - 1) * a->out_sy + a->out_oy + 1 || a->out_w_full < (a->w_out - 1) * a->out_sx + a->out_ox + 1) {
+  } else if (a->out_h_full < (a->h_out - 1) * a->out_sy + (allcls ? 1 : a->out_oy) + 1 || a->out_w_full < (a->w_out - 1) * a->out_sx + (allcls ? 1 : a->out_ox) + 1) {
     return set_err(SRGANFD_EINVAL, "conv2d: strided output does not fit the full image");
   }
   const int align = a->dtype == SRGANFD_F32 ? 4 : 8;
@@ -961,7 +987,7 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
   k.N = a->n; k.Hin = a->h_in; k.Win = a->w_in; k.up = a->up ? 1 : 0; k.pad_y = sub ? a->pad_y : a->pad; k.pad_x = sub ? a->pad_x : a->pad;
   k.osy = sub ? a->out_sy : 1; k.osx = sub ? a->out_sx : 1; k.ooy = sub ? a->out_oy : 0; k.oox = sub ? a->out_ox : 0;
   k.HoutF = sub ? a->out_h_full : a->h_out; k.WoutF = sub ? a->out_w_full : a->w_out;
-  k.Hout = a->h_out; k.Wout = a->w_out; k.nChunks = a->cin / 32; k.nNb = 0; k.cout_store = a->cout_store;
+  k.Hout = a->h_out; k.Wout = a->w_out; k.nChunks = a->cin / 32; k.nNb = 0; k.cls_sh = allcls ? 0 : -1; k.cout_store = a->cout_store;
   k.tiles_x = k.tiles_y = 0;
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;

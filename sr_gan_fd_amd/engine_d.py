@@ -205,7 +205,8 @@ class DiscriminatorEngine:
         def s2_dgrad(name, dy, dx, hd, wd, cout, cin, r1, mask):
             """data gradient of a 4x4 stride-2 conv: 4 output-parity classes (2x2-tap convs over dy)"""
             items = []
-            for par in range(4):
+            one = ops.class4_ok(dtc, cin, [O[("b", name, c)] for c in range(4)], ops.packed_bytes(dtc, 2, cout, cin))
+            for par in range(1 if one else 4):
                 py, px = par >> 1, par & 1
                 a = ops.conv_args(dtc, V(dy), V(dx), wptr + O[("b", name, par)], N, hd, wd, cout, cin, ksize=2, stride=1, pad=0,
                                   r1=V(r1) if r1 is not None else A.NULL_VIEW, r1_scale=1.0 if r1 is not None else 0.0,
@@ -214,6 +215,7 @@ class DiscriminatorEngine:
                 a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
                 a.out_h_full, a.out_w_full = 2 * hd, 2 * wd
                 a.pad_y, a.pad_x = (1 if py == 0 else 0), (1 if px == 0 else 0)
+                a.out_classes = 4 if one else 0       # one launch: the four classes' workgroups share each dy patch through L2
                 items.append(("conv", a))
             return items
 

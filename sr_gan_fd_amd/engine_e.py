@@ -156,7 +156,8 @@ class EsrganDiscriminatorEngine:
             (py,px) has hd x wd outputs; pad = 0 (the classifier's 4x4 'valid' conv): hd+1 x wd+1 outputs, the tap pairs of
             the opposite parity and one row/column of zero padding on the low side."""
             items = []
-            for par in range(4):
+            one = pad == 1 and ops.class4_ok(dtc, cin, [O[("b", key, c)] for c in range(4)], ops.packed_bytes(dtc, 2, cout, cin))
+            for par in range(1 if one else 4):
                 py, px = par >> 1, par & 1
                 wpar = par if pad == 1 else (((1 - py) << 1) | (1 - px))
                 a = ops.conv_args(dtc, V(dy), V(dx), wptr + O[("b", key, wpar)], N, hd, wd, cout, cin, ksize=2, stride=1, pad=0,
@@ -166,6 +167,7 @@ class EsrganDiscriminatorEngine:
                 a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
                 a.out_h_full, a.out_w_full = 2 * hd + 2 * ext, 2 * wd + 2 * ext
                 a.pad_y, a.pad_x = ((1 if py == 0 else 0), (1 if px == 0 else 0)) if pad == 1 else (1, 1)
+                a.out_classes = 4 if one else 0
                 items.append(("conv", a))
             return items
 

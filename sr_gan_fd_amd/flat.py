@@ -12,9 +12,14 @@ import torch
 from torch import Tensor
 
 
+MAX_GAP = 3        # FlatParams pads every tensor to 16 bytes: at most 3 fp32 elements between neighbours
+
+
 def flat_span(tensors: Sequence[Optional[Tensor]]) -> Optional[Tuple[Tensor, List[int]]]:
     """(flat view covering every tensor, element offset of each tensor inside it) if all tensors are contiguous fp32 views of ONE
-    storage on one device that do not overlap; else None."""
+    storage on one device that do not overlap and leave nothing but alignment padding between them; else None.  (A subset of a
+    network's parameters -- e.g. ``filter(lambda p: p.requires_grad, ...)`` -- has the others in its gaps: a whole-buffer kernel would
+    update those too, so such a list is not a span.)"""
     if not tensors or any(t is None for t in tensors):
         return None
     t0 = tensors[0]
@@ -31,8 +36,9 @@ def flat_span(tensors: Sequence[Optional[Tensor]]) -> Optional[Tuple[Tensor, Lis
         hi = max(hi, p + 4 * t.numel())
     order = sorted(range(len(tensors)), key=lambda i: ptrs[i])
     for a, b in zip(order[:-1], order[1:]):
-        if ptrs[a] + 4 * tensors[a].numel() > ptrs[b]:
-            return None                       # overlapping views: not a parameter layout
+        end = ptrs[a] + 4 * tensors[a].numel()
+        if end > ptrs[b] or ptrs[b] - end > 4 * MAX_GAP:
+            return None                       # overlapping views, or other tensors in between: not (all of) a parameter layout
     n = (hi - lo) // 4
     flat = torch.empty(0, dtype=torch.float32, device=t0.device).set_(t0.untyped_storage(), (lo - st0) // 4, (n,))
     return flat, [(p - lo) // 4 for p in ptrs]

@@ -66,7 +66,7 @@ def conv_label(a) -> str:
 
 
 def conv_flops(a) -> float:
-    return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store
+    return 2.0 * a.n * a.h_out * a.w_out * a.ksize * a.ksize * a.cin * a.cout_store * (4 if a.out_classes == 4 else 1)
 
 
 def conv_work(a) -> tuple:
@@ -75,7 +75,7 @@ def conv_work(a) -> tuple:
     written); weights are negligible.  Element size 2 (bf16) / 4 (f32; also the fp32 SR / logits outputs)."""
     es = 4 if a.dtype == 1 else 2
     pin = a.n * a.h_in * a.w_in * a.cin * es
-    pout = a.n * a.h_out * a.w_out * a.cout_store
+    pout = a.n * a.h_out * a.w_out * a.cout_store * (4 if a.out_classes == 4 else 1)    # a class launch reads dy once and writes all of dx
     nb = pin + pout * (4 if a.y_f32 else es)
     for v in (a.r1, a.r2, a.mask, a.y2):
         if v.ptr:

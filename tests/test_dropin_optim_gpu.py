@@ -121,3 +121,14 @@ def test_other_modules_and_layouts_take_torchs_path():
     torch.nn.functional.l1_loss(g(torch.rand(1, 3, 16, 16, device="cuda")), torch.rand(1, 3, 64, 64, device="cuda")).backward()
     o.step()
     assert o.flat_steps == 0
+    # a SUBSET of a network's parameters has the others in its gaps: a whole-buffer kernel would step those too -> torch's path,
+    # and the parameters left out of the optimizer do not move
+    g = _gen()
+    named = list(g.named_parameters())
+    kept = [p for n, p in named if not n.startswith("conv2.")]
+    left = [p for n, p in named if n.startswith("conv2.")]
+    o = O.Adam(kept, 1e-3)
+    torch.nn.functional.l1_loss(g(torch.rand(1, 3, 16, 16, device="cuda")), torch.rand(1, 3, 64, 64, device="cuda")).backward()
+    before = [p.detach().clone() for p in left]
+    o.step()
+    assert o.flat_steps == 0 and all(torch.equal(a, b) for a, b in zip(before, left))

@@ -414,3 +414,63 @@ def test_batched_spectral_norm_equals_per_layer_calls_and_torch():
         Wl = W.clone().requires_grad_(True)
         ((Wl / torch.dot(u, torch.mv(Wl, v))) * G).sum().backward()
         assert (a - Wl.grad).abs().max().item() <= 1e-4 * Wl.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    dict(n=2, hd=8, wd=8, co=128, ci=64),                      # down_block1: one 64-channel block per class
+    dict(n=1, hd=5, wd=19, co=256, ci=128, r1=True),           # two blocks per class, ragged tiles, skip gradient added
+    dict(n=1, hd=6, wd=33, co=128, ci=256, mask=True),         # four blocks per class, LeakyReLU' mask
+])
+def test_stride2_dgrad_four_classes_in_one_launch(dtype, case):
+    """data gradient of a 4x4 stride-2 pad-1 conv (model.py:103-114): the four output-parity classes as ONE launch
+    (srganfd_conv_args.out_classes = 4) are bitwise the four single-class launches, and both are torch's gradient."""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(11)
+    dt = ops.DT[dtype]
+    n, hd, wd, co, ci = case["n"], case["hd"], case["wd"], case["co"], case["ci"]
+    H, W = 2 * hd, 2 * wd
+    wt = torch.randn(co, ci, 4, 4) / 40
+    dy = torch.randn(n, co, hd, wd)
+    x = torch.zeros(n, ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, _rt(wt, dtype), None, stride=2, padding=1).backward(_rt(dy, dtype))
+    want = x.grad.clone()
+    r1 = torch.randn(n, ci, H, W) if case.get("r1") else None
+    mk = torch.randn(n, ci, H, W) if case.get("mask") else None
+    if r1 is not None:
+        want = want + _rt(r1, dtype)
+    if mk is not None:
+        want = want * torch.where(_rt(mk, dtype) > 0, 1.0, 0.2)
+    pb = ops.packed_bytes(dt, 2, co, ci)
+    packed = torch.empty(4 * pb, dtype=torch.uint8, device="cuda")
+    jobs = [ops.pack_job(c * pb, dt, 2, co, ci, [dict(src_off=0, co_src=co, ci_src=ci, k_len=co, transposed=2 + c)]) for c in range(4)]
+    ops.PackTable(jobs, torch.device("cuda")).run(wt.cuda().contiguous(), packed)
+    dyb = _nhwc(dy, dtype)
+    r1b = _nhwc(r1, dtype) if r1 is not None else None
+    mkb = _nhwc(mk, dtype) if mk is not None else None
+
+    def run(classes):
+        dxb = torch.full((n, H, W, ci), 7.0, dtype=dtype, device="cuda")
+        for par in ([0] if classes == 4 else range(4)):
+            py, px = par >> 1, par & 1
+            a = ops.conv_args(dt, A.view(dyb), A.view(dxb), packed.data_ptr() + par * pb, n, hd, wd, co, ci, ksize=2, stride=1, pad=0,
+                              r1=A.view(r1b) if r1b is not None else A.NULL_VIEW, r1_scale=1.0 if r1b is not None else 0.0,
+                              mask=A.view(mkb) if mkb is not None else A.NULL_VIEW, mask_slope=0.2)
+            a.h_out, a.w_out = hd, wd
+            a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
+            a.out_h_full, a.out_w_full = H, W
+            a.pad_y, a.pad_x = 1 - py, 1 - px
+            a.out_classes = classes
+            ops.conv2d(a)
+        torch.cuda.synchronize()
+        return dxb
+
+    four, one = run(0), run(4)
+    assert torch.equal(four, one)
+    _assert_close(one.permute(0, 3, 1, 2), want, dtype, "stride-2 dgrad, four classes in one launch")
+    assert ops.class4_ok(dt, ci, [c * pb for c in range(4)], pb)
+    # what the class launch is not: fp32 parity mode, other kernel shapes
+    a = ops.conv_args(dt, A.view(dyb), A.view(one), packed.data_ptr(), n, hd, wd, co, ci)
+    a.out_classes = 4
+    with pytest.raises(A.SrganfdError):
+        ops.conv2d(a)
