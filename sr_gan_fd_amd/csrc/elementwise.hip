@@ -223,10 +223,10 @@ __device__ __forceinline__ void bil_bwd_taps4(int k, int n, int* d, float* wt, b
   if (k == 0) wt[1] = 1.0f;
   if (k == n - 1) wt[2] = 1.0f;
 }
-template <typename T>
+template <typename T, int R = kBilRows, bool NT = false>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd_rows_kernel(const void* __restrict__ a, int aC, int a0, void* b, int bC, int b0, int h, int w, int c, int cv_shift,
                                                                     const void* __restrict__ act, int actC, int act0, void* b2, int b2C, int b20, float slope) {
-  constexpr int N = VecN<T>::N, R = kBilRows;
+  constexpr int N = VecN<T>::N;
   const int cv = c / N;
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (unsigned)(w * cv)) return;
@@ -270,12 +270,12 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_rows_kernel(const void* 
       }
     }
     const size_t op_ = (img * h + ky) * (size_t)w + kx;
-    if (b) stv<T>(b, op_ * (size_t)bC + b0 + ch, acc);
+    if (b) { if constexpr (NT) stv_nt<T>(b, op_ * (size_t)bC + b0 + ch, acc); else stv<T>(b, op_ * (size_t)bC + b0 + ch, acc); }
     if (act) {
       ldv<T>(act, op_ * (size_t)actC + act0 + ch, t);
 #pragma unroll
       for (int q = 0; q < N; ++q) acc[q] *= t[q] > 0.f ? 1.f : slope;
-      stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
+      if constexpr (NT) stv_nt<T>(b2, op_ * (size_t)b2C + b20 + ch, acc); else stv<T>(b2, op_ * (size_t)b2C + b20 + ch, acc);
     }
   }
 }
@@ -1539,9 +1539,14 @@ int resample_bwd_lrelu_impl(srganfd_view dy, srganfd_view dx_raw, srganfd_view a
   const size_t lo = (size_t)n * h * w * c;
   const int cv = c / vn, cv_shift = (cv & (cv - 1)) == 0 ? __builtin_ctz(cv) : -1;
   if (h <= 65535 && n <= 65535 && (size_t)w * cv < (1u << 31)) {
-    DISPATCH_T(dtype, SRGANFD_LAUNCH(bilinear_up2_bwd_rows_kernel<TT>, dim3((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)((h + kBilRows - 1) / kBilRows), (unsigned)n), dim3(256), 0, s, dy.ptr,
-                                     dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride, dx_raw.c0, h, w, c, cv_shift, (const void*)act.ptr, act.cstride, act.c0,
-                                     dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
+    // non-temporal stores for results one pass cannot keep in the 256 MiB Infinity Cache anyway: 867 -> 805 us (128 channels, 512^2 -> 256^2, batch 32),
+    // 427 -> 414 (256 channels), bit-equal; 8 / 16 rows per thread instead of 4 measured 3-10 % slower (tools/r4/bil_bwd_bench.py)
+    const bool nt = lo * (size_t)(dtype == SRGANFD_F32 ? 4 : 2) >= ((size_t)192 << 20);
+#define BB(NTT) DISPATCH_T(dtype, SRGANFD_LAUNCH((bilinear_up2_bwd_rows_kernel<TT, kBilRows, NTT>), dim3((unsigned)(((size_t)w * cv + 255) / 256), (unsigned)((h + kBilRows - 1) / kBilRows), (unsigned)n), dim3(256), 0, s, dy.ptr, \
+                                     dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride, dx_raw.c0, h, w, c, cv_shift, (const void*)act.ptr, act.cstride, act.c0, \
+                                     dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope))
+    if (nt) { BB(true); } else { BB(false); }
+#undef BB
   } else
   DISPATCH_T(dtype, SRGANFD_LAUNCH((resample_vec_kernel<TT, 2>), dim3(grid_for(lo / vn, 256, 65536)), dim3(256), 0, s, dy.ptr, dy.cstride, dy.c0, dx_raw.ptr, dx_raw.cstride,
                                    dx_raw.c0, n, h, w, c, (const void*)act.ptr, act.cstride, act.c0, dx_masked.ptr, dx_masked.cstride, dx_masked.c0, slope));
