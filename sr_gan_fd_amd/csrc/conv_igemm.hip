@@ -122,7 +122,7 @@ template <int MR> struct AccSet<true, MR> {
 // y2, no fp32 / partial-channel output.  A fixed kind carries no loads, address arithmetic, prefetch registers or branches for tensors
 // the launch does not have: the four growth convs of a dense block (kind 0) and their data-gradient twins (kind 4) are 80 % of a
 // generator step's launches.
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool NT = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   static_assert(!M16 || sizeof(T) == 2, "16x16x32 is a 16-bit form");
   static_assert(TS == 1 || M16, "the tap split is built for the 16x16x32 loop");
@@ -738,7 +738,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
           const int cc = c0 + cch;
           T* dstp = (T*)base + img * Cs + (p * ps + (cc >> 5) * gs + (cc & 31));
           if constexpr (sizeof(T) == 2) {
-            *(u32x4*)dstp = pack8<T>(vv);
+            // NT: outputs one pass cannot keep in the 256 MiB Infinity Cache (the 256^2 / 512^2 layers at batch 32) leave with non-temporal
+            // stores; a template parameter, because a run-time branch around the builtin is folded into a plain store
+            if constexpr (NT) __builtin_nontemporal_store(pack8<T>(vv), (u32x4*)dstp);
+            else *(u32x4*)dstp = pack8<T>(vv);
           } else {
             f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
             *(f32x4*)dstp = o;
@@ -807,10 +810,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   }   // tiles of this workgroup
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool NT = false>
 __global__ __launch_bounds__(64 * WR * WN, (ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>::MIN_WAVES_PER_SIMD)) void conv_igemm_kernel(const ConvK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_body<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>(a, smem);
+  conv_igemm_body<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, NT>(a, smem);
 }
 
 // compute units of the current device (cached per device id); 256 when nothing can be asked (dry runs on the CPU)
@@ -827,10 +830,10 @@ int conv_device_cus() {
   return c;
 }
 
-template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1>
+template <typename T, int KS, int STRIDE, int MR, int WR, int WN, bool M16 = false, int TS = 1, int EK = -1, bool NT = false>
 static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   using C = ConvCfg<T, KS, STRIDE, MR, WR, WN, TS>;
-  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, MR, WR, WN, M16, TS, EK, NT>;
   if (g_describe) {
     char ek[8] = "";
     if (EK >= 0) snprintf(ek, sizeof(ek), ",E%d", EK);
@@ -882,6 +885,8 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
 // steps power-limited (1.2 kW, clock at 2.06 of 2.4 GHz) and holds a higher clock on this form.  The 32x32x16 instantiations of the
 // 16-bit kernels and the level switch live in the experiment sources (tools/experiments/r3_src).
 int g_mfma16 = 3;
+// non-temporal stores for outputs > 192 MB (same-box A/B switch: SRGANFD_CONV_NT=0 in the environment of the process that loads the library)
+static const bool g_conv_nt = [] { const char* e = getenv("SRGANFD_CONV_NT"); return !(e && e[0] == '0'); }();
 
 // does the kernel that consumes a packed operand of this kernel size / output width read 16x16x32 B fragments?  (pack.hip asks too)
 bool conv_uses_m16(int dtype, int ksize, int cout) {
@@ -899,6 +904,13 @@ static int dispatch_conv(const srganfd_conv_args* a, const ConvK& k, hipStream_t
         // epilogue kind fixed at compile time where the launch has the vectorised epilogue and no y2 (see the kernel's EK)
         const int ek = (k.fast_epi && !k.y2) ? ((k.r1 ? 1 : 0) | (k.r2 ? 2 : 0) | (k.mask ? 4 : 0)) : -1;
         if (wide) {
+          // outputs beyond the Infinity Cache: non-temporal stores (the discriminator / VGG / tail layers at 256^2 and 512^2; never the trunk)
+          const size_t opix_ = (size_t)a->n * (size_t)k.HoutF * (size_t)k.WoutF;
+          if (g_conv_nt && opix_ * (size_t)a->cout_store * 2 >= ((size_t)192 << 20)) {
+            if (ek == 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 0, true>(k, a->cout, s);
+            if (ek == 4) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 4, true>(k, a->cout, s);
+            if (ek < 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, -1, true>(k, a->cout, s);
+          }
           if (ek == 0) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 0>(k, a->cout, s);
           if (ek == 1) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 1>(k, a->cout, s);
           if (ek == 3) return launch_conv<T, 3, 1, 2, 4, 2, true, 1, 3>(k, a->cout, s);

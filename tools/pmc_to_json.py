@@ -39,7 +39,7 @@ def label(kernel: str):
         return "conv_igemm_kernel<%s,KS=%s,S=%s,MR=%s,WR=%s,WN=%s%s%s%s%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:6], ",M16" if m.group(7) == "true" else "",
                                                                              ",TS=%s" % m.group(8) if m.group(8) and int(m.group(8)) > 1 else "",
                                                                              "",      # epilogue kinds (EK) of one tile shape: one class, as profiling.roofline groups them
-                                                                             ",DB" if m.group(10) == "true" else "")
+                                                                             "")      # non-temporal-store twin (NT) of a kind: same class
     m = re.search(r"conv3x3_ring_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
     if m:
         return "conv3x3_ring_kernel<%s,MR=%s,WR=%s,NR=%s,SCH=%s,NBUF=%s>" % (TY.get(m.group(1), m.group(1)), *m.groups()[1:])
