@@ -474,3 +474,39 @@ def test_stride2_dgrad_four_classes_in_one_launch(dtype, case):
     a.out_classes = 4
     with pytest.raises(A.SrganfdError):
         ops.conv2d(a)
+
+
+@pytest.mark.parametrize("kind", ["kind0", "kind4", "runtime_y2"])
+def test_conv2d_nontemporal_twin_is_bitwise_the_plain_kernel(kind):
+    """Outputs beyond 192 MB leave the wide 3x3 kernels through non-temporal stores (a compile-time twin of kinds 0 / 4 / run-time):
+    the same launch as two half batches (each below the threshold, plain stores) gives the same bits."""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(5)
+    dt, dtype = A.F16, torch.float16
+    n, h, c = 6, 512, 64                                        # 6 x 512 x 512 x 64 x 2 B = 201 MB
+    x = torch.randn(n, h, h, c, device="cuda", dtype=dtype)
+    wt = torch.randn(c, c, 3, 3, device="cuda") / 24
+    wp = ops.pack_single(wt, dt)
+    bias = torch.randn(c, device="cuda") if kind == "kind0" else None
+    mask = torch.randn(n, h, h, c, device="cuda", dtype=dtype) if kind == "kind4" else None
+
+    def run(lo, hi, y, y2):
+        kw = dict(bias=bias, act=A.ACT_LRELU if kind == "kind0" else A.ACT_NONE)
+        if mask is not None:
+            kw.update(mask=A.view(mask[lo:hi]), mask_slope=0.2)
+        if y2 is not None:
+            kw.update(y2=A.view(y2[lo:hi]), r1=A.view(x[lo:hi]), r1_scale=1.0)
+        ops.conv2d(ops.conv_args(dt, A.view(x[lo:hi]), A.view(y[lo:hi]), wp, hi - lo, h, h, c, c, **kw))
+
+    outs = []
+    for parts in ([(0, n)], [(0, n // 2), (n // 2, n)]):
+        y = torch.zeros_like(x)
+        y2 = torch.zeros_like(x) if kind == "runtime_y2" else None
+        for lo, hi in parts:
+            run(lo, hi, y, y2)
+        torch.cuda.synchronize()
+        outs.append((y, y2))
+    assert outs[0][0].float().abs().max() > 0
+    assert torch.equal(outs[0][0], outs[1][0])
+    if kind == "runtime_y2":
+        assert torch.equal(outs[0][1], outs[1][1])
