@@ -34,7 +34,7 @@ extern "C" {
 const char* srganfd_last_error(void);
 /* Bumped whenever an exported signature or struct changes; the binding (sr_gan_fd_amd/_abi.py) reads this constant from this
  * header and refuses a library whose srganfd_abi_version() differs (a stale A/B build selected with SRGANFD_LIB, a prebuilt .so). */
-#define SRGANFD_ABI_VERSION 5
+#define SRGANFD_ABI_VERSION 6
 int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
@@ -91,11 +91,12 @@ typedef struct {
    * adds of model.py:153,157,161 keep the LeakyReLU output so its derivative's sign is exact in backward) */
   srganfd_view y2;
   /* 0 / 1: one parity class per launch (out_oy, out_ox, pad_y, pad_x say which).  4: ALL FOUR classes of a 2x2 output stride in this
-   * launch (16-bit dtypes, ksize 2, stride 1, out_sy = out_sx = 2): class (py,px) = (c >> 1, c & 1) uses out_oy = py, out_ox = px,
-   * pad_y = 1 - py, pad_x = 1 - px and the packed operand at w_packed + c * srganfd_packed_bytes(dtype, 2, cin, cout) -- the four
-   * packs follow each other; out_oy / out_ox / pad_y / pad_x are ignored.  The four workgroups that read one patch of x are
-   * neighbours on one XCD, so x comes from HBM once instead of four times. */
-  int32_t out_classes;
+   * launch (16-bit dtypes, ksize 2 or 1, stride 1, out_sy = out_sx = 2): class (py,px) = (c >> 1, c & 1) uses out_oy = py, out_ox = px,
+   * pad_y - py * class_pad_step, pad_x - px * class_pad_step (pad_y / pad_x = class (0,0)'s) and the packed operand at
+   * w_packed + c * ksize^2 * cin * cout * 2 bytes -- the four packs follow each other; out_oy / out_ox are ignored.
+   * class_pad_step = 1: data gradient of a 4x4 stride-2 pad-1 conv (pad 1 - p); 0: the 3x3 stride-2 / 2x2 stride-2 forms whose classes
+   * share one window.  The four workgroups that read one patch of x are neighbours on one XCD, so x comes from HBM once, not four times. */
+  int32_t out_classes, class_pad_step;
 } srganfd_conv_args;
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream);

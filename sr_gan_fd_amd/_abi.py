@@ -45,7 +45,7 @@ class ConvArgs(C.Structure):
         ("r2_scale", C.c_float), ("mask_slope", C.c_float), ("act", C.c_int32), ("y_f32", C.c_int32),
         ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
         ("out_h_full", C.c_int32), ("out_w_full", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
-        ("y2", View), ("out_classes", C.c_int32),
+        ("y2", View), ("out_classes", C.c_int32), ("class_pad_step", C.c_int32),
     ]
 
 

@@ -19,6 +19,7 @@ struct ConvK {
   int nChunks;        // cin / 32
   int nNb;            // cout / (output channels per workgroup); x 4 in a class launch
   int cls_sh;         // -1, or log2(channel blocks per class) of a launch that runs all four output-parity classes (out_classes == 4)
+  int cls_pad;        // class (py,px) of such a launch pads by pad_y - py * cls_pad, pad_x - px * cls_pad
   int cout_store;
   int tiles_x, tiles_y;
   int nblocks;        // N * tiles_y * tiles_x * nNb virtual blocks; the grid may be smaller (persistent workgroups, see the kernel)

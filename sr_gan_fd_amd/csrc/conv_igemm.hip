@@ -146,7 +146,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
   // Virtual block -> tile: XCD-aware bijective remap (blocks v and v+8 share an XCD and its L2; each XCD gets a contiguous range of
   // tiles), block-uniform by construction; the readfirstlane tells the compiler so (otherwise every address product downstream
   // stays in quarter-rate vector multiplies).
-  constexpr bool kCls = KS == 2 && STRIDE == 1;
+  constexpr bool kCls = (KS == 2 || KS == 1) && STRIDE == 1 && sizeof(T) == 2;
   int cls = 0;                                                            // output-parity class of this workgroup (kCls launches)
   auto decode = [&](int vb, int& n_, int& oy_, int& ox_, int& nb_) {
     const int bid = xcd_remap(vb, a.nblocks);
@@ -168,9 +168,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvK& a, char* smem) {
 
   const int Hl = a.Hin << a.up, Wl = a.Win << a.up;
   // a class launch derives the class's padding and output offset from its index: class (py, px) produces the output pixels
-  // (2 oy + py, 2 ox + px) from the 2 x 2 window of dy that starts at (oy + py - 1, ox + px - 1)
-  auto pad_y = [&]() { return kCls && a.cls_sh >= 0 ? 1 - (cls >> 1) : a.pad_y; };
-  auto pad_x = [&]() { return kCls && a.cls_sh >= 0 ? 1 - (cls & 1) : a.pad_x; };
+  // (2 oy + py, 2 ox + px); 4x4 stride-2 gradient (cls_pad 1): from the 2 x 2 window of dy that starts at (oy + py - 1, ox + px - 1)
+  auto pad_y = [&]() { return kCls && a.cls_sh >= 0 ? a.pad_y - (cls >> 1) * a.cls_pad : a.pad_y; };
+  auto pad_x = [&]() { return kCls && a.cls_sh >= 0 ? a.pad_x - (cls & 1) * a.cls_pad : a.pad_x; };
   auto ooy = [&]() { return kCls && a.cls_sh >= 0 ? (cls >> 1) : a.ooy; };
   auto oox = [&]() { return kCls && a.cls_sh >= 0 ? (cls & 1) : a.oox; };
   // load side of the tile being staged (may run one tile ahead of the tile being computed): 64-bit per-image base (block-uniform,
@@ -854,7 +854,8 @@ static int launch_conv(const ConvK& k, int cout, hipStream_t stream) {
   kk.nNb = cout / C::NB;
   if (k.cls_sh >= 0) {
     // class launch: 4 * nNb blocks per tile, class-major (see the kernel's decode); the shift needs a power-of-two block count
-    if (KS != 2 || STRIDE != 1 || (kk.nNb & (kk.nNb - 1))) return set_err(SRGANFD_EINVAL, "conv2d: out_classes needs ksize 2, stride 1 and cout / %d a power of two", C::NB);
+    if ((KS != 2 && KS != 1) || STRIDE != 1 || sizeof(T) != 2 || (kk.nNb & (kk.nNb - 1)))
+      return set_err(SRGANFD_EINVAL, "conv2d: out_classes needs ksize 2 or 1, stride 1 and cout / %d a power of two", C::NB);
     kk.cls_sh = __builtin_ctz((unsigned)kk.nNb);
     kk.nNb *= 4;
   }
@@ -955,8 +956,9 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
   const bool sub = a->out_sy > 1 || a->out_sx > 1;  // parity-class launch of a stride-2 transposed conv
   const bool allcls = a->out_classes == 4;          // ... all four classes in this one launch
   if (a->out_classes != 0 && a->out_classes != 1 && !allcls) return set_err(SRGANFD_EINVAL, "conv2d: out_classes is 0, 1 or 4");
-  if (allcls && (a->out_sy != 2 || a->out_sx != 2 || a->ksize != 2 || a->stride != 1 || a->dtype == SRGANFD_F32 || a->up))
-    return set_err(SRGANFD_EINVAL, "conv2d: out_classes = 4 is the 16-bit data gradient of a 4x4 stride-2 conv (ksize 2, stride 1, out_sy = out_sx = 2)");
+  if (allcls && (a->out_sy != 2 || a->out_sx != 2 || (a->ksize != 2 && a->ksize != 1) || a->stride != 1 || a->dtype == SRGANFD_F32 || a->up ||
+                 (a->class_pad_step != 0 && a->class_pad_step != 1)))
+    return set_err(SRGANFD_EINVAL, "conv2d: out_classes = 4 is the 16-bit data gradient of a stride-2 conv (ksize 2 or 1, stride 1, out_sy = out_sx = 2, class_pad_step 0 / 1)");
   if (!sub) {
     const int ho = (hl + 2 * a->pad - a->ksize) / a->stride + 1, wo = (wl + 2 * a->pad - a->ksize) / a->stride + 1;
     if (ho != a->h_out || wo != a->w_out)
@@ -999,7 +1001,7 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k) {
   k.N = a->n; k.Hin = a->h_in; k.Win = a->w_in; k.up = a->up ? 1 : 0; k.pad_y = sub ? a->pad_y : a->pad; k.pad_x = sub ? a->pad_x : a->pad;
   k.osy = sub ? a->out_sy : 1; k.osx = sub ? a->out_sx : 1; k.ooy = sub ? a->out_oy : 0; k.oox = sub ? a->out_ox : 0;
   k.HoutF = sub ? a->out_h_full : a->h_out; k.WoutF = sub ? a->out_w_full : a->w_out;
-  k.Hout = a->h_out; k.Wout = a->w_out; k.nChunks = a->cin / 32; k.nNb = 0; k.cls_sh = allcls ? 0 : -1; k.cout_store = a->cout_store;
+  k.Hout = a->h_out; k.Wout = a->w_out; k.nChunks = a->cin / 32; k.nNb = 0; k.cls_sh = allcls ? 0 : -1; k.cls_pad = allcls ? a->class_pad_step : 0; k.cout_store = a->cout_store;
   k.tiles_x = k.tiles_y = 0;
   k.alpha = a->alpha; k.slope = a->slope; k.post_scale = a->post_scale; k.r1s = a->r1_scale; k.r2s = a->r2_scale;
   k.mask_slope = a->mask_slope; k.act = a->act; k.y_f32 = a->y_f32 ? 1 : 0;

@@ -259,7 +259,8 @@ class AesrganDiscriminatorEngine:
         def strided_dgrad(key_fn, ks, dy, dx, hd, wd, cin_op, cout_op, r1=None, r2=None, mask=None):
             """4 parity classes writing a (2hd x 2wd) image: ks=2 (3x3 s2 conv) or ks=1 (2x2 s2 conv)"""
             items = []
-            for par in range(4):
+            one = ops.class4_ok(dtc, cout_op, [O[key_fn(c)] for c in range(4)], ops.packed_bytes(dtc, ks, cin_op, cout_op), ksize=ks)
+            for par in range(1 if one else 4):
                 py, px = par >> 1, par & 1
                 a = ops.conv_args(dtc, V(dy), V(dx), Wp(*key_fn(par)), N, hd, wd, cin_op, cout_op, ksize=ks, stride=1, pad=0,
                                   r1=V(r1) if r1 is not None else A.NULL_VIEW, r1_scale=1.0 if r1 is not None else 0.0,
@@ -269,6 +270,7 @@ class AesrganDiscriminatorEngine:
                 a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
                 a.out_h_full, a.out_w_full = 2 * hd, 2 * wd
                 a.pad_y, a.pad_x = 0, 0
+                a.out_classes, a.class_pad_step = (4, 0) if one else (0, 0)     # one launch: every class reads the same window of dy
                 items.append(("conv", a))
             return items
 

@@ -215,7 +215,7 @@ class DiscriminatorEngine:
                 a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
                 a.out_h_full, a.out_w_full = 2 * hd, 2 * wd
                 a.pad_y, a.pad_x = (1 if py == 0 else 0), (1 if px == 0 else 0)
-                a.out_classes = 4 if one else 0       # one launch: the four classes' workgroups share each dy patch through L2
+                a.out_classes, a.class_pad_step = (4, 1) if one else (0, 0)       # one launch: the four classes' workgroups share each dy patch through L2
                 items.append(("conv", a))
             return items
 

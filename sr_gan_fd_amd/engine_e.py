@@ -167,7 +167,7 @@ class EsrganDiscriminatorEngine:
                 a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
                 a.out_h_full, a.out_w_full = 2 * hd + 2 * ext, 2 * wd + 2 * ext
                 a.pad_y, a.pad_x = ((1 if py == 0 else 0), (1 if px == 0 else 0)) if pad == 1 else (1, 1)
-                a.out_classes = 4 if one else 0
+                a.out_classes, a.class_pad_step = (4, 1) if one else (0, 0)
                 items.append(("conv", a))
             return items
 

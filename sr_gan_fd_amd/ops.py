@@ -100,11 +100,14 @@ def conv_args(dtype: int, x: A.View, y: A.View, w_packed, n: int, h_in: int, w_i
 CLASS4_ENABLED = os.environ.get("SRGANFD_CLASS4", "1") != "0"   # same-box A/B switch: 0 launches the four parity classes separately
 
 
-def class4_ok(dtype: int, n_out: int, offsets: Sequence[int], pack_bytes: int) -> bool:
-    """can the four output-parity classes of a 4x4 stride-2 data gradient go out as ONE launch (srganfd_conv_args.out_classes = 4)?
-    16-bit modes, the output's 64-channel blocks a power of two, the four packed operands back to back."""
-    nb = n_out // 64 if n_out % 64 == 0 else 0
-    return (CLASS4_ENABLED and dtype != A.F32 and nb > 0 and nb & (nb - 1) == 0
+def class4_ok(dtype: int, n_out: int, offsets: Sequence[int], pack_bytes: int, ksize: int = 2) -> bool:
+    """can the four output-parity classes of a stride-2 data gradient go out as ONE launch (srganfd_conv_args.out_classes = 4)?
+    16-bit modes, 2x2- or 1x1-tap classes, the output's channel blocks (64 wide for the 2x2 kernel over a multiple of 64 channels,
+    else 32) a power of two, the four packed operands back to back."""
+    if n_out % 32:
+        return False
+    nb = n_out // (64 if ksize == 2 and n_out % 64 == 0 else 32)
+    return (CLASS4_ENABLED and dtype != A.F32 and ksize in (1, 2) and nb > 0 and nb & (nb - 1) == 0
             and all(offsets[c] == offsets[0] + c * pack_bytes for c in range(4)))
 
 

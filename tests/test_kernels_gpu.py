@@ -421,19 +421,24 @@ def test_batched_spectral_norm_equals_per_layer_calls_and_torch():
     dict(n=2, hd=8, wd=8, co=128, ci=64),                      # down_block1: one 64-channel block per class
     dict(n=1, hd=5, wd=19, co=256, ci=128, r1=True),           # two blocks per class, ragged tiles, skip gradient added
     dict(n=1, hd=6, wd=33, co=128, ci=256, mask=True),         # four blocks per class, LeakyReLU' mask
+    dict(n=1, hd=7, wd=18, co=128, ci=64, form="k3s2", mask=True),   # A-ESRGAN encoder: 3x3 stride 2 pad 1 as 2x2-tap classes, one window
+    dict(n=2, hd=6, wd=9, co=64, ci=96, form="k3s2"),                # ... 32-channel blocks (96 is not a multiple of 64): three of them -> refused
+    dict(n=1, hd=9, wd=21, co=64, ci=64, form="k2s2", r1=True),      # attention gate theta: 2x2 stride 2 as 1x1 classes
 ])
 def test_stride2_dgrad_four_classes_in_one_launch(dtype, case):
-    """data gradient of a 4x4 stride-2 pad-1 conv (model.py:103-114): the four output-parity classes as ONE launch
-    (srganfd_conv_args.out_classes = 4) are bitwise the four single-class launches, and both are torch's gradient."""
+    """data gradient of a stride-2 conv (4x4 pad 1: model.py:103-114; A-ESRGAN's 3x3 pad 1 and 2x2 pad 0): the four output-parity classes
+    as ONE launch (srganfd_conv_args.out_classes = 4) are bitwise the four single-class launches, and both are torch's gradient."""
     from sr_gan_fd_amd import _abi as A, ops
     torch.manual_seed(11)
     dt = ops.DT[dtype]
+    form = case.get("form", "k4s2")
+    kfull, pad, kcls, tbase, step = {"k4s2": (4, 1, 2, 2, 1), "k3s2": (3, 1, 2, 6, 0), "k2s2": (2, 0, 1, 10, 0)}[form]
     n, hd, wd, co, ci = case["n"], case["hd"], case["wd"], case["co"], case["ci"]
     H, W = 2 * hd, 2 * wd
-    wt = torch.randn(co, ci, 4, 4) / 40
+    wt = torch.randn(co, ci, kfull, kfull) / 40
     dy = torch.randn(n, co, hd, wd)
     x = torch.zeros(n, ci, H, W, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x, _rt(wt, dtype), None, stride=2, padding=1).backward(_rt(dy, dtype))
+    F.conv2d(x, _rt(wt, dtype), None, stride=2, padding=pad).backward(_rt(dy, dtype))
     want = x.grad.clone()
     r1 = torch.randn(n, ci, H, W) if case.get("r1") else None
     mk = torch.randn(n, ci, H, W) if case.get("mask") else None
@@ -441,9 +446,9 @@ def test_stride2_dgrad_four_classes_in_one_launch(dtype, case):
         want = want + _rt(r1, dtype)
     if mk is not None:
         want = want * torch.where(_rt(mk, dtype) > 0, 1.0, 0.2)
-    pb = ops.packed_bytes(dt, 2, co, ci)
+    pb = ops.packed_bytes(dt, kcls, co, ci)
     packed = torch.empty(4 * pb, dtype=torch.uint8, device="cuda")
-    jobs = [ops.pack_job(c * pb, dt, 2, co, ci, [dict(src_off=0, co_src=co, ci_src=ci, k_len=co, transposed=2 + c)]) for c in range(4)]
+    jobs = [ops.pack_job(c * pb, dt, kcls, co, ci, [dict(src_off=0, co_src=co, ci_src=ci, k_len=co, transposed=tbase + c)]) for c in range(4)]
     ops.PackTable(jobs, torch.device("cuda")).run(wt.cuda().contiguous(), packed)
     dyb = _nhwc(dy, dtype)
     r1b = _nhwc(r1, dtype) if r1 is not None else None
@@ -453,24 +458,31 @@ def test_stride2_dgrad_four_classes_in_one_launch(dtype, case):
         dxb = torch.full((n, H, W, ci), 7.0, dtype=dtype, device="cuda")
         for par in ([0] if classes == 4 else range(4)):
             py, px = par >> 1, par & 1
-            a = ops.conv_args(dt, A.view(dyb), A.view(dxb), packed.data_ptr() + par * pb, n, hd, wd, co, ci, ksize=2, stride=1, pad=0,
+            a = ops.conv_args(dt, A.view(dyb), A.view(dxb), packed.data_ptr() + par * pb, n, hd, wd, co, ci, ksize=kcls, stride=1, pad=0,
                               r1=A.view(r1b) if r1b is not None else A.NULL_VIEW, r1_scale=1.0 if r1b is not None else 0.0,
                               mask=A.view(mkb) if mkb is not None else A.NULL_VIEW, mask_slope=0.2)
             a.h_out, a.w_out = hd, wd
             a.out_sy, a.out_sx, a.out_oy, a.out_ox = 2, 2, py, px
             a.out_h_full, a.out_w_full = H, W
-            a.pad_y, a.pad_x = 1 - py, 1 - px
-            a.out_classes = classes
+            base = 1 if form == "k4s2" else 0
+            a.pad_y, a.pad_x = (base, base) if classes == 4 else (base - py * step, base - px * step)
+            a.out_classes, a.class_pad_step = classes, step
             ops.conv2d(a)
         torch.cuda.synchronize()
         return dxb
 
-    four, one = run(0), run(4)
-    assert torch.equal(four, one)
-    _assert_close(one.permute(0, 3, 1, 2), want, dtype, "stride-2 dgrad, four classes in one launch")
-    assert ops.class4_ok(dt, ci, [c * pb for c in range(4)], pb)
+    four = run(0)
+    _assert_close(four.permute(0, 3, 1, 2), want, dtype, "stride-2 dgrad, four class launches")
+    ok = ops.class4_ok(dt, ci, [c * pb for c in range(4)], pb, ksize=kcls)
+    assert ok == (ci != 96)                    # three 32-channel blocks per class: the class index is not a shift of the block index
+    if ok:
+        one = run(4)
+        assert torch.equal(four, one)
+    else:
+        with pytest.raises(A.SrganfdError):
+            run(4)
     # what the class launch is not: fp32 parity mode, other kernel shapes
-    a = ops.conv_args(dt, A.view(dyb), A.view(one), packed.data_ptr(), n, hd, wd, co, ci)
+    a = ops.conv_args(dt, A.view(dyb), A.view(four), packed.data_ptr(), n, hd, wd, co, ci)
     a.out_classes = 4
     with pytest.raises(A.SrganfdError):
         ops.conv2d(a)
