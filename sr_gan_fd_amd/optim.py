@@ -92,7 +92,7 @@ class Adam(torch.optim.Adam):
         """The kernel wrote the parameters behind autograd's back: the engines compare tensor version counters to know when to re-pack
         their weights (FlatParams.signature), so bump them the way an in-place torch op would."""
         for group in self.param_groups:
-            torch._C._increment_version(group["params"])
+            torch.autograd.graph.increment_version(group["params"])
 
     def state_dict(self):
         self._sync_steps()

@@ -46,7 +46,7 @@ class AveragedModel(_swa.AveragedModel):
                 avg.copy_(self.avg_fn(avg, src, n))
             else:
                 avg.copy_(_swa.get_swa_avg_fn()(avg, src, n))
-        torch._C._increment_version(pa)          # the copy's engine re-packs its weights when these change
+        torch.autograd.graph.increment_version(pa)         # the copy's engine re-packs its weights when these change
         for b_swa, b_model in zip(self.module.buffers(), model.buffers()):      # buffers follow the source model (torch does the same)
             b_swa.detach().copy_(b_model.detach().to(b_swa.device))
         self.n_averaged += 1
