@@ -14,11 +14,18 @@ LIB_PATH = os.environ.get("SRGANFD_LIB") or os.path.join(_HERE, "libsrganfd_hip.
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "srganfd.h")
 
 
+_ABI_VERSION_BUILT = 6     # SRGANFD_ABI_VERSION this binding's structures were written against (tests/test_host_logic.py keeps it equal to the header's)
+
+
 def _header_abi_version() -> int:
-    """SRGANFD_ABI_VERSION of include/srganfd.h: the one constant the library and this binding share."""
+    """SRGANFD_ABI_VERSION of include/srganfd.h: the one constant the library and this binding share.  A copy of the package without
+    the repository's include/ directory (an install, a vendored sub-tree) falls back to the value the binding was written against."""
     import re
-    with open(HEADER) as f:
-        m = re.search(r"^#define\s+SRGANFD_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    try:
+        with open(HEADER) as f:
+            m = re.search(r"^#define\s+SRGANFD_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    except OSError:
+        return _ABI_VERSION_BUILT
     if not m:
         raise RuntimeError(f"{HEADER}: SRGANFD_ABI_VERSION not found")
     return int(m.group(1))

@@ -21,7 +21,7 @@ from .engine import generator_engine
 from .engine_a import aesrgan_engine
 from .engine_d import discriminator_engine
 from .parallel import BucketReducer, SideStreamReducer, SyncBatchNormReduce, allreduce_sum_
-from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling
+from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling, pin_training_dtype
 
 
 class GanTrainer(GanCheckpointMixin):
@@ -31,6 +31,7 @@ class GanTrainer(GanCheckpointMixin):
                  generator_first: bool = False, sync_batchnorm: bool = False):
         # defaults = BSRGAN/bsrgan_config.py:137-159
         self.g, self.d, self.content = g_model, d_model, content_criterion
+        pin_training_dtype(g_model, d_model, content_criterion)     # modules left at "follow autocast" train in the loops' float16
         # either discriminator of the reference: DiscriminatorUNet (BSRGAN / Real-ESRGAN) or the A-ESRGAN attention U-Net
         # (A-ESRGAN/train_aesrgan.py:396-483 runs the same statements around it); both engines share one interface
         d_engine = aesrgan_engine if type(d_model).__name__ == "UNetDiscriminatorAesrgan" else discriminator_engine

@@ -26,7 +26,7 @@ from .engine import _engine, generator_engine
 from .engine_e import esrgan_discriminator_engine
 from .engine_v import ContentLossGradEngine
 from .parallel import BucketReducer, allreduce_sum_
-from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling
+from .trainer import FlatAdamEMA, GanCheckpointMixin, LossScaler, check_loss_scaling, needs_loss_scaling, pin_training_dtype
 
 
 class EsrganGanTrainer(GanCheckpointMixin):
@@ -35,6 +35,7 @@ class EsrganGanTrainer(GanCheckpointMixin):
                  content_weight: float = 1.0, adversarial_weight: float = 0.005, process_group=None):
         # defaults = ESRGAN/esrgan_config.py:75-111
         self.g, self.d, self.content = g_model, d_model, content_criterion
+        pin_training_dtype(g_model, d_model, content_criterion)     # train_esrgan.py:370-410 runs under amp.autocast(): float16
         self.ge, self.de = generator_engine(g_model), esrgan_discriminator_engine(d_model)
         if content_criterion is not None and not getattr(content_criterion, "single_node", False):
             raise A.SrganfdError("EsrganGanTrainer: content_criterion must be model.ContentLoss built with ONE node name, a str (ESRGAN's form)")

@@ -29,6 +29,11 @@ class Adam(torch.optim.Adam):
     def _group_flat(self, gi: int, group) -> bool:
         if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable") or isinstance(group["lr"], torch.Tensor):
             return False
+        # fused=True makes GradScaler.step skip unscale_ and its inf check and hand grad_scale / found_inf to the optimizer as
+        # attributes (torch/amp/grad_scaler.py: _step_supports_amp_scaling): the flat kernel below reads neither, so it would apply
+        # loss-scaled gradients and never skip a non-finite step.  That contract is torch's fused implementation's: let it run.
+        if group.get("fused") or getattr(self, "grad_scale", None) is not None or getattr(self, "found_inf", None) is not None:
+            return False
         ps = group["params"]
         if not ps or not ps[0].is_cuda:
             return False
@@ -42,13 +47,18 @@ class Adam(torch.optim.Adam):
         if st is None or st["sig"] != sig:
             # (re)build the flat moments from whatever per-parameter state exists, and make the per-parameter state views of them
             m, v = torch.zeros_like(flat), torch.zeros_like(flat)
-            t = 0
+            steps = set()
             for p, o in zip(ps, offs):
                 s = self.state.get(p)
                 if s and "exp_avg" in s:
                     m[o:o + p.numel()].copy_(s["exp_avg"].reshape(-1))
                     v[o:o + p.numel()].copy_(s["exp_avg_sq"].reshape(-1))
-                    t = int(float(s["step"]))
+                    steps.add(int(float(s["step"])))
+                else:
+                    steps.add(0)
+            if len(steps) > 1:
+                return False                     # parameters at different step counts (partial state): one bias correction cannot serve them
+            t = steps.pop() if steps else 0
             for p, o in zip(ps, offs):
                 s = self.state[p]
                 s["exp_avg"], s["exp_avg_sq"] = m[o:o + p.numel()].view_as(p), v[o:o + p.numel()].view_as(p)

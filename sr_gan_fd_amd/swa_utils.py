@@ -3,9 +3,12 @@ train_bsrnet.py / the ESRGAN scripts): torch.optim.swa_utils.AveragedModel with 
 
 torch's implementation calls ``avg_fn`` once per parameter -- 702 calls for the 23-block RRDBNet, each a handful of tiny kernels plus a
 device copy of ``n_averaged`` -- 26.6 ms of the module-level BSRGAN step (bench.py --module-loop: 92 ms against the fused trainer's 59).
-``avg_fn`` is elementwise tensor arithmetic, so applying it ONCE to the flat buffers the engines keep the parameters in gives every element
-the same value: the same three kernels over 67 MB instead of over 702 tensors.  Anything that is not laid out that way (other modules,
-CPU, use_buffers=True) goes through torch's own loop.
+The scripts' ``avg_fn`` is elementwise tensor arithmetic, so applying it ONCE to the flat buffers the engines keep the parameters in gives
+every element the same value: the same three kernels over 67 MB instead of over 702 tensors.  **Requirement: ``avg_fn`` / ``multi_avg_fn``
+must be elementwise** (the reference's ``(1 - decay) * averaged + decay * current``, torch's ``get_ema_avg_fn`` / ``get_swa_avg_fn``); a
+function that looks at a tensor as a whole (per-tensor norms, shape-dependent logic) would see the network as one 1-D tensor -- pass
+``flat=False`` for such a function and torch's per-parameter loop runs instead.  Anything that is not laid out flat (other modules, CPU,
+use_buffers=True) goes through torch's own loop as well.
 
     - from torch.optim.swa_utils import AveragedModel
     + from sr_gan_fd_amd.swa_utils import AveragedModel
@@ -19,16 +22,21 @@ from .flat import engine_flatten, flat_span
 
 
 class AveragedModel(_swa.AveragedModel):
-    def __init__(self, model, device=None, avg_fn=None, multi_avg_fn=None, use_buffers=False):
-        engine_flatten(model)                    # the deep copy then inherits one flat buffer (deepcopy preserves storage sharing)
+    def __init__(self, model, device=None, avg_fn=None, multi_avg_fn=None, use_buffers=False, flat=True):
         super().__init__(model, device=device, avg_fn=avg_fn, multi_avg_fn=multi_avg_fn, use_buffers=use_buffers)
+        self.flat = flat
         self.flat_updates = 0                    # updates taken on the whole-network path (tests / reports)
+        if flat and not use_buffers:
+            # Parameter.__deepcopy__ clones every tensor, so the copy torch just made is 702 separate allocations: lay both networks
+            # out flat once, here (the engines would do it at their first forward; the EMA copy may never run one before its first update)
+            engine_flatten(model)
+            engine_flatten(self.module)
 
     @torch.no_grad()
     def update_parameters(self, model) -> None:
         fa = fm = None
-        if not self.use_buffers:
-            engine_flatten(model)
+        if self.flat and not self.use_buffers:
+            engine_flatten(model)                # no-ops (a pointer walk) unless a module was moved or rebuilt since __init__
             engine_flatten(self.module)
             pa, pm = list(self.module.parameters()), list(model.parameters())
             if len(pa) == len(pm) and all(a.shape == b.shape for a, b in zip(pa, pm)):

@@ -158,6 +158,20 @@ class MultiStepLR:
         self.optimizer.lr = self._last_lr[0]
 
 
+def pin_training_dtype(*modules) -> torch.dtype:
+    """The fused trainers ARE the reference's training loops, and those run every forward under ``amp.autocast()`` (train_bsrgan.py:415-427,
+    450-457; train_bsrnet.py:252-254): float16 + GradScaler.  A module whose ``compute_dtype`` is still None (the default: follow autocast)
+    is therefore pinned here, when a trainer takes it over, to the dtype of the autocast region the trainer is built in or -- outside any --
+    to the reference loops' float16.  Without this a trainer built as INTEGRATION.md shows (``GanTrainer(g, d, cl)``, outside autocast) would
+    train in exact fp32: the parity kernels, twice the activation memory, no thin-side kernels, no loss scaling -- nothing the reference's
+    loop does.  An explicit ``compute_dtype`` (float32 for the parity tests and configs[0], bfloat16) is kept."""
+    dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float16
+    for m in modules:
+        if m is not None and getattr(m, "compute_dtype", None) is None:
+            m.compute_dtype = dt
+    return dt
+
+
 def needs_loss_scaling(*modules) -> bool:
     """float16 is the one mode that needs GradScaler's part played: an explicit ``compute_dtype`` or -- the default -- the dtype of
     the autocast region the trainer is built and stepped in (engine.resolve_compute_dtype)."""
@@ -329,6 +343,7 @@ class GeneratorTrainer:
     def __init__(self, g_model, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.0,
                  ema_decay: Optional[float] = 0.999, loss_weight: float = 1.0, process_group=None):
         self.g = g_model
+        pin_training_dtype(g_model)
         self.eng = generator_engine(g_model)
         dev = next(g_model.parameters()).device
         self.flat = self.eng.fp.sync(dev)

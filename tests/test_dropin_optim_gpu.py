@@ -132,3 +132,41 @@ def test_other_modules_and_layouts_take_torchs_path():
     before = [p.detach().clone() for p in left]
     o.step()
     assert o.flat_steps == 0 and all(torch.equal(a, b) for a, b in zip(before, left))
+
+
+def test_fused_true_under_gradscaler_takes_torchs_path_and_non_elementwise_avg_fn_can_opt_out():
+    """``Adam(..., fused=True)`` makes GradScaler.step skip unscale_ / its inf check and pass grad_scale / found_inf to the
+    optimizer as attributes -- a contract the flat kernel does not implement, so the drop-in must leave such a step to torch's fused
+    code (same parameters as torch.optim.Adam(fused=True) under the same scaler, flat_steps == 0).  ``AveragedModel(flat=False)``
+    keeps torch's per-parameter loop for an avg_fn that is not elementwise."""
+    from sr_gan_fd_amd import optim as O, swa_utils as S
+    x, y = torch.rand(1, 3, 16, 16, device="cuda"), torch.rand(1, 3, 64, 64, device="cuda")
+    nets, opts = [], []
+    for cls in (torch.optim.Adam, O.Adam):
+        torch.manual_seed(0)
+        g = _gen()
+        nets.append(g)
+        opts.append(cls(g.parameters(), 1e-3, eps=1e-4, fused=True))
+    for g, o in zip(nets, opts):
+        sc = amp.GradScaler("cuda", init_scale=1024.0)
+        for _ in range(2):
+            o.zero_grad(set_to_none=True)
+            with amp.autocast("cuda"):
+                loss = torch.nn.functional.l1_loss(g(x), y)
+            sc.scale(loss).backward()
+            sc.step(o)
+            sc.update()
+    assert opts[1].flat_steps == 0
+    for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6)
+    # a per-tensor (non-elementwise) avg_fn: each parameter keeps its own norm -- only torch's per-parameter loop is correct for it
+    per_tensor = lambda avg, cur, n: cur / (cur.norm() + 1e-12)
+    g = _gen()
+    e_flat_off = S.AveragedModel(g, avg_fn=per_tensor, flat=False)
+    e_torch = torch.optim.swa_utils.AveragedModel(g, avg_fn=per_tensor)
+    for e in (e_flat_off, e_torch):
+        e.update_parameters(g)
+        e.update_parameters(g)
+    assert e_flat_off.flat_updates == 0
+    for a, b in zip(e_flat_off.module.parameters(), e_torch.module.parameters()):
+        assert torch.equal(a, b)

@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/srganfd.h but not exported"
     assert declared == set(A.SYMBOLS), f"binding/header mismatch: {declared ^ set(A.SYMBOLS)}"
-    assert A.lib().srganfd_abi_version() == A.ABI_VERSION == 6
+    assert A.lib().srganfd_abi_version() == A.ABI_VERSION == A._ABI_VERSION_BUILT == 6
     assert A.lib().srganfd_get_mfma16() == 3
 
 
@@ -146,12 +146,25 @@ def test_content_losses_and_fused_trainers_dry_run():
         with pytest.raises(A.SrganfdError):
             cl1(torch.rand(1, 3, 30, 32), torch.rand(1, 3, 30, 32))   # four 2x2 pools
         g = M.bsrgan_x4(num_rrdb=1)
+        assert g.compute_dtype is None
         t = GeneratorTrainer(g, lr=1e-4)
+        # a trainer built over default modules, outside autocast, trains as the reference's loop does:
+        # float16 with the loss scaler on -- not in the exact-fp32 parity mode the modules run in outside autocast
+        assert g.compute_dtype == torch.float16 and t.scaler.enabled
         assert t.step(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)).shape == (1,)
         for dfac in (lambda: M.discriminator_unet(in_channels=3, out_channels=1, channels=64), M.uNetDiscriminatorAesrgan):
             tr = GanTrainer(M.bsrgan_x4(num_rrdb=1), dfac(), M.ContentLoss(nodes, mean, std))
+            assert tr.g.compute_dtype == tr.d.compute_dtype == tr.content.compute_dtype == torch.float16 and tr.scaler.enabled
             assert tr.step(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)).shape == (8,)
             assert tr.content_vals.shape == (1, 5)
+        # an explicit dtype is kept (the parity tests' float32, configs[0]), and a bfloat16 autocast region is followed
+        g32 = M.bsrgan_x4(num_rrdb=1)
+        g32.compute_dtype = torch.float32
+        assert not GeneratorTrainer(g32, lr=1e-4).scaler.enabled and g32.compute_dtype == torch.float32
+        if torch.cuda.is_available():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                gb = M.bsrgan_x4(num_rrdb=1)
+                assert not GeneratorTrainer(gb, lr=1e-4).scaler.enabled and gb.compute_dtype == torch.bfloat16
     finally:
         A.set_dry_run(False)
 

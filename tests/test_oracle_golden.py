@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import checksum, load_golden, scaled_init, table, sd_to_params
+from tests.util import checksum, load_golden, pinned_vgg, scaled_init, table, sd_to_params
 
 TOL = 2e-5  # fp32 CPU vs fp32 CPU: only op-ordering noise
 
@@ -428,3 +428,23 @@ def test_esrgan_gan_steps(golden_dir):
         for k, want_c in table(g, f"it{it}_wsum_d").items():
             if not k.endswith("num_batches_tracked"):
                 assert np.allclose(checksum(D[k]), want_c, rtol=1e-4, atol=at * abs(want_c[1]) + 1e-9), f"D {k}: {checksum(D[k])} vs {want_c}"
+
+
+def test_content_loss_oracle_vs_pinned_torchvision_values(golden_dir):
+    """Row A7's pin, when available (tools/pin_vgg.py; skipped in the build container: no torchvision / ImageNet weights): the oracle's
+    VGG-19 restatement on the ImageNet weights against the values the reference's ContentLoss produced (BSRGAN/model.py:536-554: five
+    detached L1 values; ESRGAN/model.py:281-292: one differentiable value + d/dSR), 1e-5.  Also settles the in-place-ReLU question of
+    SURVEY 8a/A7: the fixture records whether each tap held negative values."""
+    g, sd, _ = pinned_vgg(golden_dir)
+    nodes, mean, std = [str(n) for n in g["nodes"]], [float(v) for v in g["mean"]], [float(v) for v in g["std"]]
+    sr, gt = torch.tensor(g["sr"]), torch.tensor(g["gt"])
+    post = {n: not bool(g[f"tap_stats/{n}"][2]) for n in nodes}
+    assert post == {n: n != nodes[-1] for n in nodes}, f"tap semantics differ from SURVEY's reading (post-ReLU except the last): {post}"
+    got = O.content_loss(sr, gt, sd, nodes, mean, std, taps_post_relu=True)
+    assert np.allclose(got.numpy(), g["bsrgan_values"], rtol=1e-5, atol=1e-7), (got.numpy(), g["bsrgan_values"])
+    s1 = sr.clone().requires_grad_(True)
+    v1 = O.content_loss_single(s1, gt, sd, "features.34", mean, std)
+    v1.backward()
+    assert abs(v1.item() - float(g["esrgan_value"])) < 1e-5 * abs(float(g["esrgan_value"]))
+    ref = torch.tensor(g["esrgan_dsr"])
+    assert ((s1.grad - ref).norm() / ref.norm()).item() < 1e-4

@@ -46,3 +46,35 @@ def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def rounded_weights(P, dtype):
+    """The oracle's parameters as a 16-bit kernel sees them: every conv weight (4-D) rounded through ``dtype``, biases left fp32 (the
+    kernels add them in fp32).  With these the oracle differs from a 16-bit HIP run only by the 16-bit rounding of the stored
+    activations and the accumulation order -- the method of tests/test_kernels_gpu.py, applied to whole networks."""
+    return {k: (v.detach().to(dtype).to(torch.float32) if v.dim() == 4 else v.detach().clone()) for k, v in P.items()}
+
+
+def pinned_vgg(golden_dir):
+    """(fixture, torchvision vgg19 state_dict restricted to ``features.*``) when tools/pin_vgg.py's fixture exists AND the environment
+    variable SRGANFD_VGG19_WEIGHTS names the weights it was made from (SHA-256 of the features checked); otherwise pytest.skip.
+    Neither exists in the build container or on the GPU box (no torchvision, no ImageNet weights offline): the tests that call this
+    are how row A7 of SURVEY section 8 becomes pinned, without a code change, wherever both are available."""
+    import hashlib
+    import pytest
+    path = os.path.join(golden_dir, "vgg19_taps.npz")
+    wpath = os.environ.get("SRGANFD_VGG19_WEIGHTS", "")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/vgg19_taps.npz absent: run tools/pin_vgg.py where torchvision + the ImageNet VGG-19 weights exist")
+    if not wpath or not os.path.exists(wpath):
+        pytest.skip("SRGANFD_VGG19_WEIGHTS does not name a torchvision vgg19 state_dict")
+    g = np.load(path, allow_pickle=False)
+    sd = torch.load(wpath, map_location="cpu")
+    sd = {k: v for k, v in sd.get("state_dict", sd).items() if k.startswith("features.")}
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    if h.hexdigest() != str(g["features_sha256"]):
+        pytest.skip("SRGANFD_VGG19_WEIGHTS is not the file the fixture was made from (features SHA-256 differs)")
+    return g, sd, wpath
