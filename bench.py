@@ -39,6 +39,26 @@ PEAK_HBM_GBPS = 8000.0      # HBM3E peak (same guide)
 # 1762.3/16 GFLOP, five discriminator forwards + three backwards of ~1.0 GFLOP each, VGG-19[:35] fwd on SR and GT + bwd on SR
 FLOP_PER_IMG = {"g_only": 1762.3e9, "gan": 3828.9e9, "aesrgan_gan": 10566.0e9, "esrgan_gan": 1762.3e9 / 16 + 11 * 1.0e9 + 4 * 5.1e9,
                 "realesrgan_gan": 3828.9e9 / 4}      # the BSRGAN GAN networks at 64 -> 256 (realesrgan_config.py:116); degradation FLOPs not counted
+
+
+def flop_per_image(workload: str, h: int, upscale: int, num_rrdb: int) -> float:
+    """Algorithmic FLOP of one training iteration per image for an LR side ``h`` and scale factor ``upscale`` (SURVEY 8(d) convention).
+    At the BASELINE shapes (x4) this is FLOP_PER_IMG scaled by area; for the x2 networks of bsrgan_config.py:62 / aesrgan_config.py:62
+    the generator's tail has ONE nearest-x2 stage (BSRGAN/model.py:335-352), so the generator term is rebuilt from the layer list:
+    MAC per LR pixel = 3->64 (1728) + num_rrdb x 3 x 239,616 + 64->64 (36,864) + upsampling convs at 2h (and 4h) + conv3 + conv4 at s*h."""
+    if upscale == 4:
+        return FLOP_PER_IMG[workload] * (h / BASE_LR_SIZE[workload]) ** 2 * (num_rrdb / 23.0 if workload == "g_only" else 1.0)
+    if upscale != 2 or workload not in ("g_only", "gan", "aesrgan_gan"):
+        raise SystemExit("--upscale 2: g_only / gan / aesrgan_gan only")
+    c = 36864
+    g_mac = (1728 + num_rrdb * 3 * 239616 + c + 4 * c + 4 * c + 4 * 1728) * h * h
+    g_train = 3 * 2 * g_mac
+    hr = (2 * h) ** 2
+    d_mac_px = {"gan": 103.7e9 / 512 ** 2, "aesrgan_gan": 355.3e9 / 768 ** 2}.get(workload, 0.0)      # SURVEY 8(a) rows A4 / A12
+    vgg_mac_px = 101.9e9 / 512 ** 2                                                                       # row A7
+    return g_train if workload == "g_only" else g_train + 8 * 2 * d_mac_px * hr + 2 * 2 * vgg_mac_px * hr
+
+
 BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32, "realesrgan_gan": 64}     # the input size those figures are quoted at
 
 
@@ -165,6 +185,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--esrgan-module-loop", action="store_true", help="esrgan_gan: run the script's own autograd loop over the drop-in modules instead of the fused trainer")
     ap.add_argument("--lr-size", type=int, default=0, help="LR image side (default 128; 192 for aesrgan_gan)")
+    ap.add_argument("--upscale", type=int, default=4, choices=[2, 4],
+                    help="generator scale factor: 4 = the BASELINE configs; 2 = bsrgan_config.py:62 / aesrgan_config.py:62 (reference-default shapes)")
     ap.add_argument("--num-rrdb", type=int, default=23)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
                     help="compute dtype of activations / packed weights / gradients (fp32 master weights and accumulation); f16 is what the "
@@ -175,6 +197,7 @@ def main():
     ap.add_argument("--no-module-loop", action="store_true", help="default run: skip the module-level legs under \"extra\"")
     ap.add_argument("--dropin-optim", action="store_true", help="--module-loop with sr_gan_fd_amd.optim.Adam / swa_utils.AveragedModel behind the scripts' names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="default run: skip the bf16 leg (\"bf16\" sub-object)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
@@ -234,10 +257,28 @@ def main():
                          "with_dropin_optim_and_ema": {"ms_per_step": r2["ms_per_step"], "value": r2["value"],
                                                        "module_over_fused": round(r2["ms_per_step"] / fused["ms_per_step"], 4),
                                                        "sections_ms": r2.get("module_loop_sections_ms"), "last_step_scalars": r2.get("last_step_scalars")}}
+        # first-class field: what a user of the unchanged scripts gets.  "dropin_3_imports" = the documented
+        # default (model + optim + AveragedModel imports), "model_import_only" = the one-line change
+        out["module_loop"] = {wl: {"dropin_3_imports_ms_per_step": e["with_dropin_optim_and_ema"]["ms_per_step"],
+                                   "dropin_3_imports_img_per_s": e["with_dropin_optim_and_ema"]["value"],
+                                   "model_import_only_ms_per_step": e["ms_per_step"], "model_import_only_img_per_s": e["value"],
+                                   "fused_trainer_ms_per_step": e["fused_ms_per_step"]} for wl, e in extra.items()}
         out["extra"] = {"module_loop": extra,
                         "what": "the reference's loop statements (amp.autocast + GradScaler, torch.optim.Adam, AveragedModel, autograd) over the drop-in "
                                 "modules with nothing set on them; with_dropin_optim_and_ema = the same statements with sr_gan_fd_amd.optim.Adam / "
                                 "sr_gan_fd_amd.swa_utils.AveragedModel behind the scripts' names; the headline fields are the fused trainers"}
+    if args.workload == "both" and world == 1 and not args.module_loop and args.dtype == "f16" and not args.no_bf16:
+        # BASELINE.json's metric string names bf16; the reference's autocast computes in f16, which is what the headline runs (bf16 misses the
+        # 1e-3 SR tolerance).  The same generator-only step in bf16, a short timed region of its own, with its own SR parity figure.
+        import copy
+        bargs = copy.copy(args)
+        bargs.dtype, bargs.steps, bargs.warmup, bargs.no_kernel_events = "bf16", min(args.steps, 8), min(args.warmup, 2), True
+        rb = run_workload(bargs, "g_only", rank, world, dev, pg)
+        out["bf16"] = {"ms_per_step": rb["ms_per_step"], "value": rb["value"], "unit": rb["unit"], "steps": bargs.steps, "warmup": bargs.warmup,
+                       "step_mfma_frac": round(rb["step_tflops_per_gpu"] / PEAK_BF16_TFLOPS, 4), "last_step_scalars": rb.get("last_step_scalars"),
+                       "what": "configs[1] in bfloat16 (no loss scaling needed); the headline dtype is float16 = the reference's amp.autocast() dtype"}
+        if not args.no_cpu_baseline:
+            out["bf16"]["sr_parity"] = sr_parity(args.lr_size or BASE_LR_SIZE["g_only"], args.num_rrdb, dev, "bf16")
     if rank == 0:
         h = args.lr_size or BASE_LR_SIZE[workloads[0]]
         if not args.no_cpu_baseline and world == 1:      # host-side legs: rank 0 of the single-GPU run only
@@ -264,9 +305,10 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
     cdt = getattr(torch, DTYPES[args.dtype])
     h = args.lr_size or BASE_LR_SIZE[workload]
     B = args.batch
-    flop_img = FLOP_PER_IMG[workload] * (h / BASE_LR_SIZE[workload]) ** 2 * (args.num_rrdb / 23.0 if workload == "g_only" else 1.0)
+    S = getattr(args, "upscale", 4)
+    flop_img = flop_per_image(workload, h, S, args.num_rrdb)
     torch.manual_seed(0)                      # identical weights on every rank (bsrgan_config.py:35-37 seeds at import)
-    g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)
+    g = (M.bsrgan_x4 if S == 4 else M.bsrgan_x2)(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=args.num_rrdb)
     g.compute_dtype = cdt
     g.to(dev)
     trainer = None
@@ -331,7 +373,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     n_batches = max(1, min(args.steps, 32))
-    batches = [(torch.rand(B, 3, h, h, device=dev, generator=gen), torch.rand(B, 3, 4 * h, 4 * h, device=dev, generator=gen)) for _ in range(n_batches)]
+    batches = [(torch.rand(B, 3, h, h, device=dev, generator=gen), torch.rand(B, 3, S * h, S * h, device=dev, generator=gen)) for _ in range(n_batches)]
     lr_img, gt = batches[0]
 
     def barrier():
@@ -339,7 +381,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("%s: model + inputs ready (B=%d/GPU, %dx%d -> %dx%d, %s), warm-up" % (workload, B, h, h, 4 * h, 4 * h, args.dtype))
+    log("%s: model + inputs ready (B=%d/GPU, %dx%d -> %dx%d, %s), warm-up" % (workload, B, h, h, S * h, S * h, args.dtype))
     for i in range(args.warmup):
         step_fn(lr_img, gt)
         torch.cuda.synchronize()
@@ -366,7 +408,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
     value = B * world * args.steps / dt
 
     out = {
-        "metric": "SR training images/sec (%d->%d x4, %s)" % (h, 4 * h, args.dtype), "value": round(value, 3), "unit": "img/s",
+        "metric": "SR training images/sec (%d->%d x%d, %s)" % (h, S * h, S, args.dtype), "value": round(value, 3), "unit": "img/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic (%d distinct seeded batches, resident in HBM before the timed region)" % n_batches,
@@ -377,7 +419,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
                                                   "(RRDBNet %d RRDB + U-Net D + VGG19 content), batch %d/GPU, %d->%d",
                                 "esrgan_gan": "ESRGAN relativistic GAN step, fused trainer (RRDBNet %d RRDB + BatchNorm D "
                                               "+ differentiable VGG19 content), batch %d/GPU, %d->%d",
-                                }[workload] % (args.num_rrdb, B, h, 4 * h),
+                                }[workload].replace("RRDBNet x4", "RRDBNet x%d" % S) % (args.num_rrdb, B, h, S * h),
                    "global_batch": B * world, "num_rrdb": args.num_rrdb, "parallelism": "dp%d" % world,
                    "flop_per_image": flop_img},
         "step_tflops_per_gpu": round(value / world * flop_img / 1e12, 2),
@@ -423,6 +465,9 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
     if rank == 0 and rec is not None:
         out["roofline"] = profiling.roofline(rec, PEAK_BF16_TFLOPS, PEAK_HBM_GBPS)
         out["roofline"].update(pmc_fields(workload, out["roofline"]["kernel"], B, h))
+        # the whole step against the dense 16-bit MFMA peak (north_star's ">= 40 % MFMA utilisation" is about this number): algorithmic
+        # FLOP of the iteration x images/s / GPUs / 2.5 PF
+        out["roofline"]["step_mfma_frac"] = round(out["step_tflops_per_gpu"] / PEAK_BF16_TFLOPS, 4)
         out["kernel_classes"] = profiling.summary(rec)
     del trainer, step_fn, g
     import gc

@@ -140,6 +140,11 @@ def roofline(rec: Recorder, peak_tflops: float, peak_gbps: float = 8000.0) -> di
         out.update(achieved=d["tflops"], peak=peak_tflops, unit="TFLOP/s", frac=round(d["tflops"] / peak_tflops, 4))
     if len(d["kinds"]) > 1:
         out["kinds"] = d["kinds"]
+    # the largest single kernel symbol of the step (a class above may be several epilogue kinds of one tile shape) against the MFMA roof
+    slab, sv = max(per_label.items(), key=lambda kv: kv[1]["ms"])
+    tot_ms = sum(v["ms"] for v in per_label.values())
+    out["largest_symbol"] = {"kernel": slab, "avg_us": sv["avg_us"], "launches": sv["launches"], "tflops": sv["tflops"],
+                             "mfma_frac": round(sv["tflops"] / peak_tflops, 4), "share_of_bracketed_kernel_time": round(sv["ms"] / tot_ms, 4) if tot_ms > 0 else None}
     out.update(traffic=None, avg_launch_us=d["avg_us"], launches=d["launches"],
                flop_per_launch=float(f"{d['flop'] / d['launches']:.6g}"),
                bytes_per_launch=float(f"{d['bytes'] / d['launches']:.6g}"), flop_per_byte=ai, ridge_flop_per_byte=round(ridge, 1),

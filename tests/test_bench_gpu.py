@@ -93,6 +93,15 @@ def test_bench_default_line_carries_the_module_level_legs():
         assert ml[wl]["ms_per_step"] > 0 and ml[wl]["fused_ms_per_step"] > 0 and ml[wl]["module_over_fused"] > 0
         assert all(v == v for v in ml[wl]["last_step_scalars"])
     assert ml["gan"]["loss_scale"]["enabled"] and ml["gan"]["loss_scale"]["scale"] > 0
+    # first-class fields of the line: the module-level step times, the whole-step MFMA fraction and the largest
+    # single symbol beside the dominant class, the bf16 leg BASELINE.json's metric string names
+    for wl in ("g_only", "gan"):
+        m = r["module_loop"][wl]
+        assert m["dropin_3_imports_ms_per_step"] > 0 and m["model_import_only_ms_per_step"] > 0 and m["fused_trainer_ms_per_step"] > 0
+    for obj in (r, r["gan"]):
+        rf = obj["roofline"]
+        assert 0 < rf["step_mfma_frac"] < 1 and rf["largest_symbol"]["avg_us"] > 0 and 0 <= rf["largest_symbol"]["mfma_frac"] < 1
+    assert r["bf16"]["ms_per_step"] > 0 and 0 < r["bf16"]["step_mfma_frac"] < 1 and all(v == v for v in r["bf16"]["last_step_scalars"])
     out = _run(["--workload", "gan", "--module-loop"] + SMALL)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "module-level" in _line(out)["config"]["loop"]

@@ -134,3 +134,92 @@ def test_trainers_exchange_one_flat_gradient_per_network():
         assert p.exitcode == 0
     for r in res:
         assert r[1] and r[2], f"rank {r[0]}: {r}"
+
+
+def _world8_worker(rank, world, port, q):
+    """BASELINE configs[3] (global batch 256 over 8 ranks, full GAN) and configs[4] (A-ESRGAN, SyncBatchNorm) as a gloo dry run: the
+    REAL networks (23 RRDB: 16,697,987 generator / 4,376,897 discriminator parameters) on tiny images, HIP library in dry-run mode.
+    Checked per rank and across ranks: the global batch partitions into 8 x 32 with no image lost or doubled, every rank issues the SAME
+    sequence of collectives (sizes and order), the buckets of a network cover its flat gradient exactly once, the discriminator's
+    exchange comes before the generator's, the SyncBatchNorm table reduce sits inside the discriminator passes, 1/8 reaches Adam."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from sr_gan_fd_amd import _abi as A, model as M, parallel as P
+    from sr_gan_fd_amd.gan import GanTrainer
+    A.set_dry_run(True)
+    r, _, w, pg = P.init_from_env("gloo")
+    # configs[3]'s partition: global batch 256 -> 8 contiguous shards of 32
+    ids = torch.arange(256)
+    mine = P.shard(ids, rank, world)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=pg)
+    ok_part = mine.numel() == 32 and torch.equal(torch.cat(got), ids)
+    calls = []
+    orig = dist.all_reduce
+
+    def spy(t, *a, **k):
+        calls.append(int(t.numel()))
+        return orig(t, *a, **k)
+    dist.all_reduce = spy
+    torch.manual_seed(0)
+    g = M.bsrgan_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    n_g, n_d = sum(p.numel() for p in g.parameters()), sum(p.numel() for p in d.parameters())
+    tr = GanTrainer(g, d, None, process_group=pg)
+    lr_img, gt = torch.rand(2, 3, 16, 16), torch.rand(2, 3, 64, 64)
+    scales = []
+    for opt in (tr.g_opt, tr.d_opt):
+        step0 = opt.step
+        opt.step = (lambda grad, grad_scale=1.0, *a, _s=step0, **k: (scales.append(grad_scale), _s(grad, grad_scale, *a, **k))[1])
+    tr.step(lr_img, gt)
+    gan_calls = list(calls)
+    ok_sizes = (n_g, n_d) == (16697987, 4376897)
+    ok_gan = (gan_calls[0] == tr.de.fp.total and gan_calls[1:] == tr.g_reducer.sizes and sum(gan_calls[1:]) == tr.ge.fp.total
+              and len(gan_calls) == 4 and tr.ge.fp.total >= n_g and tr.de.fp.total >= n_d)
+    ok_scale = len(scales) == 2 and all(abs(s - 1.0 / world) < 1e-12 for s in scales)
+    # configs[4]: the attention U-Net discriminator with whole-batch BatchNorm statistics (parallel.SyncBatchNormReduce)
+    calls.clear()
+    torch.manual_seed(0)
+    g2 = M.bsrgan_x4(num_rrdb=1)
+    d2 = M.uNetDiscriminatorAesrgan()
+    tr2 = GanTrainer(g2, d2, None, g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1, process_group=pg, sync_batchnorm=True)
+    tr2.step(torch.rand(2, 3, 32, 32), torch.rand(2, 3, 128, 128))
+    aes_calls = list(calls)
+    n_bn = sum(1 for c in aes_calls if c not in (tr2.de.fp.total,) and c not in tr2.g_reducer.sizes)
+    ok_aes = tr2.de.fp.total in aes_calls and sum(tr2.g_reducer.sizes) == tr2.ge.fp.total and n_bn > 0
+    # every rank must have issued the same collectives in the same order: compare with rank 0's record
+    rec = torch.tensor(gan_calls + [-1] + aes_calls, dtype=torch.int64)
+    n = torch.tensor([rec.numel()])
+    dist.broadcast(n, src=0, group=pg)
+    ref = rec.clone() if rank == 0 else torch.zeros(int(n.item()), dtype=torch.int64)
+    dist.broadcast(ref, src=0, group=pg)
+    ok_same = rec.numel() == ref.numel() and torch.equal(rec, ref)
+    dist.barrier()
+    q.put((rank, ok_part, ok_sizes, ok_gan, ok_scale, ok_aes, ok_same, gan_calls, len(aes_calls)))
+    dist.destroy_process_group()
+
+
+def test_world8_dry_run_of_the_configs3_and_configs4_partition():
+    """no 8-GPU node has been available in any round, so the N = 8 path is rehearsed here on the CPU (gloo, dry run)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    import queue, time
+    t0 = time.time()
+    while len(res) < len(procs) and time.time() - t0 < 600:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: " + str([p.exitcode for p in procs])
+    assert len(res) == len(procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:7]), f"rank {r[0]}: partition/sizes/gan/scale/aesrgan/same-order = {r[1:7]}, GAN collectives {r[7]}, A-ESRGAN collectives {r[8]}"

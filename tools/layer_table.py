@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--lr-size", type=int, default=0)
+    ap.add_argument("--upscale", type=int, default=4)
     o = ap.parse_args()
     orig = profiling.conv_label
 
@@ -35,7 +37,7 @@ def main():
         return bracket(self, label, work, fn)
     profiling.Recorder.bracket = bracket_shaped
 
-    args = argparse.Namespace(gpus=1, steps=o.steps, warmup=2, workload=o.workload, batch=o.batch, esrgan_module_loop=False, lr_size=0, num_rrdb=23,
+    args = argparse.Namespace(gpus=1, steps=o.steps, warmup=2, workload=o.workload, batch=o.batch, esrgan_module_loop=False, lr_size=o.lr_size, upscale=o.upscale, num_rrdb=23,
                               dtype="f16", no_cpu_baseline=True, no_kernel_events=False, dist_backend="nccl", module_loop=False, no_module_loop=True, dropin_optim=False)
     enable = profiling.enable
     profiling.enable = lambda every=7: enable(1)
