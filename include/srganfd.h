@@ -34,7 +34,7 @@ extern "C" {
 const char* srganfd_last_error(void);
 /* Bumped whenever an exported signature or struct changes; the binding (sr_gan_fd_amd/_abi.py) reads this constant from this
  * header and refuses a library whose srganfd_abi_version() differs (a stale A/B build selected with SRGANFD_LIB, a prebuilt .so). */
-#define SRGANFD_ABI_VERSION 6
+#define SRGANFD_ABI_VERSION 7
 int srganfd_abi_version(void);
 /* dry run: entry points validate their arguments and build plans but launch nothing (used by the
  * CPU-only host-logic tests; never set in production). */
@@ -103,6 +103,21 @@ int srganfd_conv2d(const srganfd_conv_args* a, void* stream);
 /* Name of the kernel template srganfd_conv2d dispatches these arguments to (validates them, launches nothing): the class label
  * of bench.py's per-kernel timing and of the rocprofv3 summaries under profiles/. */
 int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_len);
+
+/* A whole dense block as ONE launch with LDS-resident activations (csrc/dense_chain.hip): replaces the n_layers srganfd_conv2d
+ * launches of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62; ESRGAN/model.py:49-60, Real_ESRGAN/model.py:131-142,
+ * A-ESRGAN/model.py:441-452 are the same code) -- or of its data-gradient pass, which is the same dense structure over the stacked
+ * output gradients -- when an image is at most one 8 x 32-pixel tile per compute unit (the reference's crop sizes: 32 ... 72 pixels
+ * at batch 8-16).  `layers` are exactly the arguments those launches would get, in order: layer i (0-based) is a 16-bit 3x3
+ * stride-1 pad-1 conv reading channels [0, 64 + 32 i) of ONE buffer; all but the last write 32 channels at [64 + 32 i, 96 + 32 i) of
+ * that same buffer (bias / activation / mask as given), the last one (64 output channels, r1 / r2 / mask as given) writes anywhere
+ * else.  Results follow srganfd_conv2d's formula with the same accumulation order; the batch is processed in groups of images whose
+ * tiles are all resident at once.  `workspace`: srganfd_dense_chain_workspace_bytes() bytes of device memory that the caller zeroes
+ * ONCE at allocation (hand-off flags are re-zeroed per launch on the stream; word 0 counts hand-off waits that gave up -- always 0 in
+ * a correct run, results are wrong otherwise).  srganfd_dense_chain_check validates `layers` and the size limit without launching. */
+int srganfd_dense_chain(const srganfd_conv_args* layers, int32_t n_layers, void* workspace, size_t workspace_bytes, void* stream);
+int srganfd_dense_chain_check(const srganfd_conv_args* layers, int32_t n_layers);
+size_t srganfd_dense_chain_workspace_bytes(void);
 
 /* Weight packing: NCHW fp32 parameters -> MFMA B-fragment order (dtype bf16/f32).
  * A packed operand is a logical matrix W[tap][k][n]; its k range is assembled from up to 5

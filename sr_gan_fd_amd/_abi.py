@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SRGANFD_LIB") or os.path.join(_HERE, "libsrganfd_hip.
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "srganfd.h")
 
 
-_ABI_VERSION_BUILT = 6     # SRGANFD_ABI_VERSION this binding's structures were written against (tests/test_host_logic.py keeps it equal to the header's)
+_ABI_VERSION_BUILT = 7     # SRGANFD_ABI_VERSION this binding's structures were written against (tests/test_host_logic.py keeps it equal to the header's)
 
 
 def _header_abi_version() -> int:
@@ -119,6 +119,9 @@ SYMBOLS = {
     "srganfd_pack_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "srganfd_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srganfd_conv2d_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]),
+    "srganfd_dense_chain": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "srganfd_dense_chain_check": (C.c_int, [C.POINTER(ConvArgs), C.c_int32]),
+    "srganfd_dense_chain_workspace_bytes": (C.c_size_t, []),
     "srganfd_conv2d_thin_in": (C.c_int, [C.POINTER(ThinArgs), C.c_void_p]),
     "srganfd_conv2d_thin_out": (C.c_int, [C.POINTER(ThinArgs), C.c_void_p]),
     "srganfd_conv2d_thin_wgrad_workspace": (C.c_size_t, []),

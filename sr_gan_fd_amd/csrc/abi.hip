@@ -16,7 +16,9 @@ int set_err(int code, const char* fmt, ...) {
   return code;
 }
 int conv2d_impl(const srganfd_conv_args* a, hipStream_t stream);
-int conv2d_chain_impl(const srganfd_conv_args* args, int n, void* counters, hipStream_t stream);
+int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int dense_chain_check_impl(const srganfd_conv_args* layers, int n);
+size_t dense_chain_workspace_bytes_impl();
 int pack_weights_impl(const srganfd_pack_job* jobs_dev, int njobs, long long max_elems, const float* params,
                       const float* scalars, void* packed, hipStream_t stream);
 size_t wgrad_plan_bytes_impl(const srganfd_wgrad_shape* s, const srganfd_wgrad_conv* convs);
@@ -108,6 +110,11 @@ int srganfd_get_mfma16(void) { return srganfd::g_mfma16; }
 int srganfd_pack_layout(int32_t dtype, int32_t ksize, int32_t n) { return srganfd::conv_uses_m16(dtype, ksize, n) ? 1 : 0; }
 
 int srganfd_conv2d(const srganfd_conv_args* a, void* stream) { return conv2d_impl(a, (hipStream_t)stream); }
+int srganfd_dense_chain(const srganfd_conv_args* layers, int32_t n_layers, void* workspace, size_t workspace_bytes, void* stream) {
+  return dense_chain_impl(layers, n_layers, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int srganfd_dense_chain_check(const srganfd_conv_args* layers, int32_t n_layers) { return dense_chain_check_impl(layers, n_layers); }
+size_t srganfd_dense_chain_workspace_bytes(void) { return dense_chain_workspace_bytes_impl(); }
 int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_len) {
   if (!out || !out_len) return set_err(SRGANFD_EINVAL, "conv2d_describe: no buffer");
   out[0] = 0;

@@ -115,6 +115,54 @@ def conv2d(args: A.ConvArgs) -> None:
     A.check(A.lib().srganfd_conv2d(C.byref(args), A.stream_ptr()), "conv2d")
 
 
+# ---- LDS-resident dense-block launch (csrc/dense_chain.hip): the five convs of a dense block, or of its data-gradient pass, as one launch ----
+DENSE_CHAIN = os.environ.get("SRGANFD_DENSE_CHAIN", "auto")     # "0": never, "1": whenever the arguments qualify, "auto": small launches only (see dense_chain_wanted)
+_DC_WS = {}
+
+
+def dense_chain_workspace(device) -> torch.Tensor:
+    """hand-off flags + error word of the dense-chain launches of one device (zeroed once here; the launches re-zero the flags they use
+    on the stream, and they run in stream order, so every chain of a device can share it)"""
+    ws = _DC_WS.get(str(device))
+    if ws is None:
+        ws = _DC_WS[str(device)] = torch.zeros(int(A.lib().srganfd_dense_chain_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
+def dense_chain_wanted(n: int, h: int, w: int, cus: int = 256) -> bool:
+    """the regime the launch is built for: an image is at most one 8 x 32 tile per CU, and the batch needs few passes (each pass holds
+    cus // tiles images); above that the per-layer kernels are bandwidth- or MFMA-bound and the resident tile has nothing to win"""
+    if DENSE_CHAIN == "0":
+        return False
+    per = -(-h // 8) * -(-w // 32)
+    if per > cus:
+        return False
+    return DENSE_CHAIN == "1" or n * per <= 2 * cus
+
+
+class DenseChain:
+    """n conv launches (A.ConvArgs, the arguments srganfd_conv2d would get) run by srganfd_dense_chain; ``ok`` False when the library
+    refuses them (then the caller keeps the separate launches)."""
+
+    def __init__(self, layers: Sequence[A.ConvArgs], device):
+        self.n = len(layers)
+        self.arr = (A.ConvArgs * self.n)()
+        for i, a in enumerate(layers):
+            C.memmove(C.byref(self.arr, i * C.sizeof(A.ConvArgs)), C.byref(a), C.sizeof(A.ConvArgs))
+        self.layers = list(layers)           # keeps the structs (and the label cache on them) alive
+        self.ok = A.lib().srganfd_dense_chain_check(self.arr, self.n) == 0
+        self.ws = dense_chain_workspace(device) if self.ok else None
+        self.flops = sum(2.0 * a.n * a.h_out * a.w_out * 9 * a.cin * a.cout for a in layers)
+        self.bytes = 0.0
+
+    def run(self) -> None:
+        A.check(A.lib().srganfd_dense_chain(self.arr, self.n, self.ws.data_ptr(), self.ws.numel(), A.stream_ptr()), "dense_chain")
+
+    def errors(self) -> int:
+        """hand-off waits that gave up since the workspace was allocated (synchronises; tests)"""
+        return int(self.ws[:4].view(torch.int32).item())
+
+
 # ---- thin-side convolutions (csrc/conv_thin.hip): 1..4 channels against 64, 3x3 stride 1 pad 1, 16-bit dtypes ----
 THIN_ENABLED = os.environ.get("SRGANFD_THIN", "1") != "0"      # same-box A/B switch: 0 keeps these layers on the 32-channel-padded kernels
 

@@ -1,0 +1,94 @@
+"""LDS-resident dense-block launch (csrc/dense_chain.hip, srganfd_dense_chain) against the separate srganfd_conv2d launches it replaces:
+the five convs of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62: four growth convs with bias + LeakyReLU written into the block's
+own buffer, the closing 192 -> 64 conv with the residual epilogue) and the five launches of its data-gradient pass (masks from the saved
+activations, residual adds on the closing launch), at the reference's crop sizes and at ragged ones, NHWC and planar buffers, several
+images per pass and several passes per call.  Same accumulation order and epilogue formula -> the comparison bound is one rounding of
+the stored 16-bit value (and the CPU oracle comparison of the whole generator runs through the engine in test_generator_gpu.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(buf, planar):
+    from sr_gan_fd_amd import _abi as A
+    return lambda c0=0: A.view(buf, c0=c0, planar=planar)
+
+
+def _build(dtype, n, h, w, planar, backward, seed=0):
+    """the five launches of a dense block over fresh buffers; returns (args list, buffers to compare, keep-alive list)"""
+    from sr_gan_fd_amd import _abi as A, ops
+    torch.manual_seed(seed)
+    dt = ops.DT[dtype]
+    Cc, G = 64, 32
+    buf = torch.zeros(n, h, w, 192, device="cuda", dtype=dtype)
+    x0 = (torch.randn(n, h, w, Cc, device="cuda") * 0.6).to(dtype)
+    if planar:
+        buf.view(n, 6, h, w, 32)[:, :2].copy_(x0.view(n, h, w, 2, 32).permute(0, 3, 1, 2, 4))
+    else:
+        buf[..., :Cc].copy_(x0)
+    out = torch.full((n, h, w, Cc), 7.0, device="cuda", dtype=dtype)
+    V, VO = _views(buf, planar), _views(out, 0)
+    keep, args = [buf, out], []
+    r1 = (torch.randn(n, h, w, Cc, device="cuda")).to(dtype)
+    r2 = (torch.randn(n, h, w, Cc, device="cuda")).to(dtype)
+    act = (torch.randn(n, h, w, 192, device="cuda")).to(dtype)           # "saved activations": the sign gives the LeakyReLU' mask
+    keep += [r1, r2, act]
+    for k in range(5):
+        cin, cout = Cc + k * G, (Cc if k == 4 else G)
+        wt = torch.randn(cout, cin, 3, 3, device="cuda") / (3.0 * cin ** 0.5)
+        wp = ops.pack_single(wt, dt)
+        b = torch.randn(cout, device="cuda") * 0.1
+        keep += [wp, b]
+        if k < 4:
+            kw = dict(mask=A.view(act, c0=Cc + (3 - k) * G), mask_slope=0.2) if backward else dict(bias=b, act=A.ACT_LRELU, slope=0.2)
+            args.append(ops.conv_args(dt, V(), V(cin), wp, n, h, w, cin, cout, **kw))
+        else:
+            kw = dict(r1=A.view(r1), r1_scale=0.2, r2=A.view(r2), r2_scale=1.0) if backward else \
+                dict(bias=b, post_scale=0.04, r1=V(), r1_scale=0.2, r2=A.view(r2), r2_scale=1.0)
+            args.append(ops.conv_args(dt, V(), VO(), wp, n, h, w, cin, cout, **kw))
+    return args, (buf, out), keep
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("backward", [False, True], ids=["forward", "data-gradient"])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 1), (3, 21, 45, 1), (16, 32, 32, 1), (8, 60, 60, 1), (16, 72, 72, 1), (2, 24, 40, 0), (1, 8, 8, 1)],
+                         ids=lambda s: "n%d_%dx%d_%s" % (s[0], s[1], s[2], "planar" if s[3] else "nhwc"))
+def test_dense_chain_equals_the_separate_launches(dtype, backward, shape):
+    from sr_gan_fd_amd import ops
+    n, h, w, planar = shape
+    a_ref, (buf_ref, out_ref), k1 = _build(dtype, n, h, w, planar, backward)
+    a_dc, (buf_dc, out_dc), k2 = _build(dtype, n, h, w, planar, backward)
+    assert torch.equal(buf_ref, buf_dc)
+    for a in a_ref:
+        ops.conv2d(a)
+    chain = ops.DenseChain(a_dc, buf_dc.device)
+    assert chain.ok
+    chain.run()
+    torch.cuda.synchronize()
+    assert chain.errors() == 0
+    scale = buf_ref.float().abs().max().item()
+    e_buf = (buf_ref.float() - buf_dc.float()).abs().max().item() / scale
+    e_out = (out_ref.float() - out_dc.float()).abs().max().item() / (out_ref.float().abs().max().item() + 1e-30)
+    same = torch.equal(buf_ref, buf_dc) and torch.equal(out_ref, out_dc)
+    print(f"dense chain {dtype} n{n} {h}x{w}: buffer err {e_buf:.2e}, output err {e_out:.2e}, bitwise {same}")
+    # one rounding of a stored 16-bit value can differ where an fp32 sum lands on a rounding boundary (the epilogue is an explicit fma chain
+    # here, mul + add where the compiler chose so in conv_igemm) and propagates through the later layers
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert torch.isfinite(out_dc.float()).all() and e_buf < tol and e_out < tol
+    # a second run over the same buffers (flags re-zeroed on the stream) gives the same bits: the launch is deterministic
+    snap_b, snap_o = buf_dc.clone(), out_dc.clone()
+    chain.run()
+    torch.cuda.synchronize()
+    assert chain.errors() == 0 and torch.equal(snap_b, buf_dc) and torch.equal(snap_o, out_dc)
+
+
+def test_dense_chain_refuses_what_it_cannot_run():
+    from sr_gan_fd_amd import _abi as A, ops
+    args, _, keep = _build(torch.float16, 1, 16, 32, 1, False)
+    assert ops.DenseChain(args, "cuda").ok
+    assert not ops.DenseChain(args[:1], "cuda").ok                       # fewer than two layers
+    assert not ops.DenseChain(args[1:], "cuda").ok                       # does not start at the 64-channel layer
+    big, _, keep2 = _build(torch.float16, 1, 8 * 40, 32 * 8, 1, False)   # 320 tiles of one image: more than the device has CUs
+    assert not ops.DenseChain(big, "cuda").ok
+    assert not ops.dense_chain_wanted(32, 128, 128) and ops.dense_chain_wanted(16, 72, 72) and ops.dense_chain_wanted(16, 32, 32)

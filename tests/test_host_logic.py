@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/srganfd.h but not exported"
     assert declared == set(A.SYMBOLS), f"binding/header mismatch: {declared ^ set(A.SYMBOLS)}"
-    assert A.lib().srganfd_abi_version() == A.ABI_VERSION == A._ABI_VERSION_BUILT == 6
+    assert A.lib().srganfd_abi_version() == A.ABI_VERSION == A._ABI_VERSION_BUILT == 7
     assert A.lib().srganfd_get_mfma16() == 3
 
 
