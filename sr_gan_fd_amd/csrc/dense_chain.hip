@@ -1,29 +1,39 @@
 // dense_chain.hip -- a whole dense block as ONE launch whose activations never leave LDS.
 //
-// Replaces, for launches of at most one 8 x 32-pixel tile per compute unit (the reference's own crop sizes: bsrgan_config.py:101-102
-// 72 x 72, esrgan_config.py:73-74 32 x 32, rrdbnet_config.py:51-52 48 x 48, aesrgan_config.py:102-103 60 x 60 at batch 8-16), the five
-// srganfd_conv2d launches of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62) -- and, with the data-gradient operands, the five
-// launches of its backward pass (the same dense structure over the stacked output gradients, engine.py) -- by one persistent launch.
+// Replaces the five srganfd_conv2d launches of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62) -- and, with the data-gradient
+// operands, the five launches of its backward pass (the same dense structure over the stacked output gradients, engine.py) -- by one
+// persistent launch, for every batch whose images are at most one 16 x 16-pixel tile per compute unit (the reference's crop sizes:
+// bsrgan_config.py:101-102 72 x 72, esrgan_config.py:73-74 32 x 32, rrdbnet_config.py:51-52 48 x 48, aesrgan_config.py:102-103 60 x 60,
+// and BASELINE's 128 x 128: 64 tiles per image, four images per pass).
 //
-// Why: at those sizes a conv launch is a single tile per workgroup and costs 13-15 us whatever it computes (profiles/
-// r05_reference_shapes_before.txt): kernel boundary, argument loads, address set-up, the round trip of the tile's own data through
-// HBM/L2 and the LDS commit of every chunk are paid per layer; neither removing the boundaries (layer-persistent launch) nor the
-// commits (LDS-DMA streaming conv) changed that (profiles/r05_chain_at_small_shapes.txt, r05_stream_conv_at_small_shapes.txt).
+// Why: a per-layer conv launch pays, per tile and layer, the kernel boundary, the address set-up, the round trip of the tile's own data
+// through L2 / HBM and the LDS commit of every chunk (13-15 us per launch whatever it computes at the reference's sizes,
+// profiles/r05_reference_shapes_before.txt; 14 us + 7.3 us per 32 input channels at batch 32, 128 x 128); neither removing the boundaries
+// (layer-persistent launch) nor the commits (LDS-DMA streaming conv) changed that (profiles/r05_chain_at_small_shapes.txt,
+// r05_stream_conv_at_small_shapes.txt).  Only a kernel that keeps the tile ACROSS layers removes them.
 //
 // MI355X mapping (this is what 160 KB of LDS per CU and 256 CUs are for -- 40 MB of on-chip activation store):
-//   * one workgroup (8 waves) per CU owns ONE tile of 8 rows x 32 pixels of one image through all layers.  The tile's 192 channels
-//     with a 1-pixel halo (10 x 34 pixels x 6 groups of 32 channels x 2 B = 130,560 B) are LDS-resident: groups 0-1 (the block
-//     input) are loaded once, group 2 + k is written by layer k's epilogue straight from the accumulators.
-//   * only the halo of a NEW group crosses workgroups: the epilogue also stores the tile to the block's HBM buffer (the weight
-//     gradient and the next launch need it there anyway) with write-through (sc1) stores, drains them, and publishes one flag per
-//     (layer, tile); a consumer polls the flags of its <= 8 neighbours with relaxed agent-scope loads and reads the 84 halo pixels
-//     with sc1 loads -- row 1 of the micro-architecture guide's hand-off table; no fences, no placement assumption.  The halo of layer
-//     k is first needed by the LAST chunk of layer k + 1, so the hand-off hides behind that layer's older chunks.
-//   * weights stream through a 5-slot LDS ring of 6 KB kernel-column pieces (3 kernel rows x 2 channel halves x 1 KB B fragments in
-//     pack.hip's order) by LDS-DMA, four pieces ahead of the MFMA step that consumes them, one barrier per step.
-//   * every layer is "32 * n input channels -> 32 output channels" (the 64-channel conv5 runs as its two 32-channel n-tiles); wave
-//     (rp, ph) computes rows 2 rp, 2 rp + 1 x pixels 16 ph .. 16 ph + 15 x 32 channels: 12 v_mfma_f32_16x16x32 per step with the
-//     operands swapped (A = weights, B = pixels), so a lane ends up with 4 consecutive channels of one pixel: 8-byte LDS / global writes.
+//   * one workgroup per CU owns ONE tile of 16 x 16 pixels of one image through all layers, then walks on to its tile of the next group
+//     of images ("pass").  The tile's 192 channels with a 1-pixel halo (18 x 18 pixels x 6 groups of 32 channels x 2 B = 124,416 B) are
+//     LDS-resident: groups 0-1 (the block input) are loaded once per pass, group 2 + k is written by layer k's epilogue straight from the
+//     accumulators.
+//   * four COMPUTE waves (one per SIMD): wave w computes rows 4w .. 4w+3 x 16 pixels x 32 output channels -- per kernel-column step 6
+//     pixel fragments (patch rows 4w .. 4w+5, reused by the three kernel rows) and 6 weight fragments for 24 v_mfma_f32_16x16x32
+//     (operands swapped: A = weights, B = pixels, so a lane ends up with 4 consecutive channels of one pixel: 8-byte LDS / global
+//     writes).  48 KB of LDS reads per step and CU = 192 LDS cycles against 384 MFMA cycles per SIMD; the fragments of step t+1 are read
+//     while step t's MFMAs issue (two register sets, the step loop is unrolled by two).
+//   * two LOADER waves own the weight stream: per step three 1 KB LDS-DMA pieces each (pack.hip's fragment order: a piece is one
+//     ds_read_b128 per lane) into a ring of six 6 KB slots, five steps ahead, counted vmcnt; ONE barrier per step publishes slot t+1 and
+//     frees slot t.  No compute wave ever issues or waits for a weight piece.
+//   * only the halo of a NEW group crosses workgroups: the epilogue also stores the tile to the block's HBM buffer (the weight gradient and
+//     the next launch need it there anyway) with write-through (sc1) stores and goes on; two steps into the next layer every compute wave
+//     drains its stores (free by then), a barrier, and ONE lane publishes one flag per (layer, tile) -- row 1 of the micro-architecture
+//     guide's hand-off table.  A consumer polls the flags of its <= 8 neighbours and reads the 68 halo pixels with sc1 loads; both are
+//     ordinary loads issued by the compute waves two steps before their results are used, so the two dependent round trips (~1.1k cycles
+//     each) run beside the MFMA steps.  The halo of layer k is first needed by the LAST chunk of layer k + 1: one step before it every wave
+//     reads four interval-stamped LDS words and, if the halo is not in yet, all waves take extra barriers together (a uniform decision).
+//   * flags are epoch-valued: the launch reads its epoch from a device counter that the last workgroup to finish advances, so nothing is
+//     zeroed per launch and a captured hipGraph replays correctly.
 // Same arithmetic contract as conv_igemm.hip (include/srganfd.h, srganfd_conv2d): fp32 accumulation in chunk, kernel-column,
 // kernel-row order, v = post_scale * act(alpha * acc + bias) + r1s * r1 + r2s * r2, masked, rounded once to the 16-bit type.
 #include "conv_common.hpp"
@@ -36,11 +46,19 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k);   // conv_igemm.hip: vali
 
 namespace {
 constexpr int kDcMaxLayers = 6;      // four growth convs + the two 32-channel halves of the closing conv
-constexpr int kDcPR = 10, kDcPC = 34, kDcNPIX = kDcPR * kDcPC;
-constexpr int kDcGroupBytes = kDcNPIX * 64;          // one 32-channel group of the resident patch
+constexpr int kDcT = 16;             // tile edge
+constexpr int kDcPC = 18, kDcNPIX = kDcPC * kDcPC;
+constexpr int kDcGroupBytes = kDcNPIX * 64;          // one 32-channel group of the resident patch: 20,736 B
 constexpr int kDcGroups = 6;
-constexpr int kDcSlot = 6144, kDcSlots = 5, kDcAhead = 4;
-constexpr int kDcLds = kDcGroups * kDcGroupBytes + kDcSlots * kDcSlot + 64;     // 161,344 B
+constexpr int kDcSlot = 6144, kDcSlots = 5;          // weight ring: the step being read + four in flight
+constexpr int kDcRingOff = kDcGroups * kDcGroupBytes;            // 124,416
+constexpr int kDcStageOff = kDcRingOff + kDcSlots * kDcSlot;     // 155,136: hand-off staging of the four compute waves (LDS-DMA destinations)
+constexpr int kDcStageHalo = 1088, kDcStageWave = kDcStageHalo + 256;     // per wave: its 68 halo items of 16 B, then one flag word per lane
+constexpr int kDcCtlOff = kDcStageOff + 4 * kDcStageWave;        // 160,512: float alpha[8]; float bias[6][32]
+constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4;      // 161,312 B
+constexpr int kDcThreads = 384;      // waves 0-3 compute, 4-5 weight loaders
+constexpr int kDcHaloPix = 68, kDcHaloItems = kDcHaloPix * 4;    // 16-byte items of one group's halo ring
+constexpr int kDcMaxTiles = 16384;   // tiles of one call (flags: 4 growth layers x tiles)
 
 struct DcLayer {
   const char* w;             // this 32-channel n-tile of the packed operand: [chunk][tap][channel half][64 lanes x 16 B]
@@ -56,21 +74,40 @@ struct DcK {
   DcLayer L[kDcMaxLayers];
   const char* x;             // image-0 base of the block input (groups 0, 1)
   int xC, x_ps, x_base, x_cs;
-  int nLayers, totalSteps;
-  int N, H, W, tiles_x, tiles_y, ntiles;
-  int* flags;                // [growth layer][tile], zeroed before the launch
-  int* err;                  // [0] += 1 for every hand-off wait that gave up
-  int dbg;                   // TIMING EXPERIMENT (SRGANFD_DC_DBG): 1 no hand-off, 2 no epilogue memory traffic, 4 no memset, 8 no MFMA steps
+  int nLayers, stepsPerPass;
+  int N, H, W, tiles_x, tiles_y, tpi;       // tpi: tiles per image
+  int ipl;                   // images per pass (the grid is ipl * tpi workgroups)
+  int totalTiles;            // N * tpi
+  int* hdr;                  // [0] hand-off waits that gave up, [1] epoch of the last finished launch, [2] workgroups finished in this launch
+  int* flags;                // [growth layer][tile of the batch], epoch-valued
+#ifdef SRGANFD_EXPERIMENT
+  unsigned long long* stamps;   // [workgroup][256] s_memtime stamps of compute wave 0 (tools/r5/dc_stamps.py)
+#endif
 };
 
 __device__ __forceinline__ unsigned dc_lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // One LDS-DMA piece (see wgrad.hip glds16): 64 lanes x 16 bytes, per-lane source, wave-uniform LDS destination; outside the
-// compiler's wait-count bookkeeping, the kernel counts vmcnt itself.
+// compiler's wait-count bookkeeping, the loader waves count vmcnt themselves.
 __device__ __forceinline__ void dc_glds16(const void* gsrc, unsigned lds_dst) {
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "m0", "memory");
+#pragma clang diagnostic pop
+}
+// the hand-off's loads: the same LDS-DMA with the sc1 policy (served by memory, never a stale L1 / L2 line); 16 bytes or one dword per lane
+__device__ __forceinline__ void dc_glds16_sc1(const void* gsrc, unsigned lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(gsrc), "s"(dst) : "m0", "memory");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void dc_glds4_sc1(const void* gsrc, unsigned lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(gsrc), "s"(dst) : "m0", "memory");
 #pragma clang diagnostic pop
 }
 template <int N> __device__ __forceinline__ void dc_wait_vm() {
@@ -79,229 +116,448 @@ template <int N> __device__ __forceinline__ void dc_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #pragma clang diagnostic pop
 }
+// at most 3 * younger_steps of this loader's pieces may still be in flight (the ring holds the step being read and four more)
+__device__ __forceinline__ void dc_wait_pieces(int younger_steps) {
+  if (younger_steps >= 3) dc_wait_vm<9>(); else if (younger_steps == 2) dc_wait_vm<6>();
+  else if (younger_steps == 1) dc_wait_vm<3>(); else dc_wait_vm<0>();
+}
+// workgroup barrier that leaves vector-memory operations in flight (LDS operations of this wave are complete when it is passed)
+__device__ __forceinline__ void dc_barrier() {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma clang diagnostic pop
+}
 // byte position of (patch row, patch column, 16-byte slot) inside one group: pixel-major, slot XOR 2 * ((column >> 2) & 1) -- the
 // column-keyed swizzle of conv_igemm.hip's 16x16x32 fragment reads (conflict-free ds_read_b128 for every kernel column)
 __device__ __forceinline__ int dc_pos(int prow, int pcol, int slot) { return (prow * kDcPC + pcol) * 64 + ((slot ^ (((pcol >> 2) & 1) << 1)) << 4); }
+// halo ring pixel hp (0..67) of the 18 x 18 patch: top row, bottom row, left column, right column
+__device__ __forceinline__ void dc_halo_rc(int hp, int& prow, int& pcol) {
+  prow = hp < 18 ? 0 : (hp < 36 ? 17 : (hp < 52 ? 1 + hp - 36 : 1 + hp - 52));
+  pcol = hp < 18 ? hp : (hp < 36 ? hp - 18 : (hp < 52 ? 0 : 17));
+}
 
 typedef unsigned long long dc_u64;
 typedef __attribute__((ext_vector_type(2))) unsigned int dc_u32x2;
+
+template <typename T> __device__ __forceinline__ void dc_widen4(const dc_u32x2 q, float* f) {
+  if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 hv = __builtin_bit_cast(h4, q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)hv[i];
+  } else {
+    f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ dc_u32x2 dc_narrow4(const float* v4) {
+  if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 hv = {(_Float16)v4[0], (_Float16)v4[1], (_Float16)v4[2], (_Float16)v4[3]};
+    return __builtin_bit_cast(dc_u32x2, hv);
+  } else {
+    return dc_u32x2{(unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16), (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16)};
+  }
+}
 }  // namespace
 
 template <typename T>
-__global__ __launch_bounds__(512, 2) void dense_chain_kernel(const DcK a) {
+__global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   using Frag = typename FragAB<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const patch = smem;
-  char* const ring = smem + kDcGroups * kDcGroupBytes;
+  char* const ring = smem + kDcRingOff;
+  float* const ctl_alpha = (float*)(smem + kDcCtlOff);
+  float* const ctl_bias = (float*)(smem + kDcCtlOff + 32);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rp = wave >> 1, ph = wave & 1;          // this wave's row pair and pixel half
   const int l15 = lane & 15, g4 = lane >> 4;
 
-  const int tile = blockIdx.x;
-  const int tx = tile % a.tiles_x, t1 = tile / a.tiles_x;
-  const int ty = t1 % a.tiles_y, n = t1 / a.tiles_y;
-  const int oy0 = ty * 8, ox0 = tx * 32;
+  const int li = blockIdx.x / a.tpi, tin = blockIdx.x - li * a.tpi;       // image of the pass, tile of the image
+  const int ty = tin / a.tiles_x, tx = tin - ty * a.tiles_x;
+  const int oy0 = ty * kDcT, ox0 = tx * kDcT;
   const size_t ipix = (size_t)a.H * a.W;
+  const int npass = li < a.N ? (a.N - li + a.ipl - 1) / a.ipl : 0;
+  const int totalSteps = npass * a.stepsPerPass;
+#ifdef SRGANFD_EXPERIMENT
+  unsigned long long* const stp = a.stamps ? a.stamps + (size_t)blockIdx.x * 256 : nullptr;
+  auto now = []() { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); return t_; };
+  auto rnow = []() { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); return t_; };
+#define DC_STAMP(i) do { if (stp && wave == 0) { const unsigned long long t_ = now(); if (lane == 0) stp[i] = t_; } } while (0)
+  if (stp && wave == 0) { const unsigned long long t_ = rnow(); if (lane == 0) stp[61] = t_; }
+#else
+#define DC_STAMP(i) do {} while (0)
+#endif
+  DC_STAMP(0);
 
-  // ---- weight stream: producer cursor = the next kernel-column step to request ----
-  int pl = 0, pc = 0, pk = 0, pt = 0;
-  auto issue_next = [&]() {
-    if (pl < a.nLayers) {
-      if (wave < 6) {
-        const int ky = wave >> 1, nh = wave & 1;
-        const char* src = a.L[pl].w + (size_t)(((pc * 9 + ky * 3 + pk) * 2 + nh) * 1024) + lane * 16;
-        dc_glds16(src, dc_lds_addr(ring) + (unsigned)((pt % kDcSlots) * kDcSlot + wave * 1024));
-      }
-      ++pt;
-      if (++pk == 3) { pk = 0; if (++pc == a.L[pl].nChunks) { pc = 0; ++pl; } }
-    }
-  };
+  // resident patch of a pass: groups 0, 1 from the block input (zeros outside the image), zero halo ring for the groups to come.  Nobody
+  // reads the patch any more when this runs: the last step of the previous pass has had its fragments in registers since its barrier.
+  auto load_patch = [&](size_t img) {
+    const T* xi = (const T*)a.x + img * a.xC + a.x_base;
+    constexpr int kItems = kDcNPIX * 8, kRounds = (kItems + kDcThreads - 1) / kDcThreads;
+    u32x4 v[kRounds];
 #pragma unroll
-  for (int i = 0; i < kDcAhead; ++i) issue_next();
-
-  // ---- resident patch: groups 0, 1 from the block input (zeros outside the image), zero halo ring for the groups to come ----
-  {
-    const T* xi = (const T*)a.x + (size_t)n * ipix * a.xC + a.x_base;
-    for (int item = tid; item < kDcNPIX * 8; item += 512) {
+    for (int r = 0; r < kRounds; ++r) {
+      const int item = tid + r * kDcThreads;
       const int pix = item >> 3, g = (item >> 2) & 1, slot = item & 3;
       const int prow = pix / kDcPC, pcol = pix - prow * kDcPC;
       const int gy = oy0 - 1 + prow, gx = ox0 - 1 + pcol;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4*)(xi + ((size_t)(gy * a.W + gx) * a.x_ps + (size_t)g * a.x_cs + slot * 8));
-      *(u32x4*)(patch + g * kDcGroupBytes + dc_pos(prow, pcol, slot)) = v;
+      v[r] = u32x4{0u, 0u, 0u, 0u};
+      if (item < kItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v[r] = *(const u32x4*)(xi + ((size_t)(gy * a.W + gx) * a.x_ps + (size_t)g * a.x_cs + slot * 8));
     }
-    for (int item = tid; item < 84 * 16; item += 512) {
-      const int hp = item >> 4, g = 2 + ((item >> 2) & 3), slot = item & 3;
-      const int prow = hp < 34 ? 0 : (hp < 68 ? 9 : (hp < 76 ? 1 + hp - 68 : 1 + hp - 76));
-      const int pcol = hp < 34 ? hp : (hp < 68 ? hp - 34 : (hp < 76 ? 0 : 33));
-      *(u32x4*)(patch + g * kDcGroupBytes + dc_pos(prow, pcol, slot)) = u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-
-  // fragment address terms of this lane: the three kernel columns (pixel 16 ph + l15 + kx of the patch row), channel slot g4
-  int colt[3];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) { const int col = 16 * ph + l15 + kx; colt[kx] = col * 64 + ((g4 ^ (((col >> 2) & 1) << 1)) << 4); }
-  const int rowoff = (2 * rp) * kDcPC * 64;
-
-  // hand-off of growth layer `gl`'s output (group gd, tensor y of that layer): wait for the neighbours, read the 84 halo pixels
-  auto halo_in = [&](int gl) {
-    const DcLayer& P = a.L[gl];
-    if (wave == 0) {
-      const int j = lane < 8 ? lane : 0, q = j < 4 ? j : j + 1;         // the eight neighbours (3 x 3 without the centre)
-      const int dy = q / 3 - 1, dx = q % 3 - 1;
-      const bool valid = lane < 8 && ty + dy >= 0 && ty + dy < a.tiles_y && tx + dx >= 0 && tx + dx < a.tiles_x;
-      const int* f = a.flags + (size_t)gl * a.ntiles + (valid ? tile + dy * a.tiles_x + dx : tile);
-      for (int spins = 0;; ++spins) {
-        const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_ballot_w64(valid && v == 0) == 0ull) break;
-        if (spins > (1 << 22)) { if (lane == 0) atomicAdd(a.err, 1); break; }     // seconds: never in a correct run; wrong results, no hang
-        __builtin_amdgcn_s_sleep(4);
-      }
+    for (int r = 0; r < kRounds; ++r) {
+      const int item = tid + r * kDcThreads;
+      const int pix = item >> 3, g = (item >> 2) & 1, slot = item & 3;
+      const int prow = pix / kDcPC, pcol = pix - prow * kDcPC;
+      if (item < kItems) *(u32x4*)(patch + g * kDcGroupBytes + dc_pos(prow, pcol, slot)) = v[r];
     }
-    __syncthreads();
-    const T* yi = (const T*)P.y + (size_t)n * ipix * P.yC;
-    char* pg = patch + P.dst_group * kDcGroupBytes;
-    for (int item = tid; item < 84 * 8; item += 512) {
-      const int hp = item >> 3, piece = item & 7;
-      const int prow = hp < 34 ? 0 : (hp < 68 ? 9 : (hp < 76 ? 1 + hp - 68 : 1 + hp - 76));
-      const int pcol = hp < 34 ? hp : (hp < 68 ? hp - 34 : (hp < 76 ? 0 : 33));
-      const int gy = oy0 - 1 + prow, gx = ox0 - 1 + pcol;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const int cc = P.y_c0 + 4 * piece;
-        const dc_u64* src = (const dc_u64*)(yi + ((size_t)(gy * a.W + gx) * P.y_ps + (size_t)(cc >> 5) * P.y_gs + (cc & 31)));
-        const dc_u64 v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: served by L2 / memory, never a stale L1 line
-        *(dc_u64*)(pg + dc_pos(prow, pcol, piece >> 1) + 8 * (piece & 1)) = v;
-      }
+    for (int item = tid; item < kDcHaloItems * 4; item += kDcThreads) {
+      const int gg = item / kDcHaloItems, hi = item - gg * kDcHaloItems;
+      int prow, pcol; dc_halo_rc(hi >> 2, prow, pcol);
+      *(u32x4*)(patch + (2 + gg) * kDcGroupBytes + dc_pos(prow, pcol, hi & 3)) = u32x4{0u, 0u, 0u, 0u};
     }
-    // (the next step's barrier publishes these LDS writes; nobody has read this group yet)
   };
 
-  int t = 0;       // kernel-column steps consumed so far (all layers)
-  for (int l = 0; l < a.nLayers; ++l) {
-    const DcLayer& Ld = a.L[l];
-    const int nCh = Ld.nChunks;
-    f32x4_t acc[2][2];       // [row of the pair][16-channel half]
+  if (wave >= 4) {
+    // =====================================================  LOADER WAVES  =====================================================
+    // the weight stream: per kernel-column step this wave's three 1 KB pieces of the 6 KB slot, five steps ahead of the step that reads them
+    const int ld = wave - 4;               // pieces {0, 1, 2} / {3, 4, 5}: piece q = (kernel row q >> 1, channel half q & 1)
+    int pl = 0, pc = 0, pk = 0, pt = 0;    // producer cursor = the next step to request
+    auto issue_next = [&]() {
+      if (pt < totalSteps) {
+        const char* wl = a.L[pl].w + (size_t)((pc * 9 + pk) * 2048) + lane * 16;
+        const unsigned dst = dc_lds_addr(ring) + (unsigned)((pt % kDcSlots) * kDcSlot);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) acc[m][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    for (int c = 0; c < nCh; ++c) {
-      // the newest group (written by the previous growth layer) is read by this layer's last chunk only: take its halo in now
-      if (c == nCh - 1 && l > 0 && a.L[l - 1].dst_group == c && c >= 2 && !(a.dbg & 1)) halo_in(l - 1);
-      const char* pg = patch + c * kDcGroupBytes + rowoff;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        // this wave's piece of step t landed (at most three younger pieces of its own are in flight) ...
-        const int rem = a.totalSteps - 1 - t;
-        if (rem >= 3) dc_wait_vm<3>(); else if (rem == 2) dc_wait_vm<2>(); else if (rem == 1) dc_wait_vm<1>(); else dc_wait_vm<0>();
-        __syncthreads();      // ... and everybody's: slot t % 5 is complete, slot (t - 1) % 5 is free
-        issue_next();         // step t + 4 into it
-        const char* rs = ring + (t % kDcSlots) * kDcSlot + lane * 16;
-        Frag ap[4], bw[3][2];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ap[rr] = *(const Frag*)(pg + rr * kDcPC * 64 + colt[kx]);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int nh = 0; nh < 2; ++nh) bw[ky][nh] = *(const Frag*)(rs + (ky * 2 + nh) * 1024);
-        __builtin_amdgcn_s_setprio(1);
-        if (!(a.dbg & 8))
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m][nh] = mfma16<T>(bw[ky][nh], ap[m + ky], acc[m][nh]);
-        __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < 3; ++j) {
+          const int q = 3 * ld + j;
+          dc_glds16(wl + ((q >> 1) * 6144 + (q & 1) * 1024), dst + q * 1024);
+        }
+        ++pt;
+        if (++pk == 3) { pk = 0; if (++pc == a.L[pl].nChunks) { pc = 0; if (++pl == a.nLayers) pl = 0; } }
+      }
+    };
+#pragma unroll 1
+    for (int i = 0; i < kDcSlots; ++i) issue_next();        // steps 0 .. 4
+    int t = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      load_patch((size_t)(pass * a.ipl + li) * ipix);
+      if (pass == 0) dc_wait_pieces(3);       // slots 0 and 1 landed; later passes: the step barriers keep the ring two slots ahead
+      dc_barrier();
+#pragma unroll 1
+      for (int i = 0; i < a.stepsPerPass; ++i) {
+#ifdef SRGANFD_EXPERIMENT
+        unsigned long long l0_ = 0; if (stp && wave == 4) l0_ = now();
+#endif
+        dc_wait_pieces(totalSteps - 2 - t);   // this wave's pieces of step t + 1 have landed: only those of steps t + 2 .. t + 4 are younger
+#ifdef SRGANFD_EXPERIMENT
+        if (stp && wave == 4) { const unsigned long long l1_ = now(); if (lane == 0 && i < 78) stp[178 + i] = l1_ - l0_; }
+#endif
+        dc_barrier();                         // slot t + 1 is complete for everybody; slot t is free (its fragments are in registers)
+        issue_next();                         // step t + 5 into it
         ++t;
       }
     }
-
-    // ---- epilogue: lane = pixel 16 ph + l15 of rows 2 rp + m, channels 16 nh + 4 g4 .. + 3 ----
-    float alpha = Ld.alpha;
-    if (Ld.alpha_dev) alpha *= *Ld.alpha_dev;
-    const float ps_pos = Ld.post_scale, ps_neg = Ld.neg * Ld.post_scale;
-    const bool growth = Ld.dst_group >= 0;
-    const size_t img = (size_t)n * ipix;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int oy = oy0 + 2 * rp + m, ox = ox0 + 16 * ph + l15;
-      const bool ok = oy < a.H && ox < a.W;
-      const int p = oy * a.W + ox;
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        const int co = 16 * nh + 4 * g4;
-        float v4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = __builtin_fmaf(alpha, acc[m][nh][i], Ld.bias ? Ld.bias[co + i] : 0.f);
-          v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
-        }
-        auto widen4 = [](const dc_u32x2 q, float* f) {
-          if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
-            typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-            const h4 hv = __builtin_bit_cast(h4, q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = (float)hv[i];
-          } else {
-            f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
-            f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
-          }
-        };
-        auto ld = [&](const char* base, int Cs, int c0, int ps, int gs) -> dc_u32x2 {
-          const int cc = c0 + co;
-          return ok && !(a.dbg & 2) ? *(const dc_u32x2*)((const T*)base + img * Cs + ((size_t)p * ps + (size_t)(cc >> 5) * gs + (cc & 31))) : dc_u32x2{0u, 0u};
-        };
-        float t4[4];
-        if (Ld.r1) { widen4(ld(Ld.r1, Ld.r1C, Ld.r1_c0, Ld.r1_ps, Ld.r1_gs), t4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(Ld.r1s, t4[i], v4[i]); }
-        if (Ld.r2) { widen4(ld(Ld.r2, Ld.r2C, Ld.r2_c0, Ld.r2_ps, Ld.r2_gs), t4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(Ld.r2s, t4[i], v4[i]); }
-        if (Ld.mask) { widen4(ld(Ld.mask, Ld.mC, Ld.m_c0, Ld.m_ps, Ld.m_gs), t4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v4[i] *= t4[i] > 0.f ? 1.f : Ld.mask_slope; }
-        dc_u32x2 pk;
-        if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
-          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-          const h4 hv = {(_Float16)v4[0], (_Float16)v4[1], (_Float16)v4[2], (_Float16)v4[3]};
-          pk = __builtin_bit_cast(dc_u32x2, hv);
-        } else {
-          pk = dc_u32x2{(unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16), (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16)};
-        }
-        if (!ok) pk = dc_u32x2{0u, 0u};      // pixels beyond the image are zero padding for the layers that follow
-        if (growth) *(dc_u32x2*)(patch + Ld.dst_group * kDcGroupBytes + dc_pos(2 * rp + m + 1, 16 * ph + l15 + 1, 2 * nh + (g4 >> 1)) + 8 * (g4 & 1)) = pk;
-        if (ok && !(a.dbg & 2)) {
-          const int cc = Ld.y_c0 + co;
-          T* dst = (T*)Ld.y + img * Ld.yC + ((size_t)p * Ld.y_ps + (size_t)(cc >> 5) * Ld.y_gs + (cc & 31));
-          // growth layers: write-through (sc1), the neighbours read the halo from L2 / memory inside this launch
-          if (growth) __hip_atomic_store((dc_u64*)dst, __builtin_bit_cast(dc_u64, pk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *(dc_u32x2*)dst = pk;
-        }
+  } else {
+    // =====================================================  COMPUTE WAVES  =====================================================
+    const int cw = wave;                   // rows 4 cw .. 4 cw + 3 of the tile
+    // launch constants: epoch (polls and the publish use it), bias / alpha table
+    const int epoch = __hip_atomic_load(a.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    for (int l = 0; l < a.nLayers; ++l) {
+      if (cw == (l & 3)) {
+        if (lane < 32) ctl_bias[l * 32 + lane] = a.L[l].bias ? a.L[l].bias[lane] : 0.f;
+        if (lane == 32) ctl_alpha[l] = a.L[l].alpha * (a.L[l].alpha_dev ? *a.L[l].alpha_dev : 1.f);
       }
     }
-    if (growth) {
-      // every wave's stores are acknowledged, then ONE lane publishes the tile (this drain also retires the wave's weight pieces in
-      // flight, which keeps the counted waits above exact: nothing but weight pieces is ever outstanding inside a layer)
-      dc_wait_vm<0>();
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(a.flags + (size_t)l * a.ntiles + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      dc_wait_vm<0>();      // the epilogue's operand loads and stores are out of the vmcnt queue before the next layer counts it
+    const int rowoff = (4 * cw) * kDcPC * 64;
+    // this wave's share of a group's halo ring: items 68 cw .. 68 cw + 67 (item = 4 * halo pixel + 16-byte slot), two rounds of lanes
+    int h_off[2], h_gp[2], h_slot[2]; bool h_in[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int it = lane + 64 * r;
+      const int item = 68 * cw + (it < 68 ? it : 0);
+      int prow, pcol; dc_halo_rc(item >> 2, prow, pcol);
+      const int gy = oy0 - 1 + prow, gx = ox0 - 1 + pcol;
+      h_in[r] = it < 68 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      h_off[r] = dc_pos(prow, pcol, item & 3);
+      h_slot[r] = item & 3;
+      h_gp[r] = h_in[r] ? gy * a.W + gx : 0;          // lanes without an item read pixel 0 of the image (a valid address) and drop it
     }
+    char* const stage = smem + kDcStageOff + cw * kDcStageWave;        // this wave's hand-off staging: 68 halo items, then 64 flag words
+    const unsigned stage_lds = dc_lds_addr(stage);
+    // the eight neighbours (3 x 3 without the centre) of this tile, one per lane 0 .. 7
+    const int nq = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;
+    const int ndy = nq / 3 - 1, ndx = nq % 3 - 1;
+    const bool nvalid = lane < 8 && ty + ndy >= 0 && ty + ndy < a.tiles_y && tx + ndx >= 0 && tx + ndx < a.tiles_x;
+    const int noff = nvalid ? ndy * a.tiles_x + ndx : 0;
+
+    auto load_frags = [&](Frag* fw, Frag* fp, int c, int kx, int tt) {
+      // pixel l15 + kx of the patch row, channel slot g4 under the column-keyed swizzle (dc_pos), as arithmetic: no selects, no branches
+      const int col = l15 + kx;
+      const char* pa = patch + c * kDcGroupBytes + rowoff + (col << 6) + ((g4 ^ ((col >> 1) & 2)) << 4);
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) fp[rr] = *(const Frag*)(pa + rr * (kDcPC * 64));
+      const char* rs = ring + (tt % kDcSlots) * kDcSlot + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) fw[q] = *(const Frag*)(rs + q * 1024);
+    };
+
+    __builtin_amdgcn_s_setprio(2);
+    int t = 0;        // kernel-column steps consumed so far (all passes): ring slot t % 6
+    int giveups = 0;
+    const int orow0 = oy0 + 4 * cw, ocol = ox0 + l15;
+    const bool col_ok = ocol < a.W;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      const int n = pass * a.ipl + li;
+      const size_t img = (size_t)n * ipix;
+      const int gtile = n * a.tpi + tin;
+      load_patch(img);
+      dc_barrier();
+      DC_STAMP(1);
+      Frag Aw[6], Ap[6], Bw[6], Bp[6];       // two fragment sets: a step computes on one while the next step's are read into the other
+      load_frags(Aw, Ap, 0, 0, t);
+
+#pragma unroll 1
+      for (int l = 0; l < a.nLayers; ++l) {
+        const DcLayer& Ld = a.L[l];
+        const int nCh = Ld.nChunks, ns = 3 * nCh;
+        const bool prev_growth = l > 0 && a.L[l - 1].dst_group >= 0;
+        // hand-off of the previous layer's output (group nCh - 1, first read by the fragments requested behind barrier 3 (nCh - 1) - 1): three
+        // dependent round trips of 1.5-2.5k cycles (store acknowledgement, flag visible + poll, halo read) beside steps of ~650 cycles.
+        // Stores drained behind barrier 1, flag published behind barrier 2, neighbours' flags requested behind barrier s_poll (a poll right
+        // after the publish always reads the old value: everybody publishes at the same time), looked at and halo requested behind barrier
+        // s_chk, halo moved from the staging area into the patch behind barrier s_wr (visible behind barrier s_wr + 1 <= 3 (nCh - 1) - 1).
+        // conv2 (3 chunks) has no room for that: it waits at step 4; from conv4 on everything is hidden.
+        const int s_poll = nCh <= 4 ? 3 : nCh - 1, s_chk = nCh == 3 ? 4 : 2 * nCh - 3, s_wr = nCh == 3 ? 4 : 3 * nCh - 5;
+        const bool growth = Ld.dst_group >= 0;
+        f32x4_t acc[4][2];       // [row][16-channel half]
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) acc[m][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // epilogue operands of this lane's 4 pixels x 2 channel quads, requested behind barrier 1: slot A = r1 or mask, slot B = r2
+        dc_u32x2 eA[4][2], eB[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) { eA[m][nh] = dc_u32x2{0u, 0u}; eB[m][nh] = dc_u32x2{0u, 0u}; }
+        T* ydst = nullptr;       // this lane's first output element (row 4 cw, channels 4 g4 ..), set behind barrier 1
+        int yrow = 0;            // elements per image row of the output
+        DC_STAMP(2 + 8 * l);
+#ifdef SRGANFD_EXPERIMENT
+        unsigned long long wait_acc = 0, spin_acc = 0;
+#endif
+
+        // the rare steps: everything that is not "barrier, 12 fragment reads, 24 MFMAs" lives here, out of the step's straight line.
+        // The hand-off's loads are LDS-DMA into this wave's staging area: nothing of them lives in registers between steps.
+        auto event = [&](int s) {
+          if (s == 1) {
+            if (prev_growth) dc_wait_vm<0>();      // the previous layer's write-through stores are acknowledged (issued more than a step ago)
+            // output address and epilogue operands (residuals, mask) of this lane: in registers long before the epilogue
+            // (channel offsets are multiples of 32, checked on the host: the second channel half is 16 elements on)
+            const int p0 = col_ok && orow0 < a.H ? orow0 * a.W + ocol : 0;       // a lane without an output pixel reads pixel 0 (a valid address) and drops it
+            ydst = (T*)Ld.y + img * Ld.yC + ((size_t)p0 * Ld.y_ps + (size_t)(Ld.y_c0 >> 5) * Ld.y_gs + 4 * g4);
+            yrow = a.W * Ld.y_ps;
+            const char* opA = Ld.r1 ? Ld.r1 : Ld.mask;
+            if (opA) {
+              const int aC = Ld.r1 ? Ld.r1C : Ld.mC, a_c0 = Ld.r1 ? Ld.r1_c0 : Ld.m_c0, a_ps = Ld.r1 ? Ld.r1_ps : Ld.m_ps, a_gs = Ld.r1 ? Ld.r1_gs : Ld.m_gs;
+              const T* pa = (const T*)opA + img * aC + ((size_t)p0 * a_ps + (size_t)(a_c0 >> 5) * a_gs + 4 * g4);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const T* pm = orow0 + m < a.H ? pa + (size_t)m * a.W * a_ps : pa;
+                eA[m][0] = *(const dc_u32x2*)pm; eA[m][1] = *(const dc_u32x2*)(pm + 16);
+              }
+            }
+            if (Ld.r2) {
+              const T* pb = (const T*)Ld.r2 + img * Ld.r2C + ((size_t)p0 * Ld.r2_ps + (size_t)(Ld.r2_c0 >> 5) * Ld.r2_gs + 4 * g4);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const T* pm = orow0 + m < a.H ? pb + (size_t)m * a.W * Ld.r2_ps : pb;
+                eB[m][0] = *(const dc_u32x2*)pm; eB[m][1] = *(const dc_u32x2*)(pm + 16);
+              }
+            }
+          } else if (s == 2) {
+            // every compute wave's stores of layer l - 1 are acknowledged (vmcnt(0) behind barrier 1, then barrier 2): ONE lane publishes
+            // the tile.  Behind barrier s_poll every wave asks for its neighbours' flags (lane j < 8: neighbour j; the other lanes read this tile's own word)
+            if (cw == 0 && lane == 0) __hip_atomic_store(a.flags + (size_t)(l - 1) * a.totalTiles + gtile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (s == s_poll) {
+            dc_glds4_sc1(a.flags + (size_t)(l - 1) * a.totalTiles + gtile + noff, stage_lds + kDcStageHalo);
+          } else if (s == s_chk) {
+            const DcLayer& P = a.L[l - 1];
+#ifdef SRGANFD_EXPERIMENT
+            unsigned long long s0_ = 0; if (stp && wave == 0) s0_ = now();
+#endif
+            // all neighbours have published?  (normally yes at the first look: they run the same schedule)
+            for (int spins = 0;; ++spins) {
+              dc_wait_vm<0>();
+              const int pv = *(const volatile __attribute__((address_space(3))) int*)(stage_lds + kDcStageHalo + 4 * lane);
+              if (__builtin_amdgcn_ballot_w64(nvalid && pv != epoch) == 0ull) break;
+              if (spins > (1 << 21)) { ++giveups; break; }      // seconds: never in a correct run; wrong results, no hang
+              __builtin_amdgcn_s_sleep(2);
+              dc_glds4_sc1(a.flags + (size_t)(l - 1) * a.totalTiles + gtile + noff, stage_lds + kDcStageHalo);
+            }
+#ifdef SRGANFD_EXPERIMENT
+            if (stp && wave == 0) spin_acc += now() - s0_;
+#endif
+            // this wave's 68 halo items of the previous layer's output: 16 bytes per lane, lanes 0 .. 63 and 0 .. 3
+            const T* yi = (const T*)P.y + img * P.yC;
+            {
+              const int cc = P.y_c0 + 8 * h_slot[0];
+              dc_glds16_sc1(yi + ((size_t)h_gp[0] * P.y_ps + (size_t)(cc >> 5) * P.y_gs + (cc & 31)), stage_lds);
+            }
+            if (lane < 4) {
+              const int cc = P.y_c0 + 8 * h_slot[1];
+              dc_glds16_sc1(yi + ((size_t)h_gp[1] * P.y_ps + (size_t)(cc >> 5) * P.y_gs + (cc & 31)), stage_lds + 1024);
+            }
+          }
+          if (prev_growth && s == s_wr) {
+            dc_wait_vm<0>();       // the halo items have landed in the staging area
+            char* pg = patch + a.L[l - 1].dst_group * kDcGroupBytes;
+            if (h_in[0]) *(u32x4*)(pg + h_off[0]) = *(const u32x4*)(stage + 16 * lane);
+            if (lane < 4 && h_in[1]) *(u32x4*)(pg + h_off[1]) = *(const u32x4*)(stage + 1024 + 16 * lane);
+          }
+        };
+
+        int c = 0, kx = 0;       // chunk and kernel column of the current step
+        int ev = 1;              // the next step with an event
+        // one kernel-column step: barrier (slot t + 1 is complete, everybody is past step t - 1), the next step's fragments into N* (the
+        // next layer's first step behind this layer's last: its chunk 0 is the block input), this step's 24 MFMAs on C*
+#ifdef SRGANFD_EXPERIMENT
+#define DC_W0 unsigned long long w0_ = 0; if (stp && wave == 0) w0_ = now();
+#define DC_W1 if (stp && wave == 0) { const unsigned long long w1_ = now(); wait_acc += w1_ - w0_; if (lane == 0) stp[100 + t - pass * a.stepsPerPass] = w1_; }
+#else
+#define DC_W0
+#define DC_W1
+#endif
+#define DC_STEP(S, CW, CP, NW, NP)                                                                                  \
+        {                                                                                                           \
+          DC_W0                                                                                                     \
+          dc_barrier();                                                                                             \
+          DC_W1                                                                                                     \
+          if (__builtin_expect((S) == ev, 0)) {                                                                     \
+            event(S);                                                                                               \
+            ev = !prev_growth ? -1 : ((S) == 1 ? 2 : ((S) == 2 ? s_poll : ((S) == s_poll ? s_chk : ((S) == s_chk && s_wr > s_chk ? s_wr : -1)))); \
+          }                                                                                                         \
+          const bool wrap_ = (S) + 1 == ns;                                                                         \
+          const int kxn_ = wrap_ || kx == 2 ? 0 : kx + 1, cn_ = wrap_ ? 0 : (kx == 2 ? c + 1 : c);                  \
+          load_frags(NW, NP, cn_, kxn_, t + 1);                                                                     \
+          _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                          \
+            _Pragma("unroll") for (int nh = 0; nh < 2; ++nh)                                                        \
+              _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
+          /* issue order: the NEXT step's 12 fragment reads spread over this step's first 16 MFMAs (the scheduler would otherwise sink   \
+             the reads to the end of the step to shorten their live ranges, and the next step would start by waiting for them) */ \
+          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+          }                                                                                                         \
+          _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+          }                                                                                                         \
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                        \
+          c = cn_; kx = kxn_;                                                                                       \
+          ++t;                                                                                                      \
+        }
+        int s = 0;
+#pragma unroll 1
+        for (; s + 1 < ns; s += 2) {
+          DC_STEP(s, Aw, Ap, Bw, Bp)
+          DC_STEP(s + 1, Bw, Bp, Aw, Ap)
+        }
+        if (s < ns) {      // 3 or 5 chunks: an odd number of steps -- the next layer starts on set A like every layer
+          DC_STEP(s, Aw, Ap, Bw, Bp)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { Aw[q] = Bw[q]; Ap[q] = Bp[q]; }
+        }
+#undef DC_STEP
+        DC_STAMP(2 + 8 * l + 2);
+#ifdef SRGANFD_EXPERIMENT
+        if (stp && tid == 0) { stp[2 + 8 * l + 4] = wait_acc; stp[2 + 8 * l + 1] = spin_acc; }
+#endif
+
+        // ---- epilogue: lane = pixel l15 of rows 4 cw + m, channels 16 nh + 4 g4 .. + 3.  The operand combination is a compile-time
+        // kind (one switch per layer): OPS 0 none, 1 mask, 2 r1, 3 r1 + r2; GROWTH: also group dst_group of the patch, write-through store ----
+        const float alpha = ctl_alpha[l];
+        const float ps_pos = Ld.post_scale, ps_neg = Ld.neg * Ld.post_scale;
+        const float r1s = Ld.r1s, r2s = Ld.r2s, mslope = Ld.mask_slope;
+        const f32x4_t b0 = *(const f32x4_t*)(ctl_bias + l * 32 + 4 * g4), b1 = *(const f32x4_t*)(ctl_bias + l * 32 + 16 + 4 * g4);
+        char* const lds_out = patch + (growth ? Ld.dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, g4 >> 1) + 8 * (g4 & 1);
+        const int nh_off = (((l15 + 1) >> 1) & 2) ? -32 : 32;      // second channel half: 16-byte slot + 2 under dc_pos's column key (slot ^ 2: two slots up or down)
+        auto epilogue = [&](auto growth_c, auto ops_c) {
+          constexpr bool GROWTH = decltype(growth_c)::v != 0;
+          constexpr int OPS = decltype(ops_c)::v;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const bool ok = col_ok && orow0 + m < a.H;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              float v4[4], t4[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float v = __builtin_fmaf(alpha, acc[m][nh][i], nh ? b1[i] : b0[i]);
+                v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
+              }
+              if constexpr (OPS >= 2) { dc_widen4<T>(eA[m][nh], t4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(r1s, t4[i], v4[i]); }
+              if constexpr (OPS == 3) { dc_widen4<T>(eB[m][nh], t4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(r2s, t4[i], v4[i]); }
+              if constexpr (OPS == 1) { dc_widen4<T>(eA[m][nh], t4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v4[i] *= t4[i] > 0.f ? 1.f : mslope; }
+              dc_u32x2 pk = dc_narrow4<T>(v4);
+              if (!ok) pk = dc_u32x2{0u, 0u};      // pixels beyond the image are zero padding for the layers that follow
+              if constexpr (GROWTH) *(dc_u32x2*)(lds_out + m * (kDcPC * 64) + nh * nh_off) = pk;
+              if (ok) {
+                T* dst = ydst + (size_t)m * yrow + 16 * nh;
+                // growth layers: write-through (sc1), the neighbours read the halo from memory inside this launch
+                if constexpr (GROWTH) __hip_atomic_store((dc_u64*)dst, __builtin_bit_cast(dc_u64, pk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *(dc_u32x2*)dst = pk;
+              }
+            }
+          }
+        };
+        const int ops_kind = Ld.r1 ? (Ld.r2 ? 3 : 2) : (Ld.mask ? 1 : 0);
+        switch ((growth ? 4 : 0) + ops_kind) {
+          case 0: epilogue(IC<0>{}, IC<0>{}); break;
+          case 1: epilogue(IC<0>{}, IC<1>{}); break;
+          case 2: epilogue(IC<0>{}, IC<2>{}); break;
+          case 3: epilogue(IC<0>{}, IC<3>{}); break;
+          case 4: epilogue(IC<1>{}, IC<0>{}); break;
+          case 5: epilogue(IC<1>{}, IC<1>{}); break;
+          case 6: epilogue(IC<1>{}, IC<2>{}); break;
+          default: epilogue(IC<1>{}, IC<3>{}); break;
+        }
+        DC_STAMP(2 + 8 * l + 3);
+      }
+    }
+    if (giveups && lane == 0) atomicAdd(a.hdr, giveups);
+  }
+  DC_STAMP(60);
+#ifdef SRGANFD_EXPERIMENT
+  if (stp && wave == 0) { const unsigned long long t_ = rnow(); if (lane == 0) stp[62] = t_; }
+#endif
+  // ---- the last workgroup to finish advances the epoch for the next launch on the stream ----
+  if (tid == 0) {
+    const int done = atomicAdd(a.hdr + 2, 1);
+    if (done == (int)gridDim.x - 1) { atomicExch(a.hdr + 2, 0); atomicAdd(a.hdr + 1, 1); }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-size_t dense_chain_workspace_bytes_impl() { return 64 + sizeof(int) * 4 * 1024; }      // [err, pad] + flags of 4 growth layers x <= 1024 tiles
+#ifdef SRGANFD_EXPERIMENT
+size_t dense_chain_workspace_bytes_impl() { return 64 + sizeof(int) * 4 * kDcMaxTiles + 8 * 256 * 1024; }      // + stamps
+#else
+size_t dense_chain_workspace_bytes_impl() { return 64 + sizeof(int) * 4 * kDcMaxTiles; }      // header + flags of 4 growth layers x tiles of one call
+#endif
 
-// Validates that `layers` are the convs of one dense chain and fills the kernel arguments for images [0, n) at image 0's bases.
+// Validates that `layers` are the convs of one dense chain and fills the kernel arguments at image 0's bases.
 static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
   if (!layers || n < 2 || n > 5) return set_err(SRGANFD_EINVAL, "dense_chain: 2..5 layers");
   memset(&K, 0, sizeof(K));
@@ -318,6 +574,9 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
         a.n != a0.n || a.h_in != a0.h_in || a.w_in != a0.w_in || a.x.ptr != a0.x.ptr || a.x.c0 != a0.x.c0 || a.x.cstride != a0.x.cstride || a.x.planar != a0.x.planar ||
         a.cin != 64 + 32 * i || a.cout != (last ? 64 : 32) || a.cout_store != a.cout || !k.fast_epi)
       return set_err(SRGANFD_EINVAL, "dense_chain: layer %d is not conv %d of a dense block (3x3 stride 1, %d -> %d channels over one buffer)", i, i + 1, 64 + 32 * i, last ? 64 : 32);
+    if ((k.y_c0 | k.r1_c0 | k.r2_c0 | k.m_c0) & 31) return set_err(SRGANFD_EINVAL, "dense_chain: layer %d: channel offsets must be multiples of 32", i);
+    if (a.r2.ptr && !a.r1.ptr) return set_err(SRGANFD_EINVAL, "dense_chain: layer %d has r2 without r1", i);
+    if (a.mask.ptr && (a.r1.ptr || a.r2.ptr)) return set_err(SRGANFD_EINVAL, "dense_chain: layer %d has a mask and residuals (the epilogue keeps two operands)", i);
     if (!last && (a.y.ptr != a0.x.ptr || a.y.c0 != a0.x.c0 + a.cin || a.y.cstride != a0.x.cstride || a.y.planar != a0.x.planar))
       return set_err(SRGANFD_EINVAL, "dense_chain: layer %d must write channels [%d, %d) of the buffer it reads", i, a.cin, a.cin + 32);
     if (i == 0) { K.x = (const char*)a.x.ptr; K.xC = k.xC; K.x_ps = k.x_ps; K.x_base = k.x_base; K.x_cs = k.x_cs; }
@@ -338,37 +597,40 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
       steps += 3 * k.nChunks;
     }
   }
-  K.nLayers = nl; K.totalSteps = steps;
+  K.nLayers = nl; K.stepsPerPass = steps;
   K.N = a0.n; K.H = a0.h_in; K.W = a0.w_in;
-  K.tiles_x = ceil_div(K.W, 32); K.tiles_y = ceil_div(K.H, 8);
+  K.tiles_x = ceil_div(K.W, kDcT); K.tiles_y = ceil_div(K.H, kDcT);
+  K.tpi = K.tiles_x * K.tiles_y;
+  K.totalTiles = K.N * K.tpi;
+  const int cus = conv_device_cus();
+  K.ipl = K.tpi > cus ? 0 : (cus / K.tpi < K.N ? cus / K.tpi : K.N);      // every tile of a pass must be resident at once (one workgroup per CU)
   return SRGANFD_OK;
 }
 
-// images per launch: every tile of a launch must be resident at once (one workgroup per CU)
-static int dense_chain_images_per_launch(const DcK& K) {
-  const int per = K.tiles_x * K.tiles_y, cus = conv_device_cus();
-  return per > cus || per > 1024 ? 0 : (cus / per < K.N ? cus / per : K.N);
+static int dense_chain_limits(const DcK& K) {
+  if (K.ipl < 1) return set_err(SRGANFD_EINVAL, "dense_chain: one image is %d tiles of 16 x 16, more than the device has CUs", K.tpi);
+  if (K.totalTiles > kDcMaxTiles) return set_err(SRGANFD_EINVAL, "dense_chain: %d tiles in one call (limit %d)", K.totalTiles, kDcMaxTiles);
+  return SRGANFD_OK;
 }
 
 int dense_chain_check_impl(const srganfd_conv_args* layers, int n) {
   DcK K;
   const int rc = dense_chain_fill(layers, n, K);
-  if (rc != SRGANFD_OK) return rc;
-  if (dense_chain_images_per_launch(K) < 1) return set_err(SRGANFD_EINVAL, "dense_chain: one image is %d tiles of 8 x 32, more than the device has CUs", K.tiles_x * K.tiles_y);
-  return SRGANFD_OK;
+  return rc != SRGANFD_OK ? rc : dense_chain_limits(K);
 }
 
 int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DcK K;
   int rc = dense_chain_fill(layers, n, K);
   if (rc != SRGANFD_OK) return rc;
-  const int ipl = dense_chain_images_per_launch(K);
-  if (ipl < 1) return set_err(SRGANFD_EINVAL, "dense_chain: one image is %d tiles of 8 x 32, more than the device has CUs", K.tiles_x * K.tiles_y);
+  if ((rc = dense_chain_limits(K)) != SRGANFD_OK) return rc;
   if (!workspace || workspace_bytes < dense_chain_workspace_bytes_impl()) return set_err(SRGANFD_ENOSPC, "dense_chain: workspace too small");
   if (g_describe) { snprintf(g_describe, g_describe_len, "dense_chain_kernel<%s,%d layers>", layers[0].dtype == SRGANFD_F16 ? "f16" : "bf16", n); return SRGANFD_OK; }
-  K.err = (int*)workspace;
-  { const char* e = getenv("SRGANFD_DC_DBG"); K.dbg = e ? atoi(e) : 0; }
+  K.hdr = (int*)workspace;
   K.flags = (int*)((char*)workspace + 64);
+#ifdef SRGANFD_EXPERIMENT
+  K.stamps = getenv("SRGANFD_DC_STAMPS") ? (unsigned long long*)((char*)workspace + 64 + sizeof(int) * 4 * kDcMaxTiles) : nullptr;
+#endif
   const bool f16 = layers[0].dtype == SRGANFD_F16;
   static unsigned long long attr_done[2] = {0, 0};
   if (!g_dry_run) {
@@ -380,25 +642,10 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
       attr_done[f16] |= 1ULL << (dev & 63);
     }
   }
-  const size_t ipix = (size_t)K.H * K.W, esz = 2;
-  const int Ntot = K.N;
-  for (int n0 = 0; n0 < Ntot; n0 += ipl) {
-    DcK S = K;
-    S.N = Ntot - n0 < ipl ? Ntot - n0 : ipl;
-    S.ntiles = S.N * K.tiles_x * K.tiles_y;
-    S.x = K.x + (size_t)n0 * ipix * K.xC * esz;
-    for (int i = 0; i < K.nLayers; ++i) {
-      DcLayer& L = S.L[i];
-      L.y += (size_t)n0 * ipix * L.yC * esz;
-      if (L.r1) L.r1 += (size_t)n0 * ipix * L.r1C * esz;
-      if (L.r2) L.r2 += (size_t)n0 * ipix * L.r2C * esz;
-      if (L.mask) L.mask += (size_t)n0 * ipix * L.mC * esz;
-    }
-    if (!g_dry_run && !(S.dbg & 4)) SRGANFD_HIP_CHECK(hipMemsetAsync(S.flags, 0, sizeof(int) * 4 * (size_t)S.ntiles, stream));
-    if (f16) SRGANFD_LAUNCH(dense_chain_kernel<f16_t>, dim3((unsigned)S.ntiles), dim3(512), kDcLds, stream, S);
-    else SRGANFD_LAUNCH(dense_chain_kernel<bf16_t>, dim3((unsigned)S.ntiles), dim3(512), kDcLds, stream, S);
-    SRGANFD_HIP_CHECK(hipGetLastError());
-  }
+  const unsigned grid = (unsigned)(K.ipl * K.tpi);
+  if (f16) SRGANFD_LAUNCH(dense_chain_kernel<f16_t>, dim3(grid), dim3(kDcThreads), kDcLds, stream, K);
+  else SRGANFD_LAUNCH(dense_chain_kernel<bf16_t>, dim3(grid), dim3(kDcThreads), kDcLds, stream, K);
+  SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
 

@@ -330,14 +330,17 @@ class TrunkEngine:
                 fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
         for i, pre in enumerate(self._rdb_prefix):
             ci = catb(i)
+            blk = []
             for k in range(1, 5):
-                fw.append(ops.conv_args(dtc, VC(ci), VC(ci, c0=Cc + (k - 1) * G), wptr + pk["offs"][("f", i, k)], N, H, W, Cc + (k - 1) * G, G,
-                                        bias=bias(f"{pre}conv{k}.bias"), act=A.ACT_LRELU, slope=0.2))
+                blk.append(ops.conv_args(dtc, VC(ci), VC(ci, c0=Cc + (k - 1) * G), wptr + pk["offs"][("f", i, k)], N, H, W, Cc + (k - 1) * G, G,
+                                         bias=bias(f"{pre}conv{k}.bias"), act=A.ACT_LRELU, slope=0.2))
             last = self.rrdb and i % 3 == 2
             kw = dict(post_scale=0.04, r1=VC(ci), r1_scale=0.2, r2=VC(catb(i - 2)), r2_scale=1.0) if last else \
                 dict(post_scale=0.2, r1=VC(ci), r1_scale=1.0)
-            fw.append(ops.conv_args(dtc, VC(ci), VC(catb(i + 1)), wptr + pk["offs"][("f", i, 5)], N, H, W, Ccat, Cc,
-                                    bias=bias(f"{pre}conv5.bias"), **kw))
+            blk.append(ops.conv_args(dtc, VC(ci), VC(catb(i + 1)), wptr + pk["offs"][("f", i, 5)], N, H, W, Ccat, Cc,
+                                     bias=bias(f"{pre}conv5.bias"), **kw))
+            # small batches (the reference's own crop sizes): the five launches as ONE LDS-resident launch (csrc/dense_chain.hip)
+            fw.extend(ops.dense_chain_or_launches(blk, device) if (Cc, G) == (64, 32) else blk)
         if self.full:
             tout = catb(R)
             fw.append(ops.conv_args(dtc, VC(tout), V(sp.f0), wptr + pk["offs"][("f", "conv2")], N, H, W, Cc, Cc, bias=bias("conv2.bias"),
@@ -467,20 +470,26 @@ class TrunkEngine:
                                       dw_off=self._poff(pre + f"conv{k}.weight") - base, db_off=self._poff(pre + f"conv{k}.bias") - base,
                                       co_dst=cout, ci_dst=cin, alpha=(s5 if k == 5 else 1.0)))
                 plans[s5] = wplan(N, H, W, Ccat, Ccat, convs)
+            blk = []
             for step in range(4):
                 kdim = Cc + step * G
-                bw.append(("conv", ops.conv_args(dtc, VD(di), VD(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
-                                                 mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2)))
-            bw.append(("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight"), i))     # 6th field: dense block (batched reduction)
-            if self.full and R >= 4 and i == R // 2:      # upper half of the trunk is final: second bucket
-                bw.append(("ready", self._poff(pre + "conv1.weight"), self._poff("conv2.weight")))
+                blk.append(ops.conv_args(dtc, VD(di), VD(di, c0=Cc + step * G), wptr + pk["offs"][("b", i, step)], N, H, W, kdim, G,
+                                         mask=VC(ci, c0=Cc + (3 - step) * G), mask_slope=0.2))
             dst = VD(dyb(i - 1)) if i > 0 else V(sp.dx0)
-            if i > 0:
-                bw.append(("fence", i + 3))     # dst is the buffer block i + 3's weight gradient read (side-stream mode, see backward())
             kw = dict(r1=VD(di), r1_scale=s_out)
             if first:
                 kw.update(r2=VD(dyb(i + 2)), r2_scale=1.0)
-            bw.append(("conv", ops.conv_args(dtc, VD(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw)))
+            blk.append(ops.conv_args(dtc, VD(di), dst, wptr + pk["offs"][("b", i, 4)], N, H, W, Ccat, Cc, **kw))
+            chain = ops.dense_chain_or_launches(blk, sp.device) if (Cc, G) == (64, 32) else blk
+            wg = ("wgrad", plans[s5], VC(ci), VD(di), self._poff(pre + "conv1.weight"), i)     # 6th field: dense block (batched reduction)
+            fence = [("fence", i + 3)] if i > 0 else []     # dst is the buffer block i + 3's weight gradient read (side-stream mode, see backward())
+            ready = [("ready", self._poff(pre + "conv1.weight"), self._poff("conv2.weight"))] if self.full and R >= 4 and i == R // 2 else []     # upper half of the trunk is final: second bucket
+            if len(chain) == 1:
+                # one launch for the five data-gradient convs (it writes dst, so the fence comes first); the weight gradient reads what
+                # the chain's four growth layers wrote and follows it
+                bw.extend(fence + [("chain", chain[0]), wg] + ready)
+            else:
+                bw.extend([("conv", a_) for a_ in blk[:4]] + [wg] + ready + fence + [("conv", blk[4])])
         if self.full:
             bw.append(("call", (lambda x=V(sp.d_f0), y=V(sp.dx0): A.check(
                 A.lib().srganfd_axpby(x, y, dtc, N * H * W, Cc, 1.0, 1.0, A.stream_ptr()), "axpby"))))
@@ -516,10 +525,10 @@ class TrunkEngine:
         else:
             A.check(L.srganfd_nchw_to_nhwc(x.data_ptr(), N, self.Cc, H, W, A.view(sp.catb(0)), dtc, self.Cc, None, None, st), "nchw_to_nhwc")
         rec = profiling.REC
-        Thin = ops.ThinLaunch
+        Thin, Chain = ops.ThinLaunch, ops.DenseChain
         if rec is None:
             for a in sp.fw:
-                if type(a) is Thin:
+                if type(a) is Thin or type(a) is Chain:
                     a.run()
                     continue
                 rc = L.srganfd_conv2d(C.byref(a), st)
@@ -527,7 +536,7 @@ class TrunkEngine:
                     A.check(rc, "conv2d")
         else:
             for a in sp.fw:
-                if type(a) is Thin:
+                if type(a) is Thin or type(a) is Chain:
                     a.launch(rec)
                     continue
                 rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d"))
@@ -601,6 +610,8 @@ class TrunkEngine:
                 else:
                     a = item[1]
                     rec.bracket(profiling.conv_label(a), profiling.conv_work(a), lambda: A.check(L.srganfd_conv2d(C.byref(a), st), "conv2d(dgrad)"))
+            elif kind == "chain":
+                item[1].launch(rec)
             elif kind == "wgrad":
                 plan, xv, dyv, goff = item[1:5]
                 if len(item) > 5 and sp.wg_ws4 is not None:

@@ -130,12 +130,12 @@ def dense_chain_workspace(device) -> torch.Tensor:
 
 
 def dense_chain_wanted(n: int, h: int, w: int, cus: int = 256) -> bool:
-    """the regime the launch is built for: an image is at most one 8 x 32 tile per CU, and the batch needs few passes (each pass holds
-    cus // tiles images); above that the per-layer kernels are bandwidth- or MFMA-bound and the resident tile has nothing to win"""
+    """the launch needs every 16 x 16 tile of a pass resident at once (one workgroup per CU, cus // tiles images per pass) and keeps
+    one flag per growth layer and tile of the call; "auto" takes it where it measured faster than the five launches"""
     if DENSE_CHAIN == "0":
         return False
-    per = -(-h // 8) * -(-w // 32)
-    if per > cus:
+    per = -(-h // 16) * -(-w // 16)
+    if per > cus or n * per > 16384:
         return False
     return DENSE_CHAIN == "1" or n * per <= 2 * cus
 
@@ -153,14 +153,34 @@ class DenseChain:
         self.ok = A.lib().srganfd_dense_chain_check(self.arr, self.n) == 0
         self.ws = dense_chain_workspace(device) if self.ok else None
         self.flops = sum(2.0 * a.n * a.h_out * a.w_out * 9 * a.cin * a.cout for a in layers)
-        self.bytes = 0.0
+        # algorithmic bytes of the launch: the block input read once, every layer's output written once, the epilogue operands read once
+        es, px = 2, layers[0].n * layers[0].h_out * layers[0].w_out
+        self.bytes = float(px * es * (layers[0].cin + sum(a.cout * (1 + bool(a.r1.ptr) + bool(a.r2.ptr) + bool(a.mask.ptr)) for a in layers)))
+        self.label = "dense_chain_kernel<%s,%d layers%s>" % (A.DT_NAME[layers[0].dtype], self.n, ",mask" if layers[0].mask.ptr else "")
+        self.work = (self.flops, self.bytes)
 
     def run(self) -> None:
         A.check(A.lib().srganfd_dense_chain(self.arr, self.n, self.ws.data_ptr(), self.ws.numel(), A.stream_ptr()), "dense_chain")
 
+    def launch(self, rec=None) -> None:
+        if rec is None:
+            self.run()
+        else:
+            rec.bracket(self.label, self.work, self.run)
+
     def errors(self) -> int:
         """hand-off waits that gave up since the workspace was allocated (synchronises; tests)"""
         return int(self.ws[:4].view(torch.int32).item())
+
+
+def dense_chain_or_launches(layers: Sequence[A.ConvArgs], device) -> list:
+    """[DenseChain] when the batch is in the chain's regime and the library accepts the launches, else the launches themselves"""
+    a = layers[0]
+    if a.dtype in (A.F16, A.BF16) and dense_chain_wanted(a.n, a.h_in, a.w_in):
+        ch = DenseChain(layers, device)
+        if ch.ok:
+            return [ch]
+    return list(layers)
 
 
 # ---- thin-side convolutions (csrc/conv_thin.hip): 1..4 channels against 64, 3x3 stride 1 pad 1, 16-bit dtypes ----
