@@ -140,6 +140,16 @@ __device__ __forceinline__ void dc_halo_rc(int hp, int& prow, int& pcol) {
 typedef unsigned long long dc_u64;
 typedef __attribute__((ext_vector_type(2))) unsigned int dc_u32x2;
 
+// v_mfma_f32_16x16x32 accumulating in place (vDst == SrcC).  Written as inline assembly because the compiler, with registers to spare,
+// picks vDst != SrcC for the builtin in this kernel, and that form issues every 20-24 cycles instead of 16.4
+// (tools/probes/mfma_issue_probe.hip, profiles/r05_mfma_issue_probe.txt); conv_igemm.hip / wgrad.hip get the in-place form from the builtin.
+template <typename T> __device__ __forceinline__ void dc_mfma16_inplace(f32x4_t& c, const typename FragAB<T>::type& a, const typename FragAB<T>::type& b);
+template <> __device__ __forceinline__ void dc_mfma16_inplace<f16_t>(f32x4_t& c, const f16x8& a, const f16x8& b) {
+  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void dc_mfma16_inplace<bf16_t>(f32x4_t& c, const bf16x8& a, const bf16x8& b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 template <typename T> __device__ __forceinline__ void dc_widen4(const dc_u32x2 q, float* f) {
   if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
     typedef __attribute__((ext_vector_type(4))) _Float16 h4;
@@ -265,10 +275,21 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
     const int cw = wave;                   // rows 4 cw .. 4 cw + 3 of the tile
     // launch constants: epoch (polls and the publish use it), bias / alpha table
     const int epoch = __hip_atomic_load(a.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    for (int l = 0; l < a.nLayers; ++l) {
-      if (cw == (l & 3)) {
-        if (lane < 32) ctl_bias[l * 32 + lane] = a.L[l].bias ? a.L[l].bias[lane] : 0.f;
-        if (lane == 32) ctl_alpha[l] = a.L[l].alpha * (a.L[l].alpha_dev ? *a.L[l].alpha_dev : 1.f);
+    {
+      // all six layers' loads first, then the LDS writes: one memory round trip instead of one per layer
+      float bv[kDcMaxLayers], av[kDcMaxLayers];
+#pragma unroll
+      for (int l = 0; l < kDcMaxLayers; ++l) {
+        const bool mine = l < a.nLayers && cw == (l & 3);
+        bv[l] = mine && lane < 32 && a.L[l].bias ? a.L[l].bias[lane] : 0.f;
+        av[l] = mine && lane == 32 && a.L[l].alpha_dev ? *a.L[l].alpha_dev : 1.f;
+      }
+#pragma unroll
+      for (int l = 0; l < kDcMaxLayers; ++l) {
+        if (l < a.nLayers && cw == (l & 3)) {
+          if (lane < 32) ctl_bias[l * 32 + lane] = bv[l];
+          if (lane == 32) ctl_alpha[l] = a.L[l].alpha * av[l];
+        }
       }
     }
     const int rowoff = (4 * cw) * kDcPC * 64;
@@ -443,21 +464,21 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           }                                                                                                         \
           const bool wrap_ = (S) + 1 == ns;                                                                         \
           const int kxn_ = wrap_ || kx == 2 ? 0 : kx + 1, cn_ = wrap_ ? 0 : (kx == 2 ? c + 1 : c);                  \
-          load_frags(NW, NP, cn_, kxn_, t + 1);                                                                     \
-          _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                          \
-            _Pragma("unroll") for (int nh = 0; nh < 2; ++nh)                                                        \
-              _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
-          /* issue order: the NEXT step's 12 fragment reads spread over this step's first 16 MFMAs (the scheduler would otherwise sink   \
-             the reads to the end of the step to shorten their live ranges, and the next step would start by waiting for them) */ \
-          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+          const int col_ = l15 + kxn_;                                                                              \
+          const char* pa_ = patch + cn_ * kDcGroupBytes + rowoff + (col_ << 6) + ((g4 ^ ((col_ >> 1) & 2)) << 4);   \
+          const char* rs_ = ring + ((t + 1) % kDcSlots) * kDcSlot + lane * 16;                                      \
+          /* 24 MFMAs that accumulate IN PLACE (vDst == SrcC: 16.4 cycles each; the form the compiler picked here, vDst != SrcC,   \
+             measured 20-24: profiles/r05_mfma_issue_probe.txt), the NEXT step's 12 fragment reads behind MFMAs 0-7, 9, 11, 13, 15; \
+             a scheduling barrier after every group keeps that order (the scheduler would otherwise sink the reads to the end of the \
+             step to shorten their live ranges, and the next step would start by waiting for them) */                \
+          _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                       \
+            const int ky_ = i_ >> 3, nh_ = (i_ >> 2) & 1, m_ = i_ & 3;                                              \
+            dc_mfma16_inplace<T>(acc[m_][nh_], CW[ky_ * 2 + nh_], CP[m_ + ky_]);                                    \
+            const int r_ = i_ < 8 ? i_ : ((i_ & 1) && i_ < 16 ? 8 + ((i_ - 9) >> 1) : -1);                          \
+            if (r_ >= 0 && r_ < 6) NP[r_] = *(const Frag*)(pa_ + r_ * (kDcPC * 64));                                \
+            if (r_ >= 6) NW[r_ - 6] = *(const Frag*)(rs_ + (r_ - 6) * 1024);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
           }                                                                                                         \
-          _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
-          }                                                                                                         \
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                        \
           c = cn_; kx = kxn_;                                                                                       \
           ++t;                                                                                                      \
         }
@@ -473,6 +494,9 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           for (int q = 0; q < 6; ++q) { Aw[q] = Bw[q]; Ap[q] = Bp[q]; }
         }
 #undef DC_STEP
+        // the MFMAs above are inline assembly: the compiler's hazard recognizer does not see them, so the wait states between an MFMA's
+        // write of its accumulator and the first VALU read of it (the epilogue) are spelled out (16 are more than any 4-pass MFMA needs)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
         DC_STAMP(2 + 8 * l + 2);
 #ifdef SRGANFD_EXPERIMENT
         if (stp && tid == 0) { stp[2 + 8 * l + 4] = wait_acc; stp[2 + 8 * l + 1] = spin_acc; }
@@ -486,8 +510,8 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         const f32x4_t b0 = *(const f32x4_t*)(ctl_bias + l * 32 + 4 * g4), b1 = *(const f32x4_t*)(ctl_bias + l * 32 + 16 + 4 * g4);
         char* const lds_out = patch + (growth ? Ld.dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, g4 >> 1) + 8 * (g4 & 1);
         const int nh_off = (((l15 + 1) >> 1) & 2) ? -32 : 32;      // second channel half: 16-byte slot + 2 under dc_pos's column key (slot ^ 2: two slots up or down)
-        auto epilogue = [&](auto growth_c, auto ops_c) {
-          constexpr bool GROWTH = decltype(growth_c)::v != 0;
+        auto epilogue = [&](auto growth_c, auto ops_c, auto max_c) {
+          constexpr bool GROWTH = decltype(growth_c)::v != 0, MAXACT = decltype(max_c)::v != 0;
           constexpr int OPS = decltype(ops_c)::v;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
@@ -498,7 +522,9 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const float v = __builtin_fmaf(alpha, acc[m][nh][i], nh ? b1[i] : b0[i]);
-                v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
+                // v * (v > 0 ? pos : neg); with pos >= neg >= 0 that is max(v * pos, v * neg): two multiplies and a max, no compare / select pair
+                if constexpr (MAXACT) v4[i] = __builtin_fmaxf(v * ps_pos, v * ps_neg);
+                else v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
               }
               if constexpr (OPS >= 2) { dc_widen4<T>(eA[m][nh], t4);
 #pragma unroll
@@ -522,15 +548,24 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           }
         };
         const int ops_kind = Ld.r1 ? (Ld.r2 ? 3 : 2) : (Ld.mask ? 1 : 0);
-        switch ((growth ? 4 : 0) + ops_kind) {
-          case 0: epilogue(IC<0>{}, IC<0>{}); break;
-          case 1: epilogue(IC<0>{}, IC<1>{}); break;
-          case 2: epilogue(IC<0>{}, IC<2>{}); break;
-          case 3: epilogue(IC<0>{}, IC<3>{}); break;
-          case 4: epilogue(IC<1>{}, IC<0>{}); break;
-          case 5: epilogue(IC<1>{}, IC<1>{}); break;
-          case 6: epilogue(IC<1>{}, IC<2>{}); break;
-          default: epilogue(IC<1>{}, IC<3>{}); break;
+        const bool maxact = ps_neg >= 0.f && ps_pos >= ps_neg;
+        switch ((growth ? 4 : 0) + ops_kind + (maxact ? 8 : 0)) {
+          case 0: epilogue(IC<0>{}, IC<0>{}, IC<0>{}); break;
+          case 1: epilogue(IC<0>{}, IC<1>{}, IC<0>{}); break;
+          case 2: epilogue(IC<0>{}, IC<2>{}, IC<0>{}); break;
+          case 3: epilogue(IC<0>{}, IC<3>{}, IC<0>{}); break;
+          case 4: epilogue(IC<1>{}, IC<0>{}, IC<0>{}); break;
+          case 5: epilogue(IC<1>{}, IC<1>{}, IC<0>{}); break;
+          case 6: epilogue(IC<1>{}, IC<2>{}, IC<0>{}); break;
+          case 7: epilogue(IC<1>{}, IC<3>{}, IC<0>{}); break;
+          case 8: epilogue(IC<0>{}, IC<0>{}, IC<1>{}); break;
+          case 9: epilogue(IC<0>{}, IC<1>{}, IC<1>{}); break;
+          case 10: epilogue(IC<0>{}, IC<2>{}, IC<1>{}); break;
+          case 11: epilogue(IC<0>{}, IC<3>{}, IC<1>{}); break;
+          case 12: epilogue(IC<1>{}, IC<0>{}, IC<1>{}); break;
+          case 13: epilogue(IC<1>{}, IC<1>{}, IC<1>{}); break;
+          case 14: epilogue(IC<1>{}, IC<2>{}, IC<1>{}); break;
+          default: epilogue(IC<1>{}, IC<3>{}, IC<1>{}); break;
         }
         DC_STAMP(2 + 8 * l + 3);
       }
