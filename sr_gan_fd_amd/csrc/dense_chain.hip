@@ -37,6 +37,7 @@
 // Same arithmetic contract as conv_igemm.hip (include/srganfd.h, srganfd_conv2d): fp32 accumulation in chunk, kernel-column,
 // kernel-row order, v = post_scale * act(alpha * acc + bias) + r1s * r1 + r2s * r2, masked, rounded once to the 16-bit type.
 #include "conv_common.hpp"
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -55,7 +56,7 @@ constexpr int kDcRingOff = kDcGroups * kDcGroupBytes;            // 124,416
 constexpr int kDcStageOff = kDcRingOff + kDcSlots * kDcSlot;     // 155,136: hand-off staging of the four compute waves (LDS-DMA destinations)
 constexpr int kDcStageHalo = 1088, kDcStageWave = kDcStageHalo + 256;     // per wave: its 68 halo items of 16 B, then one flag word per lane
 constexpr int kDcCtlOff = kDcStageOff + 4 * kDcStageWave;        // 160,512: float alpha[8]; float bias[6][32]
-constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4;      // 161,312 B
+constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4 + kDcMaxLayers * 32;      // 161,504 B: + int tab[6][8]
 constexpr int kDcThreads = 384;      // waves 0-3 compute, 4-5 weight loaders
 constexpr int kDcHaloPix = 68, kDcHaloItems = kDcHaloPix * 4;    // 16-byte items of one group's halo ring
 constexpr int kDcMaxTiles = 16384;   // tiles of one call (flags: 4 growth layers x tiles)
@@ -78,9 +79,11 @@ struct DcK {
   int N, H, W, tiles_x, tiles_y, tpi;       // tpi: tiles per image
   int ipl;                   // images per pass (the grid is ipl * tpi workgroups)
   int totalTiles;            // N * tpi
+  int tab[kDcMaxLayers][8];  // per layer, copied to LDS once: nChunks, dst_group, epilogue kind, post_scale (+), post_scale * neg (-), r1s, r2s, mask_slope (floats as bits)
   int* hdr;                  // [0] hand-off waits that gave up, [1] epoch of the last finished launch, [2] workgroups finished in this launch
   int* flags;                // [growth layer][tile of the batch], epoch-valued
 #ifdef SRGANFD_EXPERIMENT
+  int dbg;                      // timing ablations (results wrong): 1 no global stores in the epilogue, 2 no LDS writes in the epilogue, 4 no epilogue arithmetic
   unsigned long long* stamps;   // [workgroup][256] s_memtime stamps of compute wave 0 (tools/r5/dc_stamps.py)
 #endif
 };
@@ -108,6 +111,16 @@ __device__ __forceinline__ void dc_glds4_sc1(const void* gsrc, unsigned lds_dst)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(gsrc), "s"(dst) : "m0", "memory");
+#pragma clang diagnostic pop
+}
+// 16-byte write-through store (no 16-byte atomic store exists; inline assembly, so the compiler's vmcnt bookkeeping does not see it:
+// the hand-off drains with an explicit vmcnt(0) before the flag is published, and a kernel's stores are complete when it ends)
+__device__ __forceinline__ void dc_store16_sc1(void* dst, const u32x4 v) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  // the s_nop is the gfx9 wait state between a store of more than 8 bytes and a VALU write of its data registers (the hazard
+  // recognizer inserts it for its own stores; it cannot see into this one, and the epilogue reuses the registers at once)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 #pragma clang diagnostic pop
 }
 template <int N> __device__ __forceinline__ void dc_wait_vm() {
@@ -140,16 +153,6 @@ __device__ __forceinline__ void dc_halo_rc(int hp, int& prow, int& pcol) {
 typedef unsigned long long dc_u64;
 typedef __attribute__((ext_vector_type(2))) unsigned int dc_u32x2;
 
-// v_mfma_f32_16x16x32 accumulating in place (vDst == SrcC).  Written as inline assembly because the compiler, with registers to spare,
-// picks vDst != SrcC for the builtin in this kernel, and that form issues every 20-24 cycles instead of 16.4
-// (tools/probes/mfma_issue_probe.hip, profiles/r05_mfma_issue_probe.txt); conv_igemm.hip / wgrad.hip get the in-place form from the builtin.
-template <typename T> __device__ __forceinline__ void dc_mfma16_inplace(f32x4_t& c, const typename FragAB<T>::type& a, const typename FragAB<T>::type& b);
-template <> __device__ __forceinline__ void dc_mfma16_inplace<f16_t>(f32x4_t& c, const f16x8& a, const f16x8& b) {
-  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-template <> __device__ __forceinline__ void dc_mfma16_inplace<bf16_t>(f32x4_t& c, const bf16x8& a, const bf16x8& b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
 template <typename T> __device__ __forceinline__ void dc_widen4(const dc_u32x2 q, float* f) {
   if constexpr (Elem<T>::kDtype == SRGANFD_F16) {
     typedef __attribute__((ext_vector_type(4))) _Float16 h4;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   char* const ring = smem + kDcRingOff;
   float* const ctl_alpha = (float*)(smem + kDcCtlOff);
   float* const ctl_bias = (float*)(smem + kDcCtlOff + 32);
+  int* const ctl_tab = (int*)(smem + kDcCtlOff + 32 + kDcMaxLayers * 32 * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
@@ -275,6 +279,8 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
     const int cw = wave;                   // rows 4 cw .. 4 cw + 3 of the tile
     // launch constants: epoch (polls and the publish use it), bias / alpha table
     const int epoch = __hip_atomic_load(a.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (cw == 3 && lane < kDcMaxLayers * 8)       // the per-layer table: one dword per lane straight from the kernel-argument segment
+      ctl_tab[lane] = ((const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(DcK, tab) / 4 + lane];
     {
       // all six layers' loads first, then the LDS writes: one memory round trip instead of one per layer
       float bv[kDcMaxLayers], av[kDcMaxLayers];
@@ -343,9 +349,14 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
 
 #pragma unroll 1
       for (int l = 0; l < a.nLayers; ++l) {
-        const DcLayer& Ld = a.L[l];
-        const int nCh = Ld.nChunks, ns = 3 * nCh;
-        const bool prev_growth = l > 0 && a.L[l - 1].dst_group >= 0;
+        const DcLayer& Ld = a.L[l];        // (kernel-argument loads: only the rare steps touch it; the per-step and epilogue scalars come from the LDS table)
+        const int4 tb0 = *(const int4*)(ctl_tab + 8 * l), tb1 = *(const int4*)(ctl_tab + 8 * l + 4);
+        const int nCh = __builtin_amdgcn_readfirstlane(tb0.x), ns = 3 * nCh;
+        const int dst_group = __builtin_amdgcn_readfirstlane(tb0.y), epi_kind = __builtin_amdgcn_readfirstlane(tb0.z);
+        const float ps_pos = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb0.w)), ps_neg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.x));
+        const float r1s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.y)), r2s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.z));
+        const float mslope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.w));
+        const bool prev_growth = l > 0 && __builtin_amdgcn_readfirstlane(ctl_tab[8 * (l > 0 ? l - 1 : 0) + 1]) >= 0;
         // hand-off of the previous layer's output (group nCh - 1, first read by the fragments requested behind barrier 3 (nCh - 1) - 1): three
         // dependent round trips of 1.5-2.5k cycles (store acknowledgement, flag visible + poll, halo read) beside steps of ~650 cycles.
         // Stores drained behind barrier 1, flag published behind barrier 2, neighbours' flags requested behind barrier s_poll (a poll right
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         // s_chk, halo moved from the staging area into the patch behind barrier s_wr (visible behind barrier s_wr + 1 <= 3 (nCh - 1) - 1).
         // conv2 (3 chunks) has no room for that: it waits at step 4; from conv4 on everything is hidden.
         const int s_poll = nCh <= 4 ? 3 : nCh - 1, s_chk = nCh == 3 ? 4 : 2 * nCh - 3, s_wr = nCh == 3 ? 4 : 3 * nCh - 5;
-        const bool growth = Ld.dst_group >= 0;
+        const bool growth = dst_group >= 0;
         f32x4_t acc[4][2];       // [row][16-channel half]
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -464,21 +475,21 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           }                                                                                                         \
           const bool wrap_ = (S) + 1 == ns;                                                                         \
           const int kxn_ = wrap_ || kx == 2 ? 0 : kx + 1, cn_ = wrap_ ? 0 : (kx == 2 ? c + 1 : c);                  \
-          const int col_ = l15 + kxn_;                                                                              \
-          const char* pa_ = patch + cn_ * kDcGroupBytes + rowoff + (col_ << 6) + ((g4 ^ ((col_ >> 1) & 2)) << 4);   \
-          const char* rs_ = ring + ((t + 1) % kDcSlots) * kDcSlot + lane * 16;                                      \
-          /* 24 MFMAs that accumulate IN PLACE (vDst == SrcC: 16.4 cycles each; the form the compiler picked here, vDst != SrcC,   \
-             measured 20-24: profiles/r05_mfma_issue_probe.txt), the NEXT step's 12 fragment reads behind MFMAs 0-7, 9, 11, 13, 15; \
-             a scheduling barrier after every group keeps that order (the scheduler would otherwise sink the reads to the end of the \
-             step to shorten their live ranges, and the next step would start by waiting for them) */                \
-          _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                       \
-            const int ky_ = i_ >> 3, nh_ = (i_ >> 2) & 1, m_ = i_ & 3;                                              \
-            dc_mfma16_inplace<T>(acc[m_][nh_], CW[ky_ * 2 + nh_], CP[m_ + ky_]);                                    \
-            const int r_ = i_ < 8 ? i_ : ((i_ & 1) && i_ < 16 ? 8 + ((i_ - 9) >> 1) : -1);                          \
-            if (r_ >= 0 && r_ < 6) NP[r_] = *(const Frag*)(pa_ + r_ * (kDcPC * 64));                                \
-            if (r_ >= 6) NW[r_ - 6] = *(const Frag*)(rs_ + (r_ - 6) * 1024);                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                      \
+          load_frags(NW, NP, cn_, kxn_, t + 1);                                                                     \
+          _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                          \
+            _Pragma("unroll") for (int nh = 0; nh < 2; ++nh)                                                        \
+              _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
+          /* issue order: the NEXT step's 12 fragment reads spread over this step's first 16 MFMAs (the scheduler would otherwise sink   \
+             the reads to the end of the step to shorten their live ranges, and the next step would start by waiting for them) */ \
+          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
           }                                                                                                         \
+          _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+          }                                                                                                         \
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                        \
           c = cn_; kx = kxn_;                                                                                       \
           ++t;                                                                                                      \
         }
@@ -494,33 +505,36 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           for (int q = 0; q < 6; ++q) { Aw[q] = Bw[q]; Ap[q] = Bp[q]; }
         }
 #undef DC_STEP
-        // the MFMAs above are inline assembly: the compiler's hazard recognizer does not see them, so the wait states between an MFMA's
-        // write of its accumulator and the first VALU read of it (the epilogue) are spelled out (16 are more than any 4-pass MFMA needs)
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
         DC_STAMP(2 + 8 * l + 2);
 #ifdef SRGANFD_EXPERIMENT
         if (stp && tid == 0) { stp[2 + 8 * l + 4] = wait_acc; stp[2 + 8 * l + 1] = spin_acc; }
 #endif
 
-        // ---- epilogue: lane = pixel l15 of rows 4 cw + m, channels 16 nh + 4 g4 .. + 3.  The operand combination is a compile-time
-        // kind (one switch per layer): OPS 0 none, 1 mask, 2 r1, 3 r1 + r2; GROWTH: also group dst_group of the patch, write-through store ----
+        // ---- epilogue: lane = pixel l15 of rows 4 cw + m, channels 16 nh + 4 g4 .. + 3 per accumulator.  The operand combination is a
+        // compile-time kind (one switch per layer): OPS 0 none, 1 mask, 2 r1, 3 r1 + r2; GROWTH: also group dst_group of the patch and a
+        // write-through store; MAXACT: activation as max(v * pos, v * neg).  The two 8-byte channel quads of a lane (nh = 0 / 1) are turned
+        // into ONE 16-byte slot by v_permlane16_swap (lane row g4 ends up with slot {0, 2, 1, 3}[g4] of its pixel): one 16-byte LDS write and
+        // one 16-byte store per pixel instead of two 8-byte ones each ----
         const float alpha = ctl_alpha[l];
-        const float ps_pos = Ld.post_scale, ps_neg = Ld.neg * Ld.post_scale;
-        const float r1s = Ld.r1s, r2s = Ld.r2s, mslope = Ld.mask_slope;
         const f32x4_t b0 = *(const f32x4_t*)(ctl_bias + l * 32 + 4 * g4), b1 = *(const f32x4_t*)(ctl_bias + l * 32 + 16 + 4 * g4);
-        char* const lds_out = patch + (growth ? Ld.dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, g4 >> 1) + 8 * (g4 & 1);
-        const int nh_off = (((l15 + 1) >> 1) & 2) ? -32 : 32;      // second channel half: 16-byte slot + 2 under dc_pos's column key (slot ^ 2: two slots up or down)
+        const int sl16 = ((g4 & 1) << 1) | (g4 >> 1);
+        char* const lds_out = patch + (growth ? dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, sl16);
+        T* const y16 = ydst + (8 * sl16 - 4 * g4);       // ydst points at this lane's channel quad 4 g4; the 16-byte slot starts at channel 8 * sl16
         auto epilogue = [&](auto growth_c, auto ops_c, auto max_c) {
           constexpr bool GROWTH = decltype(growth_c)::v != 0, MAXACT = decltype(max_c)::v != 0;
           constexpr int OPS = decltype(ops_c)::v;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const bool ok = col_ok && orow0 + m < a.H;
+            dc_u32x2 pk[2];
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
               float v4[4], t4[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
+#ifdef SRGANFD_EXPERIMENT
+                if (a.dbg & 4) { v4[i] = acc[m][nh][i]; continue; }
+#endif
                 const float v = __builtin_fmaf(alpha, acc[m][nh][i], nh ? b1[i] : b0[i]);
                 // v * (v > 0 ? pos : neg); with pos >= neg >= 0 that is max(v * pos, v * neg): two multiplies and a max, no compare / select pair
                 if constexpr (MAXACT) v4[i] = __builtin_fmaxf(v * ps_pos, v * ps_neg);
@@ -535,21 +549,28 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
               if constexpr (OPS == 1) { dc_widen4<T>(eA[m][nh], t4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v4[i] *= t4[i] > 0.f ? 1.f : mslope; }
-              dc_u32x2 pk = dc_narrow4<T>(v4);
-              if (!ok) pk = dc_u32x2{0u, 0u};      // pixels beyond the image are zero padding for the layers that follow
-              if constexpr (GROWTH) *(dc_u32x2*)(lds_out + m * (kDcPC * 64) + nh * nh_off) = pk;
-              if (ok) {
-                T* dst = ydst + (size_t)m * yrow + 16 * nh;
-                // growth layers: write-through (sc1), the neighbours read the halo from memory inside this launch
-                if constexpr (GROWTH) __hip_atomic_store((dc_u64*)dst, __builtin_bit_cast(dc_u64, pk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *(dc_u32x2*)dst = pk;
-              }
+              pk[nh] = dc_narrow4<T>(v4);
+              if (!ok) pk[nh] = dc_u32x2{0u, 0u};      // pixels beyond the image are zero padding for the layers that follow
+            }
+            const dc_u32x2 sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+            const dc_u32x2 sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+            const u32x4 q = {sx.x, sy.x, sx.y, sy.y};      // lower quad (both dwords), then upper quad of this lane's 16-byte slot
+#ifdef SRGANFD_EXPERIMENT
+            if (!(a.dbg & 2))
+#endif
+            if constexpr (GROWTH) *(u32x4*)(lds_out + m * (kDcPC * 64)) = q;
+#ifdef SRGANFD_EXPERIMENT
+            if (!(a.dbg & 1))
+#endif
+            if (ok) {
+              T* dst = y16 + (size_t)m * yrow;
+              // growth layers: write-through (sc1), the neighbours read the halo from memory inside this launch
+              if constexpr (GROWTH) dc_store16_sc1(dst, q);
+              else *(u32x4*)dst = q;
             }
           }
         };
-        const int ops_kind = Ld.r1 ? (Ld.r2 ? 3 : 2) : (Ld.mask ? 1 : 0);
-        const bool maxact = ps_neg >= 0.f && ps_pos >= ps_neg;
-        switch ((growth ? 4 : 0) + ops_kind + (maxact ? 8 : 0)) {
+        switch (epi_kind) {
           case 0: epilogue(IC<0>{}, IC<0>{}, IC<0>{}); break;
           case 1: epilogue(IC<0>{}, IC<1>{}, IC<0>{}); break;
           case 2: epilogue(IC<0>{}, IC<2>{}, IC<0>{}); break;
@@ -629,6 +650,14 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
       L.dst_group = last ? -1 : a.cin / 32;
       L.alpha = a.alpha; L.neg = a.act == SRGANFD_ACT_LRELU ? a.slope : (a.act == SRGANFD_ACT_RELU ? 0.f : 1.f);
       L.post_scale = a.post_scale; L.r1s = a.r1_scale; L.r2s = a.r2_scale; L.mask_slope = a.mask_slope;
+      {
+        const float ps_pos = L.post_scale, ps_neg = L.neg * L.post_scale;
+        const int ops = L.r1 ? (L.r2 ? 3 : 2) : (L.mask ? 1 : 0);
+        const int kind = (L.dst_group >= 0 ? 4 : 0) + ops + (ps_neg >= 0.f && ps_pos >= ps_neg ? 8 : 0);
+        int* t = K.tab[nl - 1];
+        t[0] = L.nChunks; t[1] = L.dst_group; t[2] = kind;
+        memcpy(&t[3], &ps_pos, 4); memcpy(&t[4], &ps_neg, 4); memcpy(&t[5], &L.r1s, 4); memcpy(&t[6], &L.r2s, 4); memcpy(&t[7], &L.mask_slope, 4);
+      }
       steps += 3 * k.nChunks;
     }
   }
@@ -664,6 +693,7 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
   K.hdr = (int*)workspace;
   K.flags = (int*)((char*)workspace + 64);
 #ifdef SRGANFD_EXPERIMENT
+  { const char* e = getenv("SRGANFD_DC_DBG"); K.dbg = e ? atoi(e) : 0; }
   K.stamps = getenv("SRGANFD_DC_STAMPS") ? (unsigned long long*)((char*)workspace + 64 + sizeof(int) * 4 * kDcMaxTiles) : nullptr;
 #endif
   const bool f16 = layers[0].dtype == SRGANFD_F16;
