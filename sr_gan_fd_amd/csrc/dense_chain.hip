@@ -56,7 +56,7 @@ constexpr int kDcRingOff = kDcGroups * kDcGroupBytes;            // 124,416
 constexpr int kDcStageOff = kDcRingOff + kDcSlots * kDcSlot;     // 155,136: hand-off staging of the four compute waves (LDS-DMA destinations)
 constexpr int kDcStageHalo = 1088, kDcStageWave = kDcStageHalo + 256;     // per wave: its 68 halo items of 16 B, then one flag word per lane
 constexpr int kDcCtlOff = kDcStageOff + 4 * kDcStageWave;        // 160,512: float alpha[8]; float bias[6][32]
-constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4 + kDcMaxLayers * 32;      // 161,504 B: + int tab[6][8]
+constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4 + kDcMaxLayers * 128;      // 162,080 B: + int tab[6][32]
 constexpr int kDcThreads = 384;      // waves 0-3 compute, 4-5 weight loaders
 constexpr int kDcHaloPix = 68, kDcHaloItems = kDcHaloPix * 4;    // 16-byte items of one group's halo ring
 constexpr int kDcMaxTiles = 16384;   // tiles of one call (flags: 4 growth layers x tiles)
@@ -79,7 +79,9 @@ struct DcK {
   int N, H, W, tiles_x, tiles_y, tpi;       // tpi: tiles per image
   int ipl;                   // images per pass (the grid is ipl * tpi workgroups)
   int totalTiles;            // N * tpi
-  int tab[kDcMaxLayers][8];  // per layer, copied to LDS once: nChunks, dst_group, epilogue kind, post_scale (+), post_scale * neg (-), r1s, r2s, mask_slope (floats as bits)
+  int tab[kDcMaxLayers][32]; // per layer, copied to LDS once (kernel-argument loads in the layer loop measured ~0.7k cycles per dependent round):
+                             // 0 nChunks, 1 dst_group, 2 epilogue kind, 3 post_scale (+), 4 post_scale * neg (-), 5 r1s, 6 r2s, 7 mask_slope (floats as bits),
+                             // 8-9 y, 10 yC, 11 y_ps, 12 y_gs, 13 y_c0, 14-15 operand A (r1 or mask), 16 its C, 17 ps, 18 gs, 19 c0, 20-21 r2, 22 r2C, 23 r2_ps, 24 r2_gs, 25 r2_c0
   int* hdr;                  // [0] hand-off waits that gave up, [1] epoch of the last finished launch, [2] workgroups finished in this launch
   int* flags;                // [growth layer][tile of the batch], epoch-valued
 #ifdef SRGANFD_EXPERIMENT
@@ -178,6 +180,7 @@ template <typename T> __device__ __forceinline__ dc_u32x2 dc_narrow4(const float
 template <typename T>
 __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   using Frag = typename FragAB<T>::type;
+  typedef __attribute__((address_space(1))) T GT;      // an element in global memory
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const patch = smem;
   char* const ring = smem + kDcRingOff;
@@ -279,8 +282,11 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
     const int cw = wave;                   // rows 4 cw .. 4 cw + 3 of the tile
     // launch constants: epoch (polls and the publish use it), bias / alpha table
     const int epoch = __hip_atomic_load(a.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    if (cw == 3 && lane < kDcMaxLayers * 8)       // the per-layer table: one dword per lane straight from the kernel-argument segment
-      ctl_tab[lane] = ((const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(DcK, tab) / 4 + lane];
+    if (cw == 3) {      // the per-layer table: one dword per lane and round straight from the kernel-argument segment
+#pragma unroll
+      for (int r = 0; r < kDcMaxLayers * 32 / 64; ++r)
+        ctl_tab[lane + 64 * r] = ((const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(DcK, tab) / 4 + lane + 64 * r];
+    }
     {
       // all six layers' loads first, then the LDS writes: one memory round trip instead of one per layer
       float bv[kDcMaxLayers], av[kDcMaxLayers];
@@ -350,16 +356,17 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
 #pragma unroll 1
       for (int l = 0; l < a.nLayers; ++l) {
         const DcLayer& Ld = a.L[l];        // (kernel-argument loads: only the rare steps touch it; the per-step and epilogue scalars come from the LDS table)
-        const int4 tb0 = *(const int4*)(ctl_tab + 8 * l), tb1 = *(const int4*)(ctl_tab + 8 * l + 4);
+        const int* const tl = ctl_tab + 32 * l;
+        const int4 tb0 = *(const int4*)(tl), tb1 = *(const int4*)(tl + 4);
         const int nCh = __builtin_amdgcn_readfirstlane(tb0.x), ns = 3 * nCh;
         const int dst_group = __builtin_amdgcn_readfirstlane(tb0.y), epi_kind = __builtin_amdgcn_readfirstlane(tb0.z);
         const float ps_pos = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb0.w)), ps_neg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.x));
         const float r1s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.y)), r2s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.z));
         const float mslope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(tb1.w));
-        const bool prev_growth = l > 0 && __builtin_amdgcn_readfirstlane(ctl_tab[8 * (l > 0 ? l - 1 : 0) + 1]) >= 0;
+        const bool prev_growth = l > 0 && __builtin_amdgcn_readfirstlane(ctl_tab[32 * (l > 0 ? l - 1 : 0) + 1]) >= 0;
         // hand-off of the previous layer's output (group nCh - 1, first read by the fragments requested behind barrier 3 (nCh - 1) - 1): three
         // dependent round trips of 1.5-2.5k cycles (store acknowledgement, flag visible + poll, halo read) beside steps of ~650 cycles.
-        // Stores drained behind barrier 1, flag published behind barrier 2, neighbours' flags requested behind barrier s_poll (a poll right
+        // Stores drained behind step 1, flag published behind barrier 2, neighbours' flags requested behind barrier s_poll (a poll right
         // after the publish always reads the old value: everybody publishes at the same time), looked at and halo requested behind barrier
         // s_chk, halo moved from the staging area into the patch behind barrier s_wr (visible behind barrier s_wr + 1 <= 3 (nCh - 1) - 1).
         // conv2 (3 chunks) has no room for that: it waits at step 4; from conv4 on everything is hidden.
@@ -370,14 +377,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) acc[m][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // epilogue operands of this lane's 4 pixels x 2 channel quads, requested behind barrier 1: slot A = r1 or mask, slot B = r2
-        dc_u32x2 eA[4][2], eB[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int nh = 0; nh < 2; ++nh) { eA[m][nh] = dc_u32x2{0u, 0u}; eB[m][nh] = dc_u32x2{0u, 0u}; }
-        T* ydst = nullptr;       // this lane's first output element (row 4 cw, channels 4 g4 ..), set behind barrier 1
-        int yrow = 0;            // elements per image row of the output
         DC_STAMP(2 + 8 * l);
 #ifdef SRGANFD_EXPERIMENT
         unsigned long long wait_acc = 0, spin_acc = 0;
@@ -386,39 +385,16 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         // the rare steps: everything that is not "barrier, 12 fragment reads, 24 MFMAs" lives here, out of the step's straight line.
         // The hand-off's loads are LDS-DMA into this wave's staging area: nothing of them lives in registers between steps.
         auto event = [&](int s) {
-          if (s == 1) {
-            if (prev_growth) dc_wait_vm<0>();      // the previous layer's write-through stores are acknowledged (issued more than a step ago)
-            // output address and epilogue operands (residuals, mask) of this lane: in registers long before the epilogue
-            // (channel offsets are multiples of 32, checked on the host: the second channel half is 16 elements on)
-            const int p0 = col_ok && orow0 < a.H ? orow0 * a.W + ocol : 0;       // a lane without an output pixel reads pixel 0 (a valid address) and drops it
-            ydst = (T*)Ld.y + img * Ld.yC + ((size_t)p0 * Ld.y_ps + (size_t)(Ld.y_c0 >> 5) * Ld.y_gs + 4 * g4);
-            yrow = a.W * Ld.y_ps;
-            const char* opA = Ld.r1 ? Ld.r1 : Ld.mask;
-            if (opA) {
-              const int aC = Ld.r1 ? Ld.r1C : Ld.mC, a_c0 = Ld.r1 ? Ld.r1_c0 : Ld.m_c0, a_ps = Ld.r1 ? Ld.r1_ps : Ld.m_ps, a_gs = Ld.r1 ? Ld.r1_gs : Ld.m_gs;
-              const T* pa = (const T*)opA + img * aC + ((size_t)p0 * a_ps + (size_t)(a_c0 >> 5) * a_gs + 4 * g4);
-#pragma unroll
-              for (int m = 0; m < 4; ++m) {
-                const T* pm = orow0 + m < a.H ? pa + (size_t)m * a.W * a_ps : pa;
-                eA[m][0] = *(const dc_u32x2*)pm; eA[m][1] = *(const dc_u32x2*)(pm + 16);
-              }
-            }
-            if (Ld.r2) {
-              const T* pb = (const T*)Ld.r2 + img * Ld.r2C + ((size_t)p0 * Ld.r2_ps + (size_t)(Ld.r2_c0 >> 5) * Ld.r2_gs + 4 * g4);
-#pragma unroll
-              for (int m = 0; m < 4; ++m) {
-                const T* pm = orow0 + m < a.H ? pb + (size_t)m * a.W * Ld.r2_ps : pb;
-                eB[m][0] = *(const dc_u32x2*)pm; eB[m][1] = *(const dc_u32x2*)(pm + 16);
-              }
-            }
-          } else if (s == 2) {
+          if (s == 2) {
             // every compute wave's stores of layer l - 1 are acknowledged (vmcnt(0) behind barrier 1, then barrier 2): ONE lane publishes
             // the tile.  Behind barrier s_poll every wave asks for its neighbours' flags (lane j < 8: neighbour j; the other lanes read this tile's own word)
             if (cw == 0 && lane == 0) __hip_atomic_store(a.flags + (size_t)(l - 1) * a.totalTiles + gtile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else if (s == s_poll) {
             dc_glds4_sc1(a.flags + (size_t)(l - 1) * a.totalTiles + gtile + noff, stage_lds + kDcStageHalo);
           } else if (s == s_chk) {
-            const DcLayer& P = a.L[l - 1];
+            const int4 q2 = *(const int4*)(tl - 32 + 8), q3 = *(const int4*)(tl - 32 + 12);      // the previous layer's output view
+            const int PyC = __builtin_amdgcn_readfirstlane(q2.z), Py_ps = __builtin_amdgcn_readfirstlane(q2.w), Py_gs = __builtin_amdgcn_readfirstlane(q3.x), Py_c0 = __builtin_amdgcn_readfirstlane(q3.y);
+            const T* const Py = (const T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(q2.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(q2.x));
 #ifdef SRGANFD_EXPERIMENT
             unsigned long long s0_ = 0; if (stp && wave == 0) s0_ = now();
 #endif
@@ -435,26 +411,26 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             if (stp && wave == 0) spin_acc += now() - s0_;
 #endif
             // this wave's 68 halo items of the previous layer's output: 16 bytes per lane, lanes 0 .. 63 and 0 .. 3
-            const T* yi = (const T*)P.y + img * P.yC;
+            const T* yi = Py + img * PyC;
             {
-              const int cc = P.y_c0 + 8 * h_slot[0];
-              dc_glds16_sc1(yi + ((size_t)h_gp[0] * P.y_ps + (size_t)(cc >> 5) * P.y_gs + (cc & 31)), stage_lds);
+              const int cc = Py_c0 + 8 * h_slot[0];
+              dc_glds16_sc1(yi + ((size_t)h_gp[0] * Py_ps + (size_t)(cc >> 5) * Py_gs + (cc & 31)), stage_lds);
             }
             if (lane < 4) {
-              const int cc = P.y_c0 + 8 * h_slot[1];
-              dc_glds16_sc1(yi + ((size_t)h_gp[1] * P.y_ps + (size_t)(cc >> 5) * P.y_gs + (cc & 31)), stage_lds + 1024);
+              const int cc = Py_c0 + 8 * h_slot[1];
+              dc_glds16_sc1(yi + ((size_t)h_gp[1] * Py_ps + (size_t)(cc >> 5) * Py_gs + (cc & 31)), stage_lds + 1024);
             }
           }
           if (prev_growth && s == s_wr) {
             dc_wait_vm<0>();       // the halo items have landed in the staging area
-            char* pg = patch + a.L[l - 1].dst_group * kDcGroupBytes;
+            char* pg = patch + __builtin_amdgcn_readfirstlane(tl[1 - 32]) * kDcGroupBytes;
             if (h_in[0]) *(u32x4*)(pg + h_off[0]) = *(const u32x4*)(stage + 16 * lane);
             if (lane < 4 && h_in[1]) *(u32x4*)(pg + h_off[1]) = *(const u32x4*)(stage + 1024 + 16 * lane);
           }
         };
 
         int c = 0, kx = 0;       // chunk and kernel column of the current step
-        int ev = 1;              // the next step with an event
+        int ev = prev_growth ? 2 : -1;       // the next step with an event
         // one kernel-column step: barrier (slot t + 1 is complete, everybody is past step t - 1), the next step's fragments into N* (the
         // next layer's first step behind this layer's last: its chunk 0 is the block input), this step's 24 MFMAs on C*
 #ifdef SRGANFD_EXPERIMENT
@@ -471,7 +447,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           DC_W1                                                                                                     \
           if (__builtin_expect((S) == ev, 0)) {                                                                     \
             event(S);                                                                                               \
-            ev = !prev_growth ? -1 : ((S) == 1 ? 2 : ((S) == 2 ? s_poll : ((S) == s_poll ? s_chk : ((S) == s_chk && s_wr > s_chk ? s_wr : -1)))); \
+            ev = (S) == 2 ? s_poll : ((S) == s_poll ? s_chk : ((S) == s_chk && s_wr > s_chk ? s_wr : -1));          \
           }                                                                                                         \
           const bool wrap_ = (S) + 1 == ns;                                                                         \
           const int kxn_ = wrap_ || kx == 2 ? 0 : kx + 1, cn_ = wrap_ ? 0 : (kx == 2 ? c + 1 : c);                  \
@@ -493,7 +469,69 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           c = cn_; kx = kxn_;                                                                                       \
           ++t;                                                                                                      \
         }
-        int s = 0;
+        // steps 0 and 1, then -- in straight-line code, so that nothing it loads is a loop-carried value the compiler would have to settle
+        // (wait for) at a join -- the drain of the previous layer's stores and the request of this layer's epilogue operands
+        DC_STEP(0, Aw, Ap, Bw, Bp)
+        DC_STEP(1, Bw, Bp, Aw, Ap)
+        DC_STAMP(2 + 8 * l + 5);
+        if (prev_growth) dc_wait_vm<0>();      // the previous layer's write-through stores are acknowledged (issued two steps ago: free); barrier 2 follows
+        DC_STAMP(2 + 8 * l + 6);
+        // epilogue operands of this lane's 4 pixels: slot A = r1 or mask, slot B = r2.  Loaded as ONE 16-byte slot per pixel (slot
+        // {0, 2, 1, 3}[g4], the layout the epilogue stores in) and turned into this lane's two channel quads by v_permlane16_swap in the
+        // epilogue (the swap is its own inverse): 4 load instructions per operand instead of 8 (16 requests of 8 bytes per wave took ~2.7k cycles to issue)
+        u32x4 rA[4], rB[4];
+        T* ydst;                 // this lane's first output element (row 4 cw, 16-byte slot {0, 2, 1, 3}[g4] of its pixel)
+        int yrow;                // elements per image row of the output
+        {
+          // output address and epilogue operands (residuals, mask) of this lane: in registers long before the epilogue
+          // (channel offsets are multiples of 32, checked on the host: the second channel half is 16 elements on)
+          auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+          // (global address space spelled out: a pointer assembled from two table words is generic to the compiler, and a FLAT load also counts
+          // on lgkmcnt -- the next barrier's lgkmcnt(0) would wait for the operands' whole memory latency)
+          auto ptr_of = [&](int lo, int hi) { return (const GT*)(((unsigned long long)(unsigned)rfl(hi) << 32) | (unsigned)rfl(lo)); };
+          const int4 t2 = *(const int4*)(tl + 8), t3 = *(const int4*)(tl + 12), t4 = *(const int4*)(tl + 16);
+          const int p0 = col_ok && orow0 < a.H ? orow0 * a.W + ocol : 0;       // a lane without an output pixel reads pixel 0 (a valid address) and drops it
+          const int sl16 = ((g4 & 1) << 1) | (g4 >> 1);
+          ydst = (T*)(unsigned long long)ptr_of(t2.x, t2.y) + img * rfl(t2.z) + ((size_t)p0 * rfl(t2.w) + (size_t)(rfl(t3.y) >> 5) * rfl(t3.x) + 8 * sl16);
+          yrow = a.W * rfl(t2.w);
+          // (the operand registers have ONE definition: a zero-initialised array assigned under an `if` is a merge of two, and the compiler
+          // settles such a merge by WAITING for the loads -- measured as a whole memory latency per layer)
+          const GT* opA = ptr_of(t3.z, t3.w);
+          if ((epi_kind & 3) != 0) {      // (rA stays undefined otherwise -- never read: the merge has one definition, nothing to settle)
+            const int a_ps = rfl(t4.y);
+            const GT* pa = opA + img * rfl(t4.x) + ((size_t)p0 * a_ps + (size_t)(rfl(t4.w) >> 5) * rfl(t4.z) + 8 * sl16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const GT* pm = orow0 + m < a.H ? pa + (size_t)m * a.W * a_ps : pa;
+              rA[m] = *(const __attribute__((address_space(1))) u32x4*)pm;
+            }
+          }
+        }
+        DC_STAMP(2 + 8 * l + 7);
+        // steps 2 and 3, then the second operand (one burst of requests per CU overruns the L1's miss queue and stalls the issuing wave
+        // for a memory latency: two smaller bursts two steps apart)
+        DC_STEP(2, Aw, Ap, Bw, Bp)
+        DC_STEP(3, Bw, Bp, Aw, Ap)
+        {
+          auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+          // (global address space spelled out: a pointer assembled from two table words is generic to the compiler, and a FLAT load also counts
+          // on lgkmcnt -- the next barrier's lgkmcnt(0) would wait for the operands' whole memory latency)
+          auto ptr_of = [&](int lo, int hi) { return (const GT*)(((unsigned long long)(unsigned)rfl(hi) << 32) | (unsigned)rfl(lo)); };
+          const int4 t5 = *(const int4*)(tl + 20), t6 = *(const int4*)(tl + 24);
+          const int p0 = col_ok && orow0 < a.H ? orow0 * a.W + ocol : 0;
+          const int sl16 = ((g4 & 1) << 1) | (g4 >> 1);
+          const GT* opB = ptr_of(t5.x, t5.y);
+          if ((epi_kind & 3) == 3) {
+            const int b_ps = rfl(t5.w);
+            const GT* pb = opB + img * rfl(t5.z) + ((size_t)p0 * b_ps + (size_t)(rfl(t6.y) >> 5) * rfl(t6.x) + 8 * sl16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const GT* pm = orow0 + m < a.H ? pb + (size_t)m * a.W * b_ps : pb;
+              rB[m] = *(const __attribute__((address_space(1))) u32x4*)pm;
+            }
+          }
+                }
+        int s = 4;
 #pragma unroll 1
         for (; s + 1 < ns; s += 2) {
           DC_STEP(s, Aw, Ap, Bw, Bp)
@@ -519,14 +557,22 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         const f32x4_t b0 = *(const f32x4_t*)(ctl_bias + l * 32 + 4 * g4), b1 = *(const f32x4_t*)(ctl_bias + l * 32 + 16 + 4 * g4);
         const int sl16 = ((g4 & 1) << 1) | (g4 >> 1);
         char* const lds_out = patch + (growth ? dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, sl16);
-        T* const y16 = ydst + (8 * sl16 - 4 * g4);       // ydst points at this lane's channel quad 4 g4; the 16-byte slot starts at channel 8 * sl16
+        T* const y16 = ydst;
         auto epilogue = [&](auto growth_c, auto ops_c, auto max_c) {
           constexpr bool GROWTH = decltype(growth_c)::v != 0, MAXACT = decltype(max_c)::v != 0;
           constexpr int OPS = decltype(ops_c)::v;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const bool ok = col_ok && orow0 + m < a.H;
-            dc_u32x2 pk[2];
+            dc_u32x2 pk[2], eA[2], eB[2];
+            if constexpr (OPS >= 1) {
+              const dc_u32x2 ux = __builtin_amdgcn_permlane16_swap(rA[m].x, rA[m].z, false, false), uy = __builtin_amdgcn_permlane16_swap(rA[m].y, rA[m].w, false, false);
+              eA[0] = dc_u32x2{ux.x, uy.x}; eA[1] = dc_u32x2{ux.y, uy.y};
+            }
+            if constexpr (OPS == 3) {
+              const dc_u32x2 ux = __builtin_amdgcn_permlane16_swap(rB[m].x, rB[m].z, false, false), uy = __builtin_amdgcn_permlane16_swap(rB[m].y, rB[m].w, false, false);
+              eB[0] = dc_u32x2{ux.x, uy.x}; eB[1] = dc_u32x2{ux.y, uy.y};
+            }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
               float v4[4], t4[4];
@@ -540,13 +586,13 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
                 if constexpr (MAXACT) v4[i] = __builtin_fmaxf(v * ps_pos, v * ps_neg);
                 else v4[i] = v * (v > 0.f ? ps_pos : ps_neg);
               }
-              if constexpr (OPS >= 2) { dc_widen4<T>(eA[m][nh], t4);
+              if constexpr (OPS >= 2) { dc_widen4<T>(eA[nh], t4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(r1s, t4[i], v4[i]); }
-              if constexpr (OPS == 3) { dc_widen4<T>(eB[m][nh], t4);
+              if constexpr (OPS == 3) { dc_widen4<T>(eB[nh], t4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v4[i] = __builtin_fmaf(r2s, t4[i], v4[i]); }
-              if constexpr (OPS == 1) { dc_widen4<T>(eA[m][nh], t4);
+              if constexpr (OPS == 1) { dc_widen4<T>(eA[nh], t4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v4[i] *= t4[i] > 0.f ? 1.f : mslope; }
               pk[nh] = dc_narrow4<T>(v4);
@@ -657,6 +703,12 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
         int* t = K.tab[nl - 1];
         t[0] = L.nChunks; t[1] = L.dst_group; t[2] = kind;
         memcpy(&t[3], &ps_pos, 4); memcpy(&t[4], &ps_neg, 4); memcpy(&t[5], &L.r1s, 4); memcpy(&t[6], &L.r2s, 4); memcpy(&t[7], &L.mask_slope, 4);
+        memcpy(&t[8], &L.y, 8); t[10] = L.yC; t[11] = L.y_ps; t[12] = L.y_gs; t[13] = L.y_c0;
+        if (L.r1) { memcpy(&t[14], &L.r1, 8); t[16] = L.r1C; t[17] = L.r1_ps; t[18] = L.r1_gs; t[19] = L.r1_c0; }
+        else if (L.mask) { memcpy(&t[14], &L.mask, 8); t[16] = L.mC; t[17] = L.m_ps; t[18] = L.m_gs; t[19] = L.m_c0; }
+        else { memcpy(&t[14], &L.y, 8); t[16] = L.yC; t[17] = L.y_ps; t[18] = L.y_gs; t[19] = L.y_c0; }      // absent: any valid view (the requests are unconditional)
+        if (L.r2) { memcpy(&t[20], &L.r2, 8); t[22] = L.r2C; t[23] = L.r2_ps; t[24] = L.r2_gs; t[25] = L.r2_c0; }
+        else { memcpy(&t[20], &L.y, 8); t[22] = L.yC; t[23] = L.y_ps; t[24] = L.y_gs; t[25] = L.y_c0; }
       }
       steps += 3 * k.nChunks;
     }

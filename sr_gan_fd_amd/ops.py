@@ -131,13 +131,16 @@ def dense_chain_workspace(device) -> torch.Tensor:
 
 def dense_chain_wanted(n: int, h: int, w: int, cus: int = 256) -> bool:
     """the launch needs every 16 x 16 tile of a pass resident at once (one workgroup per CU, cus // tiles images per pass) and keeps
-    one flag per growth layer and tile of the call; "auto" takes it where it measured faster than the five launches"""
+    one flag per growth layer and tile of the call.  "auto" takes it where it measured faster than the five launches
+    (profiles/r05_dense_chain_v2_bench.txt): batches that fit ONE pass -- 1.5x (forward) / 1.35x (data gradient) at the reference's
+    crop sizes; a second pass costs a whole pass whatever it holds (batch 16 at 72 x 72: 400 tiles, 0.96x / 0.83x) and at batch 32,
+    128 x 128 (eight passes) the per-layer launches are 1.2x faster"""
     if DENSE_CHAIN == "0":
         return False
     per = -(-h // 16) * -(-w // 16)
     if per > cus or n * per > 16384:
         return False
-    return DENSE_CHAIN == "1" or n * per <= 2 * cus
+    return DENSE_CHAIN == "1" or n * per <= cus
 
 
 class DenseChain:

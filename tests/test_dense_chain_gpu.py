@@ -1,4 +1,4 @@
-"""LDS-resident dense-block launch (csrc/dense_chain.hip, srganfd_dense_chain) against the separate srganfd_conv2d launches it replaces:
+"""LDS-resident dense-block launch (csrc/dense_chain.hip, srganfd_dense_chain; 16 x 16-pixel tiles, one per CU and pass) against the separate srganfd_conv2d launches it replaces:
 the five convs of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62: four growth convs with bias + LeakyReLU written into the block's
 own buffer, the closing 192 -> 64 conv with the residual epilogue) and the five launches of its data-gradient pass (masks from the saved
 activations, residual adds on the closing launch), at the reference's crop sizes and at ragged ones, NHWC and planar buffers, several
@@ -91,4 +91,5 @@ def test_dense_chain_refuses_what_it_cannot_run():
     assert not ops.DenseChain(args[1:], "cuda").ok                       # does not start at the 64-channel layer
     big, _, keep2 = _build(torch.float16, 1, 8 * 40, 32 * 8, 1, False)   # 320 tiles of one image: more than the device has CUs
     assert not ops.DenseChain(big, "cuda").ok
-    assert not ops.dense_chain_wanted(32, 128, 128) and ops.dense_chain_wanted(16, 72, 72) and ops.dense_chain_wanted(16, 32, 32)
+    # "auto": batches that fit one pass of 16 x 16 tiles on the 256 CUs
+    assert not ops.dense_chain_wanted(32, 128, 128) and not ops.dense_chain_wanted(16, 72, 72) and ops.dense_chain_wanted(16, 32, 32) and ops.dense_chain_wanted(8, 60, 60)

@@ -32,7 +32,7 @@ for l in range(6):
     if st[0, b] == 0:
         break
     start, spin, steps_e, epi_e, wacc = st[:, b], st[:, b + 1], st[:, b + 2], st[:, b + 3], st[:, b + 4]
-    print(f"         barrier -> fragment reads {med(st[:, b + 5]):7.0f}, fragment reads + 24 MFMAs + their completion {med(st[:, b + 6]):7.0f}")
+    print(f"         behind step 1: drain of the previous layer's stores {med(st[:, b + 6] - st[:, b + 5]):6.0f}, output address + operand requests {med(st[:, b + 7] - st[:, b + 6]):6.0f}")
     print(f"layer {l}: steps {med(steps_e - start):7.0f} cycles (of which at the step barriers {med(wacc):7.0f}, waiting for the neighbours' flags {med(spin):6.0f})   epilogue {med(epi_e - steps_e):6.0f}")
 d = (st[:, 101:178] - st[:, 100:177]).float().median(dim=0).values
 print("cycles from step barrier to step barrier, steps 0..76 of the last pass (median over workgroups; layer boundaries at 6, 15, 27, 42, 60):")
