@@ -63,11 +63,11 @@ BASE_LR_SIZE = {"g_only": 128, "gan": 128, "aesrgan_gan": 192, "esrgan_gan": 32,
 
 
 # Counter-derived fields of the roofline object (HBM-side traffic per launch, MFMA-pipe utilisation) come from
-# profiles/r04_pmc.json, which tools/pmc_to_json.py writes from separate `rocprofv3 --pmc` passes of this command (the guide's
+# profiles/r05_pmc.json, which tools/pmc_to_json.py writes from separate `rocprofv3 --pmc` passes of this command (the guide's
 # gfx950 rule: 16-byte-per-lane reads are tallied at half their bytes, so traffic = (2 x RDREQ + WRREQ) x 64 B; MFMA utilisation =
 # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)).  The file records the SHA of the kernel sources it was
 # measured on; when the sources differ the fields are null instead of stale.
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def csrc_sha() -> str:
@@ -86,9 +86,9 @@ def pmc_fields(workload: str, kernel: str, B: int, h: int) -> dict:
     except Exception:
         return {"traffic": None, "mfma_busy_pmc": None, "pmc_source": None}
     if rec.get("csrc_sha") != csrc_sha() or rec.get("batch") != B or rec.get("lr_size") != h:
-        return {"traffic": None, "mfma_busy_pmc": None, "pmc_source": "profiles/r04_pmc.json is from other kernel sources / another shape"}
+        return {"traffic": None, "mfma_busy_pmc": None, "pmc_source": "profiles/r05_pmc.json is from other kernel sources / another shape"}
     w = rec.get("workloads", {}).get(workload, {}).get(kernel, {})
-    return {"traffic": w.get("traffic_bytes_per_launch"), "mfma_busy_pmc": w.get("mfma_util"), "pmc_source": "profiles/r04_pmc.json (counters taken on another box of the pool, tools/profile_round.sh)"}
+    return {"traffic": w.get("traffic_bytes_per_launch"), "mfma_busy_pmc": w.get("mfma_util"), "pmc_source": "profiles/r05_pmc.json (counters taken on another box of the pool, tools/profile_round.sh)"}
 
 
 REALESRGAN_DEGRADATION = dict(      # realesrgan_config.py:67-90

@@ -107,14 +107,18 @@ int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_le
 /* A whole dense block as ONE launch with LDS-resident activations (csrc/dense_chain.hip): replaces the n_layers srganfd_conv2d
  * launches of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62; ESRGAN/model.py:49-60, Real_ESRGAN/model.py:131-142,
  * A-ESRGAN/model.py:441-452 are the same code) -- or of its data-gradient pass, which is the same dense structure over the stacked
- * output gradients -- when an image is at most one 8 x 32-pixel tile per compute unit (the reference's crop sizes: 32 ... 72 pixels
- * at batch 8-16).  `layers` are exactly the arguments those launches would get, in order: layer i (0-based) is a 16-bit 3x3
- * stride-1 pad-1 conv reading channels [0, 64 + 32 i) of ONE buffer; all but the last write 32 channels at [64 + 32 i, 96 + 32 i) of
- * that same buffer (bias / activation / mask as given), the last one (64 output channels, r1 / r2 / mask as given) writes anywhere
- * else.  Results follow srganfd_conv2d's formula with the same accumulation order; the batch is processed in groups of images whose
- * tiles are all resident at once.  `workspace`: srganfd_dense_chain_workspace_bytes() bytes of device memory that the caller zeroes
- * ONCE at allocation (hand-off flags are re-zeroed per launch on the stream; word 0 counts hand-off waits that gave up -- always 0 in
- * a correct run, results are wrong otherwise).  srganfd_dense_chain_check validates `layers` and the size limit without launching. */
+ * output gradients -- when an image is at most one 16 x 16-pixel tile per compute unit (the reference's crop sizes: 32 ... 72 pixels
+ * at batch 8-16; faster than the separate launches while the whole batch is at most one tile per compute unit).  `layers` are exactly
+ * the arguments those launches would get, in order: layer i (0-based) is a 16-bit 3x3 stride-1 pad-1 conv reading channels
+ * [0, 64 + 32 i) of ONE buffer; all but the last write 32 channels at [64 + 32 i, 96 + 32 i) of that same buffer (bias / activation /
+ * mask as given), the last one (64 output channels, r1 / r2 as given) writes anywhere else.  Per layer either a mask or residuals
+ * (r2 only with r1); every channel offset a multiple of 32.  Results follow srganfd_conv2d's formula with the same accumulation order;
+ * the whole batch is one launch (a workgroup walks the groups of images whose tiles are resident at once).  `workspace`:
+ * srganfd_dense_chain_workspace_bytes() bytes of device memory that the caller zeroes ONCE at allocation and gives to one stream's
+ * launches at a time (hand-off flags are epoch-valued from a counter in its header: nothing is zeroed per launch and a captured graph
+ * replays correctly; word 0 counts hand-off waits that gave up after ~2 s -- always 0 in a correct run, results are wrong otherwise).
+ * srganfd_dense_chain_check validates `layers` and the size limits (tiles of one image <= compute units, 16384 tiles per call)
+ * without launching. */
 int srganfd_dense_chain(const srganfd_conv_args* layers, int32_t n_layers, void* workspace, size_t workspace_bytes, void* stream);
 int srganfd_dense_chain_check(const srganfd_conv_args* layers, int32_t n_layers);
 size_t srganfd_dense_chain_workspace_bytes(void);
