@@ -61,11 +61,15 @@ def count_rrdb(P: Params) -> int:
     return n
 
 
-def rrdbnet_forward(x: Tensor, P: Params, upscale_factor: int = 4, clamp: bool = True) -> Tensor:
+def rrdbnet_forward(x: Tensor, P: Params, upscale_factor: int = 4, clamp: bool = True, unshuffle: int = 1) -> Tensor:
     """BSRGAN._forward_impl -- BSRGAN/model.py:366-381; RRDBNet._forward_impl -- ESRGAN/model.py:208-229.
+    ``unshuffle`` = 2 / 4: Real_ESRGAN/model.py:190-204,248-262 below x4 -- the input is pixel-unshuffled (conv1 reads 12 / 48 channels)
+    and both nearest-x2 stages run (pass upscale_factor=4 for the stage count; the net factor is 4 / unshuffle).
 
     x: (N,3,h,w) in [0,1]  ->  (N,3,s*h,s*w), clamped to [0,1].
     """
+    if unshuffle > 1:
+        x = F.pixel_unshuffle(x, unshuffle)
     out1 = _conv(x, P, "conv1")
     out = out1
     for i in range(count_rrdb(P)):

@@ -318,7 +318,8 @@ class TrunkEngine:
             s = 1 << self.n_up
             # thin-side kernels (csrc/conv_thin.hip) for conv1 / conv4 in the 16-bit modes: the image side is NHWC with a 4-channel pitch
             sp.thin_i, sp.thin_o = ops.thin_ok(dtc, Cc, self.in_ch), ops.thin_ok(dtc, Cc, self.out_ch)
-            sp.xin = new(N, H, W, 4 if sp.thin_i else 32)
+            cin1 = ops.pad32(self.in_ch)          # 3 -> 32; Real-ESRGAN below x4: 12 -> 32, 48 -> 64 (Real_ESRGAN/model.py:190-201)
+            sp.xin = new(N, H, W, 4 if sp.thin_i else cin1)
             sp.f0 = new(N, H, W, Cc)
             sp.ups = [new(N, H << u, W << u, Cc) for u in range(1, self.n_up + 1)]
             sp.c3 = new(N, H * s, W * s, Cc)
@@ -327,7 +328,7 @@ class TrunkEngine:
                 fw.append(ops.ThinLaunch("thin_in", ops.thin_args(dtc, N, H, W, self.in_ch, bias("conv1.weight"), VC(catb(0)), w_big_is_cout=True,
                                                                   bias=bias("conv1.bias"), thin=sp.xin)))
             else:
-                fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, 32, Cc, bias=bias("conv1.bias")))
+                fw.append(ops.conv_args(dtc, V(sp.xin), VC(catb(0)), wptr + pk["offs"][("f", "conv1")], N, H, W, cin1, Cc, bias=bias("conv1.bias")))
         for i, pre in enumerate(self._rdb_prefix):
             ci = catb(i)
             blk = []
@@ -498,8 +499,9 @@ class TrunkEngine:
                                                                               V(sp.dx0), w_big_is_cout=True, thin=sp.xin),
                                                   dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), ws=sp.thin_ws)))
             else:
-                convs = [dict(cin=32, cout=Cc, dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), co_dst=Cc, ci_dst=self.in_ch)]
-                bw.append(("wgrad", wplan(N, H, W, 32, Cc, convs), V(sp.xin), V(sp.dx0), 0))
+                cin1 = ops.pad32(self.in_ch)
+                convs = [dict(cin=cin1, cout=Cc, dw_off=self._poff("conv1.weight"), db_off=self._poff("conv1.bias"), co_dst=Cc, ci_dst=self.in_ch)]
+                bw.append(("wgrad", wplan(N, H, W, cin1, Cc, convs), V(sp.xin), V(sp.dx0), 0))
         # last bucket: whatever the earlier markers did not cover
         covered = min([it[1] for it in bw if it[0] == "ready"], default=self.fp.total)
         bw.append(("ready", 0, covered))

@@ -80,13 +80,19 @@ class _RRDBGenerator(nn.Module):
     """Shared body of BSRGAN (BSRGAN/model.py:311-384) and RRDBNet (ESRGAN/model.py:144-243)."""
 
     def __init__(self, in_channels: int, out_channels: int, channels: int, growth_channels: int,
-                 num_blocks: int, upscale_factor: int, always_up1: bool, rdb_self_init: bool = False) -> None:
+                 num_blocks: int, upscale_factor: int, always_up1: bool, rdb_self_init: bool = False, unshuffle: int = 1) -> None:
         super().__init__()
         self.upscale_factor = upscale_factor
+        # Real-ESRGAN below x4 (Real_ESRGAN/model.py:190-204,248): the input is pixel-unshuffled by `unshuffle` (conv1 sees
+        # in_channels * unshuffle^2 channels at 1 / unshuffle of the size) and BOTH nearest-x2 stages always run
+        self.unshuffle = unshuffle
+        if unshuffle > 1:
+            in_channels *= unshuffle * unshuffle
+            self.downsampling = nn.PixelUnshuffle(unshuffle)
         self.conv1 = nn.Conv2d(in_channels, channels, (3, 3), (1, 1), (1, 1))
         self.trunk = nn.Sequential(*[_ResidualResidualDenseBlock(channels, growth_channels, rdb_self_init) for _ in range(num_blocks)])
         self.conv2 = nn.Conv2d(channels, channels, (3, 3), (1, 1), (1, 1))
-        n_up = {1: 0, 2: 1, 4: 2, 8: 3}[upscale_factor]
+        n_up = {1: 0, 2: 1, 4: 2, 8: 3}[upscale_factor * unshuffle]
         if always_up1:               # BSRGAN builds upsampling1 unconditionally (model.py:337-340)
             n_up = max(n_up, 1)
         for u in range(1, n_up + 1):
@@ -104,13 +110,17 @@ class _RRDBGenerator(nn.Module):
         self.compute_dtype = None
 
     def n_upsample(self) -> int:
-        return {1: 0, 2: 1, 4: 2, 8: 3}[self.upscale_factor]
+        return {1: 0, 2: 1, 4: 2, 8: 3}[self.upscale_factor * getattr(self, "unshuffle", 1)]
 
     def forward(self, x: Tensor) -> Tensor:
         return self._forward_impl(x)
 
     def _forward_impl(self, x: Tensor) -> Tensor:
         from .engine import generator_apply
+        if getattr(self, "unshuffle", 1) > 1:
+            # a pure re-indexing of the input image (no parameters, no arithmetic; the input needs no gradient): torch's op, then the
+            # engine's conv1 reads 12 / 48 channels (padded to 32 / 64 for the MFMA path)
+            x = torch.nn.functional.pixel_unshuffle(x, self.unshuffle)
         return generator_apply(self, x)
 
 
@@ -121,19 +131,21 @@ class BSRGAN(_RRDBGenerator):
 
 
 class RRDBNet(_RRDBGenerator):
-    """ESRGAN/model.py:144-243 (``num_blocks``) and, for the x4 factory it ships, Real_ESRGAN/model.py:179-262
-    (``num_rrdb``; its PixelUnshuffle is the identity at x4 and both upsampling stages always run)."""
+    """ESRGAN/model.py:144-243 (``num_blocks``) and Real_ESRGAN/model.py:179-262 (``num_rrdb``: x4 as its shipped factory --
+    PixelUnshuffle is the identity --, x2 / x1 with PixelUnshuffle(2 / 4) in front of conv1; both upsampling stages always run)."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, channels: int = 64, growth_channels: int = 32,
                  num_blocks: int = 23, upscale_factor: int = 4, num_rrdb: int = None) -> None:
+        unshuffle = 1
         if num_rrdb is not None:
-            if upscale_factor != 4:
-                raise ValueError("Real-ESRGAN's RRDBNet is mirrored for upscale_factor=4 only (x2 / x1 use PixelUnshuffle)")
+            if upscale_factor not in (1, 2, 4):
+                raise ValueError("Real-ESRGAN's RRDBNet takes upscale_factor 1, 2 or 4 (Real_ESRGAN/model.py:190-201)")
+            unshuffle = 4 // upscale_factor       # x2: PixelUnshuffle(2), x1: PixelUnshuffle(4), x4: identity
             num_blocks = num_rrdb
         # Real-ESRGAN's dense blocks draw their own initialisation first: same random stream, so a seeded construction
         # gives the reference's initial weights
         super().__init__(in_channels, out_channels, channels, growth_channels, num_blocks, upscale_factor, always_up1=False,
-                         rdb_self_init=num_rrdb is not None)
+                         rdb_self_init=num_rrdb is not None, unshuffle=unshuffle)
 
 
 class DiscriminatorUNet(nn.Module):

@@ -152,6 +152,32 @@ def gold_generator(MB, ME):
     save("generator.npz", **out)
 
 
+def gold_realesrgan_rrdbnet(MR):
+    """Real_ESRGAN/model.py:179-262 at the factors its class supports beyond the shipped x4 factory: x2 / x1 unshuffle the input
+    (PixelUnshuffle 2 / 4: conv1 sees 12 / 48 channels) and always run both nearest-x2 upsampling stages"""
+    out = {}
+    cases = [("x2_r2_s3", 2, 3.0, (2, 3, 16, 16)), ("x1_r2_s3", 1, 3.0, (1, 3, 16, 16)), ("x2_r2_s3_odd", 2, 3.0, (1, 3, 12, 20))]
+    for name, s, scale, shape in cases:
+        torch.manual_seed(0)
+        g = MR.RRDBNet(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2, upscale_factor=s)
+        scaled_init(g, scale, 0.5)
+        x = torch.rand(*shape)
+        gt = torch.rand(shape[0], 3, shape[2] * s, shape[3] * s)
+        sr = g(x)
+        loss = torch.nn.functional.l1_loss(sr, gt)
+        loss.backward()
+        out[f"{name}/x"] = np_(x)
+        out[f"{name}/gt"] = np_(gt)
+        out[f"{name}/sr"] = np_(sr)
+        out[f"{name}/loss"] = np.array(loss.item())
+        named = dict(g.named_parameters())
+        out[f"{name}/wsum"] = sd_checksums(g.state_dict())
+        out[f"{name}/gsum"] = {k: checksum(p.grad) for k, p in named.items()}
+        for k in ("conv1.weight", "conv1.bias", "conv4.weight", "trunk.0.rdb1.conv1.bias", "trunk.1.rdb3.conv5.bias", "conv2.bias"):
+            out[f"{name}/grad/{k}"] = np_(named[k].grad)
+    save("realesrgan_rrdbnet.npz", **out)
+
+
 def gold_discriminator(MB):
     out = {}
     torch.manual_seed(0)
@@ -686,6 +712,8 @@ def main():
         return gold_degradation()
     if "--only-realesrgan" in sys.argv:
         return gold_realesrgan_gan_steps(load_ref("Real_ESRGAN"))
+    if "--only-realesrgan-rrdbnet" in sys.argv:
+        return gold_realesrgan_rrdbnet(load_ref("Real_ESRGAN"))
     MB = load_ref("BSRGAN")
     ME = load_ref("ESRGAN")
     gold_blocks(MB)
@@ -700,7 +728,9 @@ def main():
     gold_esrgan_discriminator(ME)
     gold_esrgan_gan_steps(ME)
     gold_degradation()
-    gold_realesrgan_gan_steps(load_ref("Real_ESRGAN"))
+    MR = load_ref("Real_ESRGAN")
+    gold_realesrgan_gan_steps(MR)
+    gold_realesrgan_rrdbnet(MR)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,36 @@ def test_generator(golden_dir, dtype, name, fac, kw, s, scale):
     assert torch.equal(sr2, sr.detach())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name,s", [("x2_r2_s3", 2), ("x1_r2_s3", 1), ("x2_r2_s3_odd", 2)])
+def test_realesrgan_rrdbnet_below_x4(golden_dir, dtype, name, s):
+    """Real-ESRGAN's RRDBNet at x2 / x1 (Real_ESRGAN/model.py:190-204,248-262: PixelUnshuffle(2 / 4) in front of conv1, which then reads
+    12 / 48 channels; both upsampling stages) against outputs and gradients of the reference class; bounds TOL / GTOL as test_generator"""
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "realesrgan_rrdbnet.npz")
+    torch.manual_seed(0)
+    net = M.RRDBNet(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2, upscale_factor=s)
+    scaled_init(net, 3.0, 0.5)
+    net.compute_dtype = dtype
+    net.cuda()
+    x, gt = torch.tensor(g[f"{name}/x"]).cuda(), torch.tensor(g[f"{name}/gt"]).cuda()
+    sr = net(x)
+    assert sr.shape == gt.shape
+    e = _rel(sr, g[f"{name}/sr"])
+    print(f"Real-ESRGAN RRDBNet {name} {dtype}: SR max err {e:.2e}")
+    assert e < TOL[dtype]
+    loss = torch.nn.functional.l1_loss(sr, gt)
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < TOL[dtype] * abs(float(g[f"{name}/loss"]))
+    S = LOSS_SCALE[dtype]
+    (loss * S).backward()
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for k in ("conv1.weight", "conv1.bias", "conv4.weight", "trunk.0.rdb1.conv1.bias", "trunk.1.rdb3.conv5.bias", "conv2.bias"):
+        worst = max(worst, _rel(named[k].grad / S, g[f"{name}/grad/{k}"]))
+    print(f"Real-ESRGAN RRDBNet {name} {dtype}: worst grad err {worst:.2e}")
+    assert worst < GTOL[dtype]
+
+
 def test_state_dict_roundtrip_and_deepcopy(golden_dir):
     """the boundary: state_dict keys/shapes of the reference, deepcopy (AveragedModel), load_state_dict"""
     import copy

@@ -74,6 +74,26 @@ def test_generator(golden_dir, name, fac, kw, s, scale):
         assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * abs(want[1]) + 1e-12), f"{name} grad checksum {k}: {got} {want}"
 
 
+@pytest.mark.parametrize("name,s", [("x2_r2_s3", 2), ("x1_r2_s3", 1), ("x2_r2_s3_odd", 2)])
+def test_realesrgan_rrdbnet_below_x4(golden_dir, name, s):
+    """Real_ESRGAN/model.py:190-204,248: PixelUnshuffle(4 / s) in front of conv1, both upsampling stages (fixture from the reference class)"""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    g = load_golden(golden_dir, "realesrgan_rrdbnet.npz")
+    torch.manual_seed(0)
+    net = M.RRDBNet(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=2, upscale_factor=s)
+    scaled_init(net, 3.0, 0.5)
+    _check_table(table(g, f"{name}/wsum"), net.state_dict(), what=name)
+    P = sd_to_params(net.state_dict(), grad=True)
+    sr = O.rrdbnet_forward(torch.tensor(g[f"{name}/x"]), P, 4, unshuffle=4 // s)
+    _close(sr.detach(), g[f"{name}/sr"], what="sr")
+    loss = O.l1_mean(sr, torch.tensor(g[f"{name}/gt"]))
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-6
+    loss.backward()
+    for k in ("conv1.weight", "conv1.bias", "conv4.weight", "trunk.0.rdb1.conv1.bias", "trunk.1.rdb3.conv5.bias", "conv2.bias"):
+        _close(P[k].grad, g[f"{name}/grad/{k}"], tol=2e-4, what=f"grad {k}")
+
+
 def test_discriminator(golden_dir):
     from oracle import srgan_oracle as O
     from sr_gan_fd_amd import model as M

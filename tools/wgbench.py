@@ -15,7 +15,7 @@ VARIANTS = [int(x) for x in arg("--variants", "0,1,2").split(",")]
 DBG = int(arg("--dbg", "0"))     # experiment builds: 1 no global loads, 16 no LDS reads / MFMA, 4 no slab store (results are wrong)
 if DBG:
     A.lib().srganfd_set_debug(DBG)
-N, H, W, Cc, G = int(arg("--batch", "32")), 128, 128, 64, 32
+N, H, W, Cc, G = int(arg("--batch", "32")), int(arg("--size", "128")), int(arg("--size", "128")), 64, 32
 Ccat = Cc + 4 * G
 dtc = ops.DT[DT]
 x = (torch.randn(N, H, W, Ccat, device="cuda") * 0.5).to(DT)
