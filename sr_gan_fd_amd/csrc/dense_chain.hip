@@ -3,8 +3,8 @@
 // Replaces the five srganfd_conv2d launches of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62) -- and, with the data-gradient
 // operands, the five launches of its backward pass (the same dense structure over the stacked output gradients, engine.py) -- by one
 // persistent launch, for every batch whose images are at most one 16 x 16-pixel tile per compute unit (the reference's crop sizes:
-// bsrgan_config.py:101-102 72 x 72, esrgan_config.py:73-74 32 x 32, rrdbnet_config.py:51-52 48 x 48, aesrgan_config.py:102-103 60 x 60,
-// and BASELINE's 128 x 128: 64 tiles per image, four images per pass).
+// esrgan_config.py:73-74 32 x 32, rrdbnet_config.py:51-52 48 x 48, aesrgan_config.py:102-103 60 x 60 at batch 8-16 are ONE pass;
+// bsrgan_config.py:101-102 72 x 72 at batch 16 is two, BASELINE's 128 x 128 at batch 32 eight -- correct there, not faster).
 //
 // Why: a per-layer conv launch pays, per tile and layer, the kernel boundary, the address set-up, the round trip of the tile's own data
 // through L2 / HBM and the LDS commit of every chunk (13-15 us per launch whatever it computes at the reference's sizes,
@@ -14,26 +14,32 @@
 //
 // MI355X mapping (this is what 160 KB of LDS per CU and 256 CUs are for -- 40 MB of on-chip activation store):
 //   * one workgroup per CU owns ONE tile of 16 x 16 pixels of one image through all layers, then walks on to its tile of the next group
-//     of images ("pass").  The tile's 192 channels with a 1-pixel halo (18 x 18 pixels x 6 groups of 32 channels x 2 B = 124,416 B) are
-//     LDS-resident: groups 0-1 (the block input) are loaded once per pass, group 2 + k is written by layer k's epilogue straight from the
-//     accumulators.
+//     of images ("pass"; the whole batch is one launch).  The tile's 192 channels with a 1-pixel halo (18 x 18 pixels x 6 groups of 32
+//     channels x 2 B = 124,416 B) are LDS-resident: groups 0-1 (the block input) are loaded once per pass, group 2 + k is written by
+//     layer k's epilogue straight from the accumulators.
 //   * four COMPUTE waves (one per SIMD): wave w computes rows 4w .. 4w+3 x 16 pixels x 32 output channels -- per kernel-column step 6
 //     pixel fragments (patch rows 4w .. 4w+5, reused by the three kernel rows) and 6 weight fragments for 24 v_mfma_f32_16x16x32
-//     (operands swapped: A = weights, B = pixels, so a lane ends up with 4 consecutive channels of one pixel: 8-byte LDS / global
-//     writes).  48 KB of LDS reads per step and CU = 192 LDS cycles against 384 MFMA cycles per SIMD; the fragments of step t+1 are read
-//     while step t's MFMAs issue (two register sets, the step loop is unrolled by two).
+//     (operands swapped: A = weights, B = pixels, so a lane ends up with 4 consecutive channels of one pixel).  48 KB of LDS reads per
+//     step and CU = 192 LDS cycles against 384 MFMA cycles per SIMD; the fragments of step t+1 are read behind step t's first 16 MFMAs
+//     (sched_group_barrier pins that order), two fragment register sets, the step written out twice.
 //   * two LOADER waves own the weight stream: per step three 1 KB LDS-DMA pieces each (pack.hip's fragment order: a piece is one
-//     ds_read_b128 per lane) into a ring of six 6 KB slots, five steps ahead, counted vmcnt; ONE barrier per step publishes slot t+1 and
+//     ds_read_b128 per lane) into a ring of five 6 KB slots, four steps ahead, counted vmcnt; ONE barrier per step publishes slot t+1 and
 //     frees slot t.  No compute wave ever issues or waits for a weight piece.
+//   * everything that is not "barrier, 12 fragment reads, 24 MFMAs" is out of the step's straight line: per-layer scalars come from an
+//     LDS table copied once from the kernel arguments, the rare steps sit behind ONE unlikely test, the epilogue's operand requests are
+//     straight-line code behind steps 1 and 3 (one definition per register: nothing for the compiler to settle with a wait).
+//   * epilogue by compile-time kind (operands none / mask / r1 / r1 + r2, growth or closing layer, max-form activation); a lane's two
+//     channel quads become ONE 16-byte slot through v_permlane16_swap: one 16-byte LDS write and one 16-byte store per pixel.
 //   * only the halo of a NEW group crosses workgroups: the epilogue also stores the tile to the block's HBM buffer (the weight gradient and
-//     the next launch need it there anyway) with write-through (sc1) stores and goes on; two steps into the next layer every compute wave
-//     drains its stores (free by then), a barrier, and ONE lane publishes one flag per (layer, tile) -- row 1 of the micro-architecture
-//     guide's hand-off table.  A consumer polls the flags of its <= 8 neighbours and reads the 68 halo pixels with sc1 loads; both are
-//     ordinary loads issued by the compute waves two steps before their results are used, so the two dependent round trips (~1.1k cycles
-//     each) run beside the MFMA steps.  The halo of layer k is first needed by the LAST chunk of layer k + 1: one step before it every wave
-//     reads four interval-stamped LDS words and, if the halo is not in yet, all waves take extra barriers together (a uniform decision).
+//     the next launch need it there anyway) with write-through (sc1) stores and goes on; behind step 1 of the next layer every compute
+//     wave drains its stores, behind barrier 2 ONE lane publishes one flag per (layer, tile) -- row 1 of the micro-architecture guide's
+//     hand-off table.  A consumer fetches its <= 8 neighbours' flags and then its share of the 68 halo pixels by LDS-DMA (sc1) into a
+//     staging area -- nothing of the hand-off lives in registers between steps -- on a per-layer schedule (s_poll / s_chk / s_wr) that
+//     puts the three dependent round trips (~1.5-2.5k cycles each) beside MFMA steps: hidden from conv4 on, a 4-5k-cycle wait in conv2.
 //   * flags are epoch-valued: the launch reads its epoch from a device counter that the last workgroup to finish advances, so nothing is
 //     zeroed per launch and a captured hipGraph replays correctly.
+// Measured (profiles/r05_dense_chain_v2_*): 36.5-38.2 us (forward) / 41.1-43.4 us (data gradient) per pass of up to 256 tiles against
+// 55.5-58.3 us for the five launches; a pass costs the same whatever it holds, so the engines take the launch for one-pass batches only.
 // Same arithmetic contract as conv_igemm.hip (include/srganfd.h, srganfd_conv2d): fp32 accumulation in chunk, kernel-column,
 // kernel-row order, v = post_scale * act(alpha * acc + bias) + r1s * r1 + r2s * r2, masked, rounded once to the 16-bit type.
 #include "conv_common.hpp"
@@ -355,7 +361,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
 
 #pragma unroll 1
       for (int l = 0; l < a.nLayers; ++l) {
-        const DcLayer& Ld = a.L[l];        // (kernel-argument loads: only the rare steps touch it; the per-step and epilogue scalars come from the LDS table)
         const int* const tl = ctl_tab + 32 * l;
         const int4 tb0 = *(const int4*)(tl), tb1 = *(const int4*)(tl + 4);
         const int nCh = __builtin_amdgcn_readfirstlane(tb0.x), ns = 3 * nCh;
