@@ -299,7 +299,7 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
     import torch
     import torch.distributed as dist
     from sr_gan_fd_amd import model as M
-    from sr_gan_fd_amd import profiling
+    from sr_gan_fd_amd import ops, profiling
     from sr_gan_fd_amd.trainer import GeneratorTrainer
 
     cdt = getattr(torch, DTYPES[args.dtype])
@@ -469,6 +469,12 @@ def run_workload(args, workload, rank, world, dev, pg, module_loop=False, dropin
         # FLOP of the iteration x images/s / GPUs / 2.5 PF
         out["roofline"]["step_mfma_frac"] = round(out["step_tflops_per_gpu"] / PEAK_BF16_TFLOPS, 4)
         out["kernel_classes"] = profiling.summary(rec)
+    # the LDS-resident dense-block launch (small batches): a neighbour hand-off that gave up would mean wrong results, not a slow step
+    giveups = ops.dense_chain_giveups(dev)
+    if giveups is not None:
+        out["dense_chain"] = {"handoff_waits_given_up": giveups}
+        if giveups:
+            raise SystemExit("bench.py: %d dense-chain hand-off waits gave up (results are wrong)" % giveups)
     del trainer, step_fn, g
     import gc
     gc.collect()

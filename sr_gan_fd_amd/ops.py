@@ -129,6 +129,13 @@ def dense_chain_workspace(device) -> torch.Tensor:
     return ws
 
 
+def dense_chain_giveups(device):
+    """hand-off waits that gave up since the device's workspace was allocated (None: no dense-chain launch was ever planned there);
+    synchronises -- for the end of a run, not for the step"""
+    ws = _DC_WS.get(str(device))
+    return None if ws is None else int(ws[:4].view(torch.int32).item())
+
+
 def dense_chain_wanted(n: int, h: int, w: int, cus: int = 256) -> bool:
     """the launch needs every 16 x 16 tile of a pass resident at once (one workgroup per CU, cus // tiles images per pass) and keeps
     one flag per growth layer and tile of the call.  "auto" takes it where it measured faster than the five launches

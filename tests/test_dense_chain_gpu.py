@@ -93,3 +93,34 @@ def test_dense_chain_refuses_what_it_cannot_run():
     assert not ops.DenseChain(big, "cuda").ok
     # "auto": batches that fit one pass of 16 x 16 tiles on the 256 CUs
     assert not ops.dense_chain_wanted(32, 128, 128) and not ops.dense_chain_wanted(16, 72, 72) and ops.dense_chain_wanted(16, 32, 32) and ops.dense_chain_wanted(8, 60, 60)
+
+
+def test_dense_chain_beside_kernels_of_another_stream():
+    """The launch needs one workgroup per CU resident at once; kernels of another stream (in training: RCCL's all-reduce, the side-stream
+    weight gradients) may hold CUs for a while.  The chain then waits for them (its workgroups poll their neighbours' flags) and must give the
+    same bits, with no hand-off wait given up."""
+    from sr_gan_fd_amd import ops
+    n, h, w = 16, 32, 32
+    a_ref, (buf_ref, out_ref), k1 = _build(torch.float16, n, h, w, 1, False)
+    a_dc, (buf_dc, out_dc), k2 = _build(torch.float16, n, h, w, 1, False)
+    for a in a_ref:
+        ops.conv2d(a)
+    chain = ops.DenseChain(a_dc, buf_dc.device)
+    assert chain.ok
+    chain.run()
+    torch.cuda.synchronize()
+    want_b, want_o = buf_dc.clone(), out_dc.clone()
+    side = torch.cuda.Stream()
+    big_a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+    big_b = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+    for rep in range(5):
+        buf_dc.view(n, 6, h, w, 32)[:, 2:].zero_(); out_dc.fill_(7.0)      # planar groups 2..5 = the growth layers' outputs
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big_c = big_a @ big_b             # chip-filling GEMMs with LDS of their own
+        for _ in range(4):
+            chain.run()
+        torch.cuda.synchronize()
+        assert chain.errors() == 0
+        assert torch.equal(buf_dc, want_b) and torch.equal(out_dc, want_o)
