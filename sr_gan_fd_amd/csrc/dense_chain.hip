@@ -90,10 +90,6 @@ struct DcK {
                              // 8-9 y, 10 yC, 11 y_ps, 12 y_gs, 13 y_c0, 14-15 operand A (r1 or mask), 16 its C, 17 ps, 18 gs, 19 c0, 20-21 r2, 22 r2C, 23 r2_ps, 24 r2_gs, 25 r2_c0
   int* hdr;                  // [0] hand-off waits that gave up, [1] epoch of the last finished launch, [2] workgroups finished in this launch
   int* flags;                // [growth layer][tile of the batch], epoch-valued
-#ifdef SRGANFD_EXPERIMENT
-  int dbg;                      // timing ablations (results wrong): 1 no global stores in the epilogue, 2 no LDS writes in the epilogue, 4 no epilogue arithmetic
-  unsigned long long* stamps;   // [workgroup][256] s_memtime stamps of compute wave 0 (tools/r5/dc_stamps.py)
-#endif
 };
 
 __device__ __forceinline__ unsigned dc_lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
@@ -203,16 +199,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   const size_t ipix = (size_t)a.H * a.W;
   const int npass = li < a.N ? (a.N - li + a.ipl - 1) / a.ipl : 0;
   const int totalSteps = npass * a.stepsPerPass;
-#ifdef SRGANFD_EXPERIMENT
-  unsigned long long* const stp = a.stamps ? a.stamps + (size_t)blockIdx.x * 256 : nullptr;
-  auto now = []() { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); return t_; };
-  auto rnow = []() { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); return t_; };
-#define DC_STAMP(i) do { if (stp && wave == 0) { const unsigned long long t_ = now(); if (lane == 0) stp[i] = t_; } } while (0)
-  if (stp && wave == 0) { const unsigned long long t_ = rnow(); if (lane == 0) stp[61] = t_; }
-#else
-#define DC_STAMP(i) do {} while (0)
-#endif
-  DC_STAMP(0);
 
   // resident patch of a pass: groups 0, 1 from the block input (zeros outside the image), zero halo ring for the groups to come.  Nobody
   // reads the patch any more when this runs: the last step of the previous pass has had its fragments in registers since its barrier.
@@ -271,13 +257,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       dc_barrier();
 #pragma unroll 1
       for (int i = 0; i < a.stepsPerPass; ++i) {
-#ifdef SRGANFD_EXPERIMENT
-        unsigned long long l0_ = 0; if (stp && wave == 4) l0_ = now();
-#endif
         dc_wait_pieces(totalSteps - 2 - t);   // this wave's pieces of step t + 1 have landed: only those of steps t + 2 .. t + 4 are younger
-#ifdef SRGANFD_EXPERIMENT
-        if (stp && wave == 4) { const unsigned long long l1_ = now(); if (lane == 0 && i < 78) stp[178 + i] = l1_ - l0_; }
-#endif
         dc_barrier();                         // slot t + 1 is complete for everybody; slot t is free (its fragments are in registers)
         issue_next();                         // step t + 5 into it
         ++t;
@@ -355,7 +335,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       const int gtile = n * a.tpi + tin;
       load_patch(img);
       dc_barrier();
-      DC_STAMP(1);
       Frag Aw[6], Ap[6], Bw[6], Bp[6];       // two fragment sets: a step computes on one while the next step's are read into the other
       load_frags(Aw, Ap, 0, 0, t);
 
@@ -382,10 +361,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) acc[m][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        DC_STAMP(2 + 8 * l);
-#ifdef SRGANFD_EXPERIMENT
-        unsigned long long wait_acc = 0, spin_acc = 0;
-#endif
 
         // the rare steps: everything that is not "barrier, 12 fragment reads, 24 MFMAs" lives here, out of the step's straight line.
         // The hand-off's loads are LDS-DMA into this wave's staging area: nothing of them lives in registers between steps.
@@ -400,9 +375,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             const int4 q2 = *(const int4*)(tl - 32 + 8), q3 = *(const int4*)(tl - 32 + 12);      // the previous layer's output view
             const int PyC = __builtin_amdgcn_readfirstlane(q2.z), Py_ps = __builtin_amdgcn_readfirstlane(q2.w), Py_gs = __builtin_amdgcn_readfirstlane(q3.x), Py_c0 = __builtin_amdgcn_readfirstlane(q3.y);
             const T* const Py = (const T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(q2.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(q2.x));
-#ifdef SRGANFD_EXPERIMENT
-            unsigned long long s0_ = 0; if (stp && wave == 0) s0_ = now();
-#endif
             // all neighbours have published?  (normally yes at the first look: they run the same schedule)
             for (int spins = 0;; ++spins) {
               dc_wait_vm<0>();
@@ -412,9 +384,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
               __builtin_amdgcn_s_sleep(2);
               dc_glds4_sc1(a.flags + (size_t)(l - 1) * a.totalTiles + gtile + noff, stage_lds + kDcStageHalo);
             }
-#ifdef SRGANFD_EXPERIMENT
-            if (stp && wave == 0) spin_acc += now() - s0_;
-#endif
             // this wave's 68 halo items of the previous layer's output: 16 bytes per lane, lanes 0 .. 63 and 0 .. 3
             const T* yi = Py + img * PyC;
             {
@@ -438,18 +407,9 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         int ev = prev_growth ? 2 : -1;       // the next step with an event
         // one kernel-column step: barrier (slot t + 1 is complete, everybody is past step t - 1), the next step's fragments into N* (the
         // next layer's first step behind this layer's last: its chunk 0 is the block input), this step's 24 MFMAs on C*
-#ifdef SRGANFD_EXPERIMENT
-#define DC_W0 unsigned long long w0_ = 0; if (stp && wave == 0) w0_ = now();
-#define DC_W1 if (stp && wave == 0) { const unsigned long long w1_ = now(); wait_acc += w1_ - w0_; if (lane == 0) stp[100 + t - pass * a.stepsPerPass] = w1_; }
-#else
-#define DC_W0
-#define DC_W1
-#endif
 #define DC_STEP(S, CW, CP, NW, NP)                                                                                  \
         {                                                                                                           \
-          DC_W0                                                                                                     \
           dc_barrier();                                                                                             \
-          DC_W1                                                                                                     \
           if (__builtin_expect((S) == ev, 0)) {                                                                     \
             event(S);                                                                                               \
             ev = (S) == 2 ? s_poll : ((S) == s_poll ? s_chk : ((S) == s_chk && s_wr > s_chk ? s_wr : -1));          \
@@ -478,9 +438,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         // (wait for) at a join -- the drain of the previous layer's stores and the request of this layer's epilogue operands
         DC_STEP(0, Aw, Ap, Bw, Bp)
         DC_STEP(1, Bw, Bp, Aw, Ap)
-        DC_STAMP(2 + 8 * l + 5);
         if (prev_growth) dc_wait_vm<0>();      // the previous layer's write-through stores are acknowledged (issued two steps ago: free); barrier 2 follows
-        DC_STAMP(2 + 8 * l + 6);
         // epilogue operands of this lane's 4 pixels: slot A = r1 or mask, slot B = r2.  Loaded as ONE 16-byte slot per pixel (slot
         // {0, 2, 1, 3}[g4], the layout the epilogue stores in) and turned into this lane's two channel quads by v_permlane16_swap in the
         // epilogue (the swap is its own inverse): 4 load instructions per operand instead of 8 (16 requests of 8 bytes per wave took ~2.7k cycles to issue)
@@ -512,7 +470,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             }
           }
         }
-        DC_STAMP(2 + 8 * l + 7);
         // steps 2 and 3, then the second operand (one burst of requests per CU overruns the L1's miss queue and stalls the issuing wave
         // for a memory latency: two smaller bursts two steps apart)
         DC_STEP(2, Aw, Ap, Bw, Bp)
@@ -548,10 +505,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           for (int q = 0; q < 6; ++q) { Aw[q] = Bw[q]; Ap[q] = Bp[q]; }
         }
 #undef DC_STEP
-        DC_STAMP(2 + 8 * l + 2);
-#ifdef SRGANFD_EXPERIMENT
-        if (stp && tid == 0) { stp[2 + 8 * l + 4] = wait_acc; stp[2 + 8 * l + 1] = spin_acc; }
-#endif
 
         // ---- epilogue: lane = pixel l15 of rows 4 cw + m, channels 16 nh + 4 g4 .. + 3 per accumulator.  The operand combination is a
         // compile-time kind (one switch per layer): OPS 0 none, 1 mask, 2 r1, 3 r1 + r2; GROWTH: also group dst_group of the patch and a
@@ -583,9 +536,6 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
               float v4[4], t4[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-#ifdef SRGANFD_EXPERIMENT
-                if (a.dbg & 4) { v4[i] = acc[m][nh][i]; continue; }
-#endif
                 const float v = __builtin_fmaf(alpha, acc[m][nh][i], nh ? b1[i] : b0[i]);
                 // v * (v > 0 ? pos : neg); with pos >= neg >= 0 that is max(v * pos, v * neg): two multiplies and a max, no compare / select pair
                 if constexpr (MAXACT) v4[i] = __builtin_fmaxf(v * ps_pos, v * ps_neg);
@@ -606,13 +556,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             const dc_u32x2 sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
             const dc_u32x2 sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
             const u32x4 q = {sx.x, sy.x, sx.y, sy.y};      // lower quad (both dwords), then upper quad of this lane's 16-byte slot
-#ifdef SRGANFD_EXPERIMENT
-            if (!(a.dbg & 2))
-#endif
             if constexpr (GROWTH) *(u32x4*)(lds_out + m * (kDcPC * 64)) = q;
-#ifdef SRGANFD_EXPERIMENT
-            if (!(a.dbg & 1))
-#endif
             if (ok) {
               T* dst = y16 + (size_t)m * yrow;
               // growth layers: write-through (sc1), the neighbours read the halo from memory inside this launch
@@ -639,15 +583,10 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           case 14: epilogue(IC<1>{}, IC<2>{}, IC<1>{}); break;
           default: epilogue(IC<1>{}, IC<3>{}, IC<1>{}); break;
         }
-        DC_STAMP(2 + 8 * l + 3);
       }
     }
     if (giveups && lane == 0) atomicAdd(a.hdr, giveups);
   }
-  DC_STAMP(60);
-#ifdef SRGANFD_EXPERIMENT
-  if (stp && wave == 0) { const unsigned long long t_ = rnow(); if (lane == 0) stp[62] = t_; }
-#endif
   // ---- the last workgroup to finish advances the epoch for the next launch on the stream ----
   if (tid == 0) {
     const int done = atomicAdd(a.hdr + 2, 1);
@@ -658,11 +597,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-#ifdef SRGANFD_EXPERIMENT
-size_t dense_chain_workspace_bytes_impl() { return 64 + sizeof(int) * 4 * kDcMaxTiles + 8 * 256 * 1024; }      // + stamps
-#else
 size_t dense_chain_workspace_bytes_impl() { return 64 + sizeof(int) * 4 * kDcMaxTiles; }      // header + flags of 4 growth layers x tiles of one call
-#endif
 
 // Validates that `layers` are the convs of one dense chain and fills the kernel arguments at image 0's bases.
 static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
@@ -749,10 +684,6 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
   if (g_describe) { snprintf(g_describe, g_describe_len, "dense_chain_kernel<%s,%d layers>", layers[0].dtype == SRGANFD_F16 ? "f16" : "bf16", n); return SRGANFD_OK; }
   K.hdr = (int*)workspace;
   K.flags = (int*)((char*)workspace + 64);
-#ifdef SRGANFD_EXPERIMENT
-  { const char* e = getenv("SRGANFD_DC_DBG"); K.dbg = e ? atoi(e) : 0; }
-  K.stamps = getenv("SRGANFD_DC_STAMPS") ? (unsigned long long*)((char*)workspace + 64 + sizeof(int) * 4 * kDcMaxTiles) : nullptr;
-#endif
   const bool f16 = layers[0].dtype == SRGANFD_F16;
   static unsigned long long attr_done[2] = {0, 0};
   if (!g_dry_run) {

@@ -1,5 +1,5 @@
 """EXPERIMENT: in-kernel timeline of the LDS-resident dense-block launch (variant library built with -DSRGANFD_EXPERIMENT):
-    make -C sr_gan_fd_amd/csrc -j8 OUT=../libsrganfd_dcx.so EXTRA=-DSRGANFD_EXPERIMENT
+    git apply tools/experiments/r5_dense_chain_stamps.diff && make -C sr_gan_fd_amd/csrc -j8 OUT=../libsrganfd_dcx.so EXTRA=-DSRGANFD_EXPERIMENT && git checkout sr_gan_fd_amd/csrc/dense_chain.hip
     SRGANFD_LIB=$PWD/sr_gan_fd_amd/libsrganfd_dcx.so SRGANFD_DC_STAMPS=1 python tools/r5/dc_stamps.py [N H W]
 prints, per layer, the median over workgroups of wave 0's s_memtime differences (in shader-clock cycles and in us)."""
 import os, sys
