@@ -117,6 +117,9 @@ int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_le
  * srganfd_dense_chain_workspace_bytes() bytes of device memory that the caller zeroes ONCE at allocation and gives to one stream's
  * launches at a time (hand-off flags are epoch-valued from a counter in its header: nothing is zeroed per launch and a captured graph
  * replays correctly; word 0 counts hand-off waits that gave up after ~2 s -- always 0 in a correct run, results are wrong otherwise).
+ * ONE such launch at a time per device: every workgroup of a pass must be resident (one per compute unit, all of its LDS), so two
+ * concurrent launches -- two streams, or two processes sharing the GPU -- whose grids together exceed the compute units can starve
+ * each other until the waits give up.  Other kernels beside it only delay it.
  * srganfd_dense_chain_check validates `layers` and the size limits (tiles of one image <= compute units, 16384 tiles per call)
  * without launching. */
 int srganfd_dense_chain(const srganfd_conv_args* layers, int32_t n_layers, void* workspace, size_t workspace_bytes, void* stream);
