@@ -53,18 +53,33 @@ int conv_fill_k(const srganfd_conv_args* a, ConvK& k);   // conv_igemm.hip: vali
 
 namespace {
 constexpr int kDcMaxLayers = 6;      // four growth convs + the two 32-channel halves of the closing conv
-constexpr int kDcT = 16;             // tile edge
-constexpr int kDcPC = 18, kDcNPIX = kDcPC * kDcPC;
-constexpr int kDcGroupBytes = kDcNPIX * 64;          // one 32-channel group of the resident patch: 20,736 B
+constexpr int kDcTW = 16;            // tile width (one MFMA row of pixels)
+constexpr int kDcPC = 18;            // patch columns
 constexpr int kDcGroups = 6;
-constexpr int kDcSlot = 6144, kDcSlots = 5;          // weight ring: the step being read + four in flight
-constexpr int kDcRingOff = kDcGroups * kDcGroupBytes;            // 124,416
-constexpr int kDcStageOff = kDcRingOff + kDcSlots * kDcSlot;     // 155,136: hand-off staging of the four compute waves (LDS-DMA destinations)
-constexpr int kDcStageHalo = 1088, kDcStageWave = kDcStageHalo + 256;     // per wave: its 68 halo items of 16 B, then one flag word per lane
-constexpr int kDcCtlOff = kDcStageOff + 4 * kDcStageWave;        // 160,512: float alpha[8]; float bias[6][32]
-constexpr int kDcLds = kDcCtlOff + 32 + kDcMaxLayers * 32 * 4 + kDcMaxLayers * 128;      // 162,080 B: + int tab[6][32]
+constexpr int kDcSlot = 6144;        // one kernel-column step of weights: 3 kernel rows x 2 channel halves x 1 KB fragments
+// Tile geometry by rows per compute wave.  RPW = 4: 16 x 16-pixel tiles (256 pixels per CU and pass: the densest form the LDS holds).
+// RPW = 2: 8 x 16-pixel tiles for batches that fit one pass that way too: twice the workgroups, half the MFMAs, epilogue and patch per
+// workgroup -- a single-wave-per-SIMD step is bound by its instruction count and the barrier, so the shorter step is not half as long,
+// but the pass is shorter: 29.6 against 37.1 us (batch 16, 32 x 32).  (4 x 16 tiles, RPW = 1, were built and measured: 29.0 us alone,
+// but SLOWER inside the training step -- every workgroup streams the block's whole 0.96 MB of weights, and four times the workgroups
+// on cold weights is four times that stream: profiles/r05_dense_chain_tile_rows_ab.txt.)
+template <int RPW> struct DcGeo {
+  static constexpr int TR = 4 * RPW;                      // tile rows
+  static constexpr int PR = TR + 2;                       // patch rows
+  static constexpr int NPIX = PR * kDcPC;
+  static constexpr int GroupBytes = NPIX * 64;            // one 32-channel group of the resident patch: 20,736 / 11,520 B
+  static constexpr int HaloPix = 2 * kDcPC + 2 * TR;      // 68 / 52
+  static constexpr int HaloItems = HaloPix * 4;           // 16-byte items of one group's halo ring
+  static constexpr int WaveItems = HaloItems / 4;         // ... of one compute wave: 68 / 52
+  static constexpr int Slots = RPW == 4 ? 5 : 8;          // weight ring: the step being read + 4 / 7 in flight (16-row tiles: what the LDS left over holds)
+  static constexpr int RingOff = kDcGroups * GroupBytes;  // 124,416 / 69,120
+  static constexpr int StageOff = RingOff + Slots * kDcSlot;        // hand-off staging of the four compute waves (LDS-DMA destinations)
+  static constexpr int StageHalo = (WaveItems > 64 ? WaveItems : 64) * 16;       // per wave: its halo items (a full 64-lane piece first), ...
+  static constexpr int StageWave = StageHalo + 256;                 // ... then one flag word per lane
+  static constexpr int CtlOff = StageOff + 4 * StageWave;           // float alpha[8]; float bias[6][32]; int tab[6][32]
+  static constexpr int Lds = CtlOff + 32 + kDcMaxLayers * 32 * 4 + kDcMaxLayers * 128;      // 162,080 / 124,000 B
+};
 constexpr int kDcThreads = 384;      // waves 0-3 compute, 4-5 weight loaders
-constexpr int kDcHaloPix = 68, kDcHaloItems = kDcHaloPix * 4;    // 16-byte items of one group's halo ring
 constexpr int kDcMaxTiles = 16384;   // tiles of one call (flags: 4 growth layers x tiles)
 
 struct DcLayer {
@@ -83,6 +98,7 @@ struct DcK {
   int xC, x_ps, x_base, x_cs;
   int nLayers, stepsPerPass;
   int N, H, W, tiles_x, tiles_y, tpi;       // tpi: tiles per image
+  int rpw;                   // rows per compute wave: 4 (16 x 16 tiles) or 2 (8 x 16 tiles), see DcGeo
   int ipl;                   // images per pass (the grid is ipl * tpi workgroups)
   int totalTiles;            // N * tpi
   int tab[kDcMaxLayers][32]; // per layer, copied to LDS once (kernel-argument loads in the layer loop measured ~0.7k cycles per dependent round):
@@ -133,10 +149,13 @@ template <int N> __device__ __forceinline__ void dc_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #pragma clang diagnostic pop
 }
-// at most 3 * younger_steps of this loader's pieces may still be in flight (the ring holds the step being read and four more)
-__device__ __forceinline__ void dc_wait_pieces(int younger_steps) {
-  if (younger_steps >= 3) dc_wait_vm<9>(); else if (younger_steps == 2) dc_wait_vm<6>();
-  else if (younger_steps == 1) dc_wait_vm<3>(); else dc_wait_vm<0>();
+// at most 3 * younger_steps of this loader's pieces may still be in flight (the ring holds the step being read and SLOTS - 1 more:
+// when step t + 1 must have landed, steps t + 2 .. t + SLOTS - 1 are younger)
+template <int SLOTS> __device__ __forceinline__ void dc_wait_pieces(int younger_steps) {
+  constexpr int kMax = SLOTS - 2;
+  if (younger_steps >= kMax) dc_wait_vm<3 * kMax>();
+  else if (younger_steps == 5) dc_wait_vm<15>(); else if (younger_steps == 4) dc_wait_vm<12>(); else if (younger_steps == 3) dc_wait_vm<9>();
+  else if (younger_steps == 2) dc_wait_vm<6>(); else if (younger_steps == 1) dc_wait_vm<3>(); else dc_wait_vm<0>();
 }
 // workgroup barrier that leaves vector-memory operations in flight (LDS operations of this wave are complete when it is passed)
 __device__ __forceinline__ void dc_barrier() {
@@ -148,10 +167,10 @@ __device__ __forceinline__ void dc_barrier() {
 // byte position of (patch row, patch column, 16-byte slot) inside one group: pixel-major, slot XOR 2 * ((column >> 2) & 1) -- the
 // column-keyed swizzle of conv_igemm.hip's 16x16x32 fragment reads (conflict-free ds_read_b128 for every kernel column)
 __device__ __forceinline__ int dc_pos(int prow, int pcol, int slot) { return (prow * kDcPC + pcol) * 64 + ((slot ^ (((pcol >> 2) & 1) << 1)) << 4); }
-// halo ring pixel hp (0..67) of the 18 x 18 patch: top row, bottom row, left column, right column
-__device__ __forceinline__ void dc_halo_rc(int hp, int& prow, int& pcol) {
-  prow = hp < 18 ? 0 : (hp < 36 ? 17 : (hp < 52 ? 1 + hp - 36 : 1 + hp - 52));
-  pcol = hp < 18 ? hp : (hp < 36 ? hp - 18 : (hp < 52 ? 0 : 17));
+// halo ring pixel hp of the (TR + 2) x 18 patch: top row (18), bottom row (18), left column (TR), right column (TR)
+template <int TR> __device__ __forceinline__ void dc_halo_rc(int hp, int& prow, int& pcol) {
+  prow = hp < 18 ? 0 : (hp < 36 ? TR + 1 : (hp < 36 + TR ? 1 + hp - 36 : 1 + hp - 36 - TR));
+  pcol = hp < 18 ? hp : (hp < 36 ? hp - 18 : (hp < 36 + TR ? 0 : 17));
 }
 
 typedef unsigned long long dc_u64;
@@ -179,23 +198,25 @@ template <typename T> __device__ __forceinline__ dc_u32x2 dc_narrow4(const float
 }
 }  // namespace
 
-template <typename T>
+template <typename T, int RPW>
 __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   using Frag = typename FragAB<T>::type;
+  using Geo = DcGeo<RPW>;
+  constexpr int kDcGroupBytes = Geo::GroupBytes, kDcSlots = Geo::Slots, kDcStageHalo = Geo::StageHalo;
   typedef __attribute__((address_space(1))) T GT;      // an element in global memory
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const patch = smem;
-  char* const ring = smem + kDcRingOff;
-  float* const ctl_alpha = (float*)(smem + kDcCtlOff);
-  float* const ctl_bias = (float*)(smem + kDcCtlOff + 32);
-  int* const ctl_tab = (int*)(smem + kDcCtlOff + 32 + kDcMaxLayers * 32 * 4);
+  char* const ring = smem + Geo::RingOff;
+  float* const ctl_alpha = (float*)(smem + Geo::CtlOff);
+  float* const ctl_bias = (float*)(smem + Geo::CtlOff + 32);
+  int* const ctl_tab = (int*)(smem + Geo::CtlOff + 32 + kDcMaxLayers * 32 * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
 
   const int li = blockIdx.x / a.tpi, tin = blockIdx.x - li * a.tpi;       // image of the pass, tile of the image
   const int ty = tin / a.tiles_x, tx = tin - ty * a.tiles_x;
-  const int oy0 = ty * kDcT, ox0 = tx * kDcT;
+  const int oy0 = ty * Geo::TR, ox0 = tx * kDcTW;
   const size_t ipix = (size_t)a.H * a.W;
   const int npass = li < a.N ? (a.N - li + a.ipl - 1) / a.ipl : 0;
   const int totalSteps = npass * a.stepsPerPass;
@@ -204,7 +225,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
   // reads the patch any more when this runs: the last step of the previous pass has had its fragments in registers since its barrier.
   auto load_patch = [&](size_t img) {
     const T* xi = (const T*)a.x + img * a.xC + a.x_base;
-    constexpr int kItems = kDcNPIX * 8, kRounds = (kItems + kDcThreads - 1) / kDcThreads;
+    constexpr int kItems = Geo::NPIX * 8, kRounds = (kItems + kDcThreads - 1) / kDcThreads;
     u32x4 v[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
@@ -222,9 +243,9 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       const int prow = pix / kDcPC, pcol = pix - prow * kDcPC;
       if (item < kItems) *(u32x4*)(patch + g * kDcGroupBytes + dc_pos(prow, pcol, slot)) = v[r];
     }
-    for (int item = tid; item < kDcHaloItems * 4; item += kDcThreads) {
-      const int gg = item / kDcHaloItems, hi = item - gg * kDcHaloItems;
-      int prow, pcol; dc_halo_rc(hi >> 2, prow, pcol);
+    for (int item = tid; item < Geo::HaloItems * 4; item += kDcThreads) {
+      const int gg = item / Geo::HaloItems, hi = item - gg * Geo::HaloItems;
+      int prow, pcol; dc_halo_rc<Geo::TR>(hi >> 2, prow, pcol);
       *(u32x4*)(patch + (2 + gg) * kDcGroupBytes + dc_pos(prow, pcol, hi & 3)) = u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -248,24 +269,24 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       }
     };
 #pragma unroll 1
-    for (int i = 0; i < kDcSlots; ++i) issue_next();        // steps 0 .. 4
+    for (int i = 0; i < kDcSlots; ++i) issue_next();        // steps 0 .. SLOTS - 1
     int t = 0;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
       load_patch((size_t)(pass * a.ipl + li) * ipix);
-      if (pass == 0) dc_wait_pieces(3);       // slots 0 and 1 landed; later passes: the step barriers keep the ring two slots ahead
+      if (pass == 0) dc_wait_pieces<kDcSlots>(kDcSlots - 2);       // slots 0 and 1 landed; later passes: the step barriers keep the ring two slots ahead
       dc_barrier();
 #pragma unroll 1
       for (int i = 0; i < a.stepsPerPass; ++i) {
-        dc_wait_pieces(totalSteps - 2 - t);   // this wave's pieces of step t + 1 have landed: only those of steps t + 2 .. t + 4 are younger
+        dc_wait_pieces<kDcSlots>(totalSteps - 2 - t);   // this wave's pieces of step t + 1 have landed: only those of steps t + 2 .. t + 4 are younger
         dc_barrier();                         // slot t + 1 is complete for everybody; slot t is free (its fragments are in registers)
-        issue_next();                         // step t + 5 into it
+        issue_next();                         // step t + SLOTS into it
         ++t;
       }
     }
   } else {
     // =====================================================  COMPUTE WAVES  =====================================================
-    const int cw = wave;                   // rows 4 cw .. 4 cw + 3 of the tile
+    const int cw = wave;                   // rows RPW cw .. RPW cw + RPW - 1 of the tile
     // launch constants: epoch (polls and the publish use it), bias / alpha table
     const int epoch = __hip_atomic_load(a.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     if (cw == 3) {      // the per-layer table: one dword per lane and round straight from the kernel-argument segment
@@ -290,21 +311,21 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         }
       }
     }
-    const int rowoff = (4 * cw) * kDcPC * 64;
+    const int rowoff = (RPW * cw) * kDcPC * 64;
     // this wave's share of a group's halo ring: items 68 cw .. 68 cw + 67 (item = 4 * halo pixel + 16-byte slot), two rounds of lanes
     int h_off[2], h_gp[2], h_slot[2]; bool h_in[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int it = lane + 64 * r;
-      const int item = 68 * cw + (it < 68 ? it : 0);
-      int prow, pcol; dc_halo_rc(item >> 2, prow, pcol);
+      const int item = Geo::WaveItems * cw + (it < Geo::WaveItems ? it : 0);
+      int prow, pcol; dc_halo_rc<Geo::TR>(item >> 2, prow, pcol);
       const int gy = oy0 - 1 + prow, gx = ox0 - 1 + pcol;
-      h_in[r] = it < 68 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      h_in[r] = it < Geo::WaveItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       h_off[r] = dc_pos(prow, pcol, item & 3);
       h_slot[r] = item & 3;
       h_gp[r] = h_in[r] ? gy * a.W + gx : 0;          // lanes without an item read pixel 0 of the image (a valid address) and drop it
     }
-    char* const stage = smem + kDcStageOff + cw * kDcStageWave;        // this wave's hand-off staging: 68 halo items, then 64 flag words
+    char* const stage = smem + Geo::StageOff + cw * Geo::StageWave;        // this wave's hand-off staging: 68 halo items, then 64 flag words
     const unsigned stage_lds = dc_lds_addr(stage);
     // the eight neighbours (3 x 3 without the centre) of this tile, one per lane 0 .. 7
     const int nq = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       const int col = l15 + kx;
       const char* pa = patch + c * kDcGroupBytes + rowoff + (col << 6) + ((g4 ^ ((col >> 1) & 2)) << 4);
 #pragma unroll
-      for (int rr = 0; rr < 6; ++rr) fp[rr] = *(const Frag*)(pa + rr * (kDcPC * 64));
+      for (int rr = 0; rr < RPW + 2; ++rr) fp[rr] = *(const Frag*)(pa + rr * (kDcPC * 64));
       const char* rs = ring + (tt % kDcSlots) * kDcSlot + lane * 16;
 #pragma unroll
       for (int q = 0; q < 6; ++q) fw[q] = *(const Frag*)(rs + q * 1024);
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
     __builtin_amdgcn_s_setprio(2);
     int t = 0;        // kernel-column steps consumed so far (all passes): ring slot t % 6
     int giveups = 0;
-    const int orow0 = oy0 + 4 * cw, ocol = ox0 + l15;
+    const int orow0 = oy0 + RPW * cw, ocol = ox0 + l15;
     const bool col_ok = ocol < a.W;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
       const int gtile = n * a.tpi + tin;
       load_patch(img);
       dc_barrier();
-      Frag Aw[6], Ap[6], Bw[6], Bp[6];       // two fragment sets: a step computes on one while the next step's are read into the other
+      Frag Aw[6], Ap[RPW + 2], Bw[6], Bp[RPW + 2];       // two fragment sets: a step computes on one while the next step's are read into the other
       load_frags(Aw, Ap, 0, 0, t);
 
 #pragma unroll 1
@@ -354,11 +375,12 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         // after the publish always reads the old value: everybody publishes at the same time), looked at and halo requested behind barrier
         // s_chk, halo moved from the staging area into the patch behind barrier s_wr (visible behind barrier s_wr + 1 <= 3 (nCh - 1) - 1).
         // conv2 (3 chunks) has no room for that: it waits at step 4; from conv4 on everything is hidden.
-        const int s_poll = nCh <= 4 ? 3 : nCh - 1, s_chk = nCh == 3 ? 4 : 2 * nCh - 3, s_wr = nCh == 3 ? 4 : 3 * nCh - 5;
+        // (8-row tiles: the steps are shorter, the round trips are not: everything one step later where the layer has room)
+        const int s_poll = nCh <= 3 ? 3 : (RPW == 4 ? (nCh == 4 ? 3 : nCh - 1) : nCh), s_chk = nCh == 3 ? 4 : (RPW == 4 ? 2 * nCh - 3 : 2 * nCh - 2), s_wr = nCh == 3 ? 4 : 3 * nCh - 5;
         const bool growth = dst_group >= 0;
-        f32x4_t acc[4][2];       // [row][16-channel half]
+        f32x4_t acc[RPW][2];     // [row][16-channel half]
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < RPW; ++m)
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) acc[m][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
               const int cc = Py_c0 + 8 * h_slot[0];
               dc_glds16_sc1(yi + ((size_t)h_gp[0] * Py_ps + (size_t)(cc >> 5) * Py_gs + (cc & 31)), stage_lds);
             }
-            if (lane < 4) {
+            if (Geo::WaveItems > 64 && lane < Geo::WaveItems - 64) {
               const int cc = Py_c0 + 8 * h_slot[1];
               dc_glds16_sc1(yi + ((size_t)h_gp[1] * Py_ps + (size_t)(cc >> 5) * Py_gs + (cc & 31)), stage_lds + 1024);
             }
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             dc_wait_vm<0>();       // the halo items have landed in the staging area
             char* pg = patch + __builtin_amdgcn_readfirstlane(tl[1 - 32]) * kDcGroupBytes;
             if (h_in[0]) *(u32x4*)(pg + h_off[0]) = *(const u32x4*)(stage + 16 * lane);
-            if (lane < 4 && h_in[1]) *(u32x4*)(pg + h_off[1]) = *(const u32x4*)(stage + 1024 + 16 * lane);
+            if (Geo::WaveItems > 64 && h_in[1]) *(u32x4*)(pg + h_off[1]) = *(const u32x4*)(stage + 1024 + 16 * lane);
           }
         };
 
@@ -419,18 +441,19 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
           load_frags(NW, NP, cn_, kxn_, t + 1);                                                                     \
           _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                          \
             _Pragma("unroll") for (int nh = 0; nh < 2; ++nh)                                                        \
-              _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
-          /* issue order: the NEXT step's 12 fragment reads spread over this step's first 16 MFMAs (the scheduler would otherwise sink   \
-             the reads to the end of the step to shorten their live ranges, and the next step would start by waiting for them) */ \
-          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+              _Pragma("unroll") for (int m = 0; m < RPW; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
+          /* issue order: the NEXT step's fragment reads (RPW + 2 pixel rows + 6 weight pieces) spread over this step's first MFMAs   \
+             (the scheduler would otherwise sink the reads to the end of the step to shorten their live ranges, and the next step     \
+             would start by waiting for them): 16 rows: 12 reads behind MFMAs 0-7, 9, 11, 13, 15 of 24; 8 rows: 10 behind MFMAs 0-9 of 12 */                         \
+          _Pragma("unroll") for (int i_ = 0; i_ < (RPW == 4 ? 8 : 10); ++i_) {                                      \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
           }                                                                                                         \
-          _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+          _Pragma("unroll") for (int i_ = 0; i_ < (RPW == 4 ? 4 : 0); ++i_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
           }                                                                                                         \
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                        \
+          __builtin_amdgcn_sched_group_barrier(0x008, RPW == 4 ? 8 : 2, 0);                                         \
           c = cn_; kx = kxn_;                                                                                       \
           ++t;                                                                                                      \
         }
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         // epilogue operands of this lane's 4 pixels: slot A = r1 or mask, slot B = r2.  Loaded as ONE 16-byte slot per pixel (slot
         // {0, 2, 1, 3}[g4], the layout the epilogue stores in) and turned into this lane's two channel quads by v_permlane16_swap in the
         // epilogue (the swap is its own inverse): 4 load instructions per operand instead of 8 (16 requests of 8 bytes per wave took ~2.7k cycles to issue)
-        u32x4 rA[4], rB[4];
+        u32x4 rA[RPW], rB[RPW];
         T* ydst;                 // this lane's first output element (row 4 cw, 16-byte slot {0, 2, 1, 3}[g4] of its pixel)
         int yrow;                // elements per image row of the output
         {
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             const int a_ps = rfl(t4.y);
             const GT* pa = opA + img * rfl(t4.x) + ((size_t)p0 * a_ps + (size_t)(rfl(t4.w) >> 5) * rfl(t4.z) + 8 * sl16);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < RPW; ++m) {
               const GT* pm = orow0 + m < a.H ? pa + (size_t)m * a.W * a_ps : pa;
               rA[m] = *(const __attribute__((address_space(1))) u32x4*)pm;
             }
@@ -487,7 +510,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             const int b_ps = rfl(t5.w);
             const GT* pb = opB + img * rfl(t5.z) + ((size_t)p0 * b_ps + (size_t)(rfl(t6.y) >> 5) * rfl(t6.x) + 8 * sl16);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < RPW; ++m) {
               const GT* pm = orow0 + m < a.H ? pb + (size_t)m * a.W * b_ps : pb;
               rB[m] = *(const __attribute__((address_space(1))) u32x4*)pm;
             }
@@ -502,7 +525,9 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         if (s < ns) {      // 3 or 5 chunks: an odd number of steps -- the next layer starts on set A like every layer
           DC_STEP(s, Aw, Ap, Bw, Bp)
 #pragma unroll
-          for (int q = 0; q < 6; ++q) { Aw[q] = Bw[q]; Ap[q] = Bp[q]; }
+          for (int q = 0; q < 6; ++q) Aw[q] = Bw[q];
+#pragma unroll
+          for (int q = 0; q < RPW + 2; ++q) Ap[q] = Bp[q];
         }
 #undef DC_STEP
 
@@ -514,13 +539,13 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
         const float alpha = ctl_alpha[l];
         const f32x4_t b0 = *(const f32x4_t*)(ctl_bias + l * 32 + 4 * g4), b1 = *(const f32x4_t*)(ctl_bias + l * 32 + 16 + 4 * g4);
         const int sl16 = ((g4 & 1) << 1) | (g4 >> 1);
-        char* const lds_out = patch + (growth ? dst_group : 0) * kDcGroupBytes + dc_pos(4 * cw + 1, l15 + 1, sl16);
+        char* const lds_out = patch + (growth ? dst_group : 0) * kDcGroupBytes + dc_pos(RPW * cw + 1, l15 + 1, sl16);
         T* const y16 = ydst;
         auto epilogue = [&](auto growth_c, auto ops_c, auto max_c) {
           constexpr bool GROWTH = decltype(growth_c)::v != 0, MAXACT = decltype(max_c)::v != 0;
           constexpr int OPS = decltype(ops_c)::v;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
+          for (int m = 0; m < RPW; ++m) {
             const bool ok = col_ok && orow0 + m < a.H;
             dc_u32x2 pk[2], eA[2], eB[2];
             if constexpr (OPS >= 1) {
@@ -655,16 +680,20 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
   }
   K.nLayers = nl; K.stepsPerPass = steps;
   K.N = a0.n; K.H = a0.h_in; K.W = a0.w_in;
-  K.tiles_x = ceil_div(K.W, kDcT); K.tiles_y = ceil_div(K.H, kDcT);
+  const int cus = conv_device_cus();
+  // 8 x 16 tiles when the whole batch is one pass that way too (twice the workgroups, a shorter pass); else 16 x 16 (the densest form)
+  K.tiles_x = ceil_div(K.W, kDcTW);
+  K.rpw = (long long)K.N * K.tiles_x * ceil_div(K.H, 8) <= cus ? 2 : 4;
+  if (const char* e = getenv("SRGANFD_DC_RPW")) { const int v = atoi(e); if (v == 2 || v == 4) K.rpw = v; }      // same-box A/B switch
+  K.tiles_y = ceil_div(K.H, 4 * K.rpw);
   K.tpi = K.tiles_x * K.tiles_y;
   K.totalTiles = K.N * K.tpi;
-  const int cus = conv_device_cus();
   K.ipl = K.tpi > cus ? 0 : (cus / K.tpi < K.N ? cus / K.tpi : K.N);      // every tile of a pass must be resident at once (one workgroup per CU)
   return SRGANFD_OK;
 }
 
 static int dense_chain_limits(const DcK& K) {
-  if (K.ipl < 1) return set_err(SRGANFD_EINVAL, "dense_chain: one image is %d tiles of 16 x 16, more than the device has CUs", K.tpi);
+  if (K.ipl < 1) return set_err(SRGANFD_EINVAL, "dense_chain: one image is %d tiles of %d x 16, more than the device has CUs", K.tpi, 4 * K.rpw);
   if (K.totalTiles > kDcMaxTiles) return set_err(SRGANFD_EINVAL, "dense_chain: %d tiles in one call (limit %d)", K.totalTiles, kDcMaxTiles);
   return SRGANFD_OK;
 }
@@ -685,19 +714,26 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
   K.hdr = (int*)workspace;
   K.flags = (int*)((char*)workspace + 64);
   const bool f16 = layers[0].dtype == SRGANFD_F16;
-  static unsigned long long attr_done[2] = {0, 0};
+  const int variant = (f16 ? 1 : 0) + (K.rpw == 2 ? 2 : 0);
+  const void* const kerns[4] = {(const void*)dense_chain_kernel<bf16_t, 4>, (const void*)dense_chain_kernel<f16_t, 4>, (const void*)dense_chain_kernel<bf16_t, 2>,
+                                (const void*)dense_chain_kernel<f16_t, 2>};
+  const int lds = K.rpw == 2 ? DcGeo<2>::Lds : DcGeo<4>::Lds;
+  static unsigned long long attr_done[4] = {0, 0, 0, 0};
   if (!g_dry_run) {
     int dev = 0;
     SRGANFD_HIP_CHECK(hipGetDevice(&dev));
-    if (!(attr_done[f16] >> (dev & 63) & 1ULL)) {
-      if (f16) SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_chain_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kDcLds));
-      else SRGANFD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_chain_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kDcLds));
-      attr_done[f16] |= 1ULL << (dev & 63);
+    if (!(attr_done[variant] >> (dev & 63) & 1ULL)) {
+      SRGANFD_HIP_CHECK(hipFuncSetAttribute(kerns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_done[variant] |= 1ULL << (dev & 63);
     }
   }
   const unsigned grid = (unsigned)(K.ipl * K.tpi);
-  if (f16) SRGANFD_LAUNCH(dense_chain_kernel<f16_t>, dim3(grid), dim3(kDcThreads), kDcLds, stream, K);
-  else SRGANFD_LAUNCH(dense_chain_kernel<bf16_t>, dim3(grid), dim3(kDcThreads), kDcLds, stream, K);
+  switch (variant) {
+    case 0: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 4>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    case 1: SRGANFD_LAUNCH((dense_chain_kernel<f16_t, 4>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    case 2: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 2>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    default: SRGANFD_LAUNCH((dense_chain_kernel<f16_t, 2>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+  }
   SRGANFD_HIP_CHECK(hipGetLastError());
   return SRGANFD_OK;
 }
