@@ -109,7 +109,7 @@ int srganfd_conv2d_describe(const srganfd_conv_args* a, char* out, size_t out_le
  * A-ESRGAN/model.py:441-452 are the same code) -- or of its data-gradient pass, which is the same dense structure over the stacked
  * output gradients -- when an image is at most one 16 x 16-pixel tile per compute unit (the reference's crop sizes: 32 ... 72 pixels
  * at batch 8-16; faster than the separate launches while the whole batch is at most one tile per compute unit; the library tiles
- * 8 x 16 instead when the batch is one pass that way too).  `layers` are exactly
+ * 8 x 16, else 12 x 16, instead when the batch is one pass that way too).  `layers` are exactly
  * the arguments those launches would get, in order: layer i (0-based) is a 16-bit 3x3 stride-1 pad-1 conv reading channels
  * [0, 64 + 32 i) of ONE buffer; all but the last write 32 channels at [64 + 32 i, 96 + 32 i) of that same buffer (bias / activation /
  * mask as given), the last one (64 output channels, r1 / r2 as given) writes anywhere else.  Per layer either a mask or residuals

@@ -58,7 +58,7 @@ constexpr int kDcPC = 18;            // patch columns
 constexpr int kDcGroups = 6;
 constexpr int kDcSlot = 6144;        // one kernel-column step of weights: 3 kernel rows x 2 channel halves x 1 KB fragments
 // Tile geometry by rows per compute wave.  RPW = 4: 16 x 16-pixel tiles (256 pixels per CU and pass: the densest form the LDS holds).
-// RPW = 2: 8 x 16-pixel tiles for batches that fit one pass that way too: twice the workgroups, half the MFMAs, epilogue and patch per
+// RPW = 2 (3): 8 x 16- (12 x 16-) pixel tiles for batches that fit one pass that way too: more workgroups, fewer MFMAs, a shorter epilogue and a smaller patch per
 // workgroup -- a single-wave-per-SIMD step is bound by its instruction count and the barrier, so the shorter step is not half as long,
 // but the pass is shorter: 29.6 against 37.1 us (batch 16, 32 x 32).  (4 x 16 tiles, RPW = 1, were built and measured: 29.0 us alone,
 // but SLOWER inside the training step -- every workgroup streams the block's whole 0.96 MB of weights, and four times the workgroups
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
               _Pragma("unroll") for (int m = 0; m < RPW; ++m) acc[m][nh] = mfma16<T>(CW[ky * 2 + nh], CP[m + ky], acc[m][nh]); \
           /* issue order: the NEXT step's fragment reads (RPW + 2 pixel rows + 6 weight pieces) spread over this step's first MFMAs   \
              (the scheduler would otherwise sink the reads to the end of the step to shorten their live ranges, and the next step     \
-             would start by waiting for them): 16 rows: 12 reads behind MFMAs 0-7, 9, 11, 13, 15 of 24; 8 rows: 10 behind MFMAs 0-9 of 12 */                         \
-          _Pragma("unroll") for (int i_ = 0; i_ < (RPW == 4 ? 8 : 10); ++i_) {                                      \
+             would start by waiting for them): 16 rows: 12 reads behind MFMAs 0-7, 9, 11, 13, 15 of 24; 12 / 8 rows: 11 / 10 reads behind the first 11 / 10 of 18 / 12 */   \
+          _Pragma("unroll") for (int i_ = 0; i_ < (RPW == 4 ? 8 : RPW + 8); ++i_) {                                 \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
           }                                                                                                         \
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kDcThreads) void dense_chain_kernel(const DcK a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
           }                                                                                                         \
-          __builtin_amdgcn_sched_group_barrier(0x008, RPW == 4 ? 8 : 2, 0);                                         \
+          __builtin_amdgcn_sched_group_barrier(0x008, RPW == 4 ? 8 : 5 * RPW - 8, 0);                               \
           c = cn_; kx = kxn_;                                                                                       \
           ++t;                                                                                                      \
         }
@@ -681,10 +681,10 @@ static int dense_chain_fill(const srganfd_conv_args* layers, int n, DcK& K) {
   K.nLayers = nl; K.stepsPerPass = steps;
   K.N = a0.n; K.H = a0.h_in; K.W = a0.w_in;
   const int cus = conv_device_cus();
-  // 8 x 16 tiles when the whole batch is one pass that way too (twice the workgroups, a shorter pass); else 16 x 16 (the densest form)
+  // 8 x 16 (else 12 x 16) tiles when the whole batch is one pass that way too (more workgroups, a shorter pass); else 16 x 16 (the densest form)
   K.tiles_x = ceil_div(K.W, kDcTW);
-  K.rpw = (long long)K.N * K.tiles_x * ceil_div(K.H, 8) <= cus ? 2 : 4;
-  if (const char* e = getenv("SRGANFD_DC_RPW")) { const int v = atoi(e); if (v == 2 || v == 4) K.rpw = v; }      // same-box A/B switch
+  K.rpw = (long long)K.N * K.tiles_x * ceil_div(K.H, 8) <= cus ? 2 : ((long long)K.N * K.tiles_x * ceil_div(K.H, 12) <= cus ? 3 : 4);
+  if (const char* e = getenv("SRGANFD_DC_RPW")) { const int v = atoi(e); if (v >= 2 && v <= 4) K.rpw = v; }      // same-box A/B switch
   K.tiles_y = ceil_div(K.H, 4 * K.rpw);
   K.tpi = K.tiles_x * K.tiles_y;
   K.totalTiles = K.N * K.tpi;
@@ -714,11 +714,11 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
   K.hdr = (int*)workspace;
   K.flags = (int*)((char*)workspace + 64);
   const bool f16 = layers[0].dtype == SRGANFD_F16;
-  const int variant = (f16 ? 1 : 0) + (K.rpw == 2 ? 2 : 0);
-  const void* const kerns[4] = {(const void*)dense_chain_kernel<bf16_t, 4>, (const void*)dense_chain_kernel<f16_t, 4>, (const void*)dense_chain_kernel<bf16_t, 2>,
-                                (const void*)dense_chain_kernel<f16_t, 2>};
-  const int lds = K.rpw == 2 ? DcGeo<2>::Lds : DcGeo<4>::Lds;
-  static unsigned long long attr_done[4] = {0, 0, 0, 0};
+  const int variant = (f16 ? 1 : 0) + 2 * (4 - K.rpw);       // rows per wave 4, 3, 2 x {bf16, f16}
+  const void* const kerns[6] = {(const void*)dense_chain_kernel<bf16_t, 4>, (const void*)dense_chain_kernel<f16_t, 4>, (const void*)dense_chain_kernel<bf16_t, 3>,
+                                (const void*)dense_chain_kernel<f16_t, 3>, (const void*)dense_chain_kernel<bf16_t, 2>, (const void*)dense_chain_kernel<f16_t, 2>};
+  const int lds = K.rpw == 2 ? DcGeo<2>::Lds : (K.rpw == 3 ? DcGeo<3>::Lds : DcGeo<4>::Lds);
+  static unsigned long long attr_done[6] = {0, 0, 0, 0, 0, 0};
   if (!g_dry_run) {
     int dev = 0;
     SRGANFD_HIP_CHECK(hipGetDevice(&dev));
@@ -731,7 +731,9 @@ int dense_chain_impl(const srganfd_conv_args* layers, int n, void* workspace, si
   switch (variant) {
     case 0: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 4>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
     case 1: SRGANFD_LAUNCH((dense_chain_kernel<f16_t, 4>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
-    case 2: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 2>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    case 2: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 3>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    case 3: SRGANFD_LAUNCH((dense_chain_kernel<f16_t, 3>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
+    case 4: SRGANFD_LAUNCH((dense_chain_kernel<bf16_t, 2>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
     default: SRGANFD_LAUNCH((dense_chain_kernel<f16_t, 2>), dim3(grid), dim3(kDcThreads), lds, stream, K); break;
   }
   SRGANFD_HIP_CHECK(hipGetLastError());

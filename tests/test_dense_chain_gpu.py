@@ -1,4 +1,4 @@
-"""LDS-resident dense-block launch (csrc/dense_chain.hip, srganfd_dense_chain; 16 x 16- or 8 x 16-pixel tiles, one per CU and pass) against the separate srganfd_conv2d launches it replaces:
+"""LDS-resident dense-block launch (csrc/dense_chain.hip, srganfd_dense_chain; 16 x 16-, 12 x 16- or 8 x 16-pixel tiles, one per CU and pass) against the separate srganfd_conv2d launches it replaces:
 the five convs of _ResidualDenseBlock.forward (BSRGAN/model.py:51-62: four growth convs with bias + LeakyReLU written into the block's
 own buffer, the closing 192 -> 64 conv with the residual epilogue) and the five launches of its data-gradient pass (masks from the saved
 activations, residual adds on the closing launch), at the reference's crop sizes and at ragged ones, NHWC and planar buffers, several
@@ -50,14 +50,14 @@ def _build(dtype, n, h, w, planar, backward, seed=0):
     return args, (buf, out), keep
 
 
-@pytest.mark.parametrize("rows", [None, 16], ids=["tile-rows-auto", "tile-rows-16"])
+@pytest.mark.parametrize("rows", [None, 12, 16], ids=["tile-rows-auto", "tile-rows-12", "tile-rows-16"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("backward", [False, True], ids=["forward", "data-gradient"])
 @pytest.mark.parametrize("shape", [(2, 16, 32, 1), (3, 21, 45, 1), (16, 32, 32, 1), (8, 60, 60, 1), (16, 72, 72, 1), (2, 24, 40, 0), (1, 8, 8, 1)],
                          ids=lambda s: "n%d_%dx%d_%s" % (s[0], s[1], s[2], "planar" if s[3] else "nhwc"))
 def test_dense_chain_equals_the_separate_launches(dtype, backward, shape, rows, monkeypatch):
-    """(the library picks 8 x 16 tiles when the batch is one pass that way -- every shape here but 16 x 72 x 72 -- and 16 x 16 otherwise;
-    ``rows`` = 16 forces the 16-row form everywhere through the A/B switch SRGANFD_DC_RPW)"""
+    """(the library picks 8 x 16 tiles when the batch is one pass that way -- every shape here but 16 x 72 x 72 --, else 12 x 16, else
+    16 x 16; ``rows`` forces one form everywhere through the A/B switch SRGANFD_DC_RPW)"""
     from sr_gan_fd_amd import ops
     if rows is not None:
         monkeypatch.setenv("SRGANFD_DC_RPW", str(rows // 4))
