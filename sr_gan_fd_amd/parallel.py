@@ -36,7 +36,37 @@ def init_from_env(backend: Optional[str] = None):
         kw["device_id"] = torch.device("cuda", local_rank)
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    dense_chain_needs_its_own_gpu(torch.device('cuda', local_rank) if torch.cuda.is_available() else None, dist.group.WORLD)
     return rank, local_rank, world, dist.group.WORLD
+
+
+def dense_chain_needs_its_own_gpu(device, pg, identity=None) -> bool:
+    """The LDS-resident dense-block launch (csrc/dense_chain.hip) needs every workgroup of a pass resident at once, one per compute
+    unit: two processes that share a GPU could hold compute units each other's launches wait for.  Ranks that find another rank of
+    ``pg`` on their device (same host, same PCI address) keep the per-layer launches -- unless SRGANFD_DENSE_CHAIN=1 insists.
+    Called by init_from_env and by the trainers' reducers (plans are made at the first step, after this).  True: switched off.
+    ``identity`` replaces (host, PCI address) in the host tests."""
+    from . import ops
+    if pg is None or os.environ.get("SRGANFD_DENSE_CHAIN") == "1":
+        return False
+    if identity is None:
+        if device is None or torch.device(device).type != "cuda":
+            return False
+        import socket
+        p = torch.cuda.get_device_properties(device)
+        pci = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        index = torch.device(device).index
+        identity = (socket.gethostname(),) + (pci if pci[1] is not None else ("index", torch.cuda.current_device() if index is None else index))
+    everyone = [None] * dist.get_world_size(pg)
+    if torch.device(device if device is not None else "cpu").type == "cuda":
+        with torch.cuda.device(device):        # an RCCL object collective stages through the CURRENT device
+            dist.all_gather_object(everyone, identity, group=pg)
+    else:
+        dist.all_gather_object(everyone, identity, group=pg)
+    if everyone.count(identity) > 1:
+        ops.DENSE_CHAIN = "0"
+        return True
+    return False
 
 
 def allreduce_sum_(flat_grad: torch.Tensor, pg) -> float:
@@ -102,6 +132,7 @@ class BucketReducer:
         self.world = dist.get_world_size(pg) if pg is not None else 1
         self.stream = torch.cuda.Stream(device=device) if pg is not None and torch.device(device).type == "cuda" else None
         self.sizes = []                   # elements per bucket of the last backward pass (tests look at it)
+        dense_chain_needs_its_own_gpu(device, pg)
 
     def begin(self) -> None:
         self.sizes = []

@@ -54,7 +54,14 @@ def _worker(rank, world, port, q):
     ok4 = torch.allclose(gl * sc, gfull, atol=1e-6)
     t = P.max_over_ranks(float(rank + 1), pg, "cpu")
     ok5 = t == float(world)
-    q.put((rank, ok1, ok2, ok3, ok4, ok5))
+    # 6. ranks that share a GPU keep the per-layer launches (the dense-block launch needs a GPU's compute units to itself)
+    from sr_gan_fd_amd import ops
+    before = ops.DENSE_CHAIN
+    apart = P.dense_chain_needs_its_own_gpu(None, pg, identity=("host", 0, rank, 0))
+    ok6 = not apart and ops.DENSE_CHAIN == before and not P.dense_chain_needs_its_own_gpu("cpu", pg)
+    shared = P.dense_chain_needs_its_own_gpu(None, pg, identity=("host", 0, 5, 0))
+    ok6 = ok6 and shared and ops.DENSE_CHAIN == "0" and not ops.dense_chain_wanted(1, 16, 16)
+    q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6))
     dist.destroy_process_group()
 
 

@@ -59,6 +59,8 @@ CHILD = textwrap.dedent("""
         kw = dict(g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1, sync_batchnorm=True) if aes else {}
         t1 = GanTrainer(g1, d1, None, process_group=pg, **kw)
         assert t1.g_reducer.stream is not None and t1.d_reducer.stream is not None        # the exchanges really run off the main stream
+        from sr_gan_fd_amd import ops
+        assert ops.DENSE_CHAIN == "0"      # two ranks on one GPU: the dense-block launch (one workgroup per CU, all resident) is switched off
         part = [t1.step(shard(x), shard(y)).cpu().numpy().copy() for x, y in batches]
         torch.cuda.synchronize()
         # every rank must hold the same parameters (they saw the same all-reduced gradients) ...
