@@ -49,6 +49,9 @@ def label(kernel: str):
     m = re.search(r"thin_in_kernel<([^,]+), (true|false)", kernel)          # ops.ThinLaunch.label
     if m:
         return "thin_in_kernel<%s%s>" % (TY.get(m.group(1), m.group(1)), ",mask" if m.group(2) == "true" else "")
+    m = re.search(r"dense_chain_kernel<([^,>]+), (\d+)>", kernel)              # ops.DenseChain (rows per compute wave -> tile rows)
+    if m:
+        return "dense_chain_kernel<%s,tile=%dx16>" % (TY.get(m.group(1), m.group(1)), 4 * int(m.group(2)))
     m = re.search(r"(thin_out|thin_wgrad)_kernel<([^,>]+)>", kernel)
     if m:
         return "%s_kernel<%s>" % (m.group(1), TY.get(m.group(2), m.group(2)))
