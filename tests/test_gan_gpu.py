@@ -643,6 +643,8 @@ def test_bucketed_generator_exchange_equals_inline(monkeypatch):
         t.mul_(1.0)                                   # a kernel on the reducer's stream that reads and rewrites the whole range
     monkeypatch.setattr(P.dist, "all_reduce", fake_all_reduce)
     monkeypatch.setattr(P.dist, "get_world_size", lambda pg=None: 1)
+    # BucketReducer asks the group who shares its GPU (parallel.dense_chain_needs_its_own_gpu): the one-rank stand-in answers with itself
+    monkeypatch.setattr(P.dist, "all_gather_object", lambda out, obj, group=None: out.__setitem__(slice(None), [obj]))
     torch.manual_seed(12)
     batches = [(torch.rand(2, 3, 16, 16).cuda(), torch.rand(2, 3, 64, 64).cuda()) for _ in range(2)]
 
