@@ -72,7 +72,7 @@ def test_two_rank_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]      # generous: on a cold page cache two spawned ranks importing torch take minutes
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -130,7 +130,7 @@ def test_trainers_exchange_one_flat_gradient_per_network():
     res = []
     import queue, time
     t0 = time.time()
-    while len(res) < len(procs) and time.time() - t0 < 300:
+    while len(res) < len(procs) and time.time() - t0 < 900:      # generous: this test failed once in a 492 s suite run that shared the host with a compile job (85 s alone); cause not captured, 300 s was the limit then
         try:
             res.append(q.get(timeout=2))
         except queue.Empty:
@@ -219,7 +219,7 @@ def test_world8_dry_run_of_the_configs3_and_configs4_partition():
     res = []
     import queue, time
     t0 = time.time()
-    while len(res) < len(procs) and time.time() - t0 < 600:
+    while len(res) < len(procs) and time.time() - t0 < 1200:
         try:
             res.append(q.get(timeout=2))
         except queue.Empty:
