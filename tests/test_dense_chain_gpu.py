@@ -129,3 +129,61 @@ def test_dense_chain_beside_kernels_of_another_stream():
         torch.cuda.synchronize()
         assert chain.errors() == 0
         assert torch.equal(buf_dc, want_b) and torch.equal(out_dc, want_o)
+
+
+@pytest.mark.parametrize("batch,size,num_rrdb,rows", [
+    (16, 32, 23, 8),      # ESRGAN/esrgan_config.py:73-74, the whole 23-RRDB generator: 128 tiles of 8 x 16
+    (16, 48, 4, 12),      # ESRGAN/rrdbnet_config.py:51-52: 192 tiles of 12 x 16
+    (4, 128, 2, 16),      # batch 4 at the headline crop: 256 tiles of 16 x 16
+])
+def test_generator_iteration_at_the_reference_crops_through_the_launch_meets_the_tolerance(batch, size, num_rrdb, rows):
+    """A generator-only training iteration (train_rrdbnet.py:244-267) in float16 -- the scripts' autocast dtype -- at the crop sizes the
+    reference's configs ship, where the engine takes the dense-block launch for every dense block, forward and data gradient: SR and
+    loss against the fp32 CPU oracle within BASELINE.json's 1e-3 (SR absolute, loss relative), the Adam update against the oracle's as one
+    relative L2 norm (< 2e-2: f16 gradients; measured 1.3e-3 ... 7.1e-3), and the same iteration with the per-layer launches (SRGANFD_DENSE_CHAIN=0) within one
+    16-bit rounding's propagation of it (SR 2e-4; measured: identical bits, SR max error against the oracle 6.0e-4 at 23 RRDB)."""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M, ops
+    from sr_gan_fd_amd.trainer import GeneratorTrainer
+    from tests.util import scaled_init
+    torch.manual_seed(5)
+    lr_img, gt = torch.rand(batch, 3, size, size), torch.rand(batch, 3, 4 * size, 4 * size)
+
+    def gen():
+        torch.manual_seed(0)
+        g = M.bsrgan_x4(num_rrdb=num_rrdb)
+        scaled_init(g, 3.0, 0.5)
+        return g
+    g0 = gen()
+    G = {k: v.detach().clone() for k, v in g0.state_dict().items()}
+    G0 = {k: v.clone() for k, v in G.items()}
+    opt = O.AdamState(G, O.g_param_names(G))
+    want_loss, want_sr = O.g_only_step(G, opt, lr_img, gt, upscale=4, lr=1e-4, betas=(0.9, 0.99), eps=1e-4)
+    res = {}
+    old = ops.DENSE_CHAIN
+    try:
+        for mode in ("auto", "0"):
+            ops.DENSE_CHAIN = mode
+            g = gen()
+            g.compute_dtype = torch.float16
+            tr = GeneratorTrainer(g.cuda().train(), lr=1e-4, betas=(0.9, 0.99), eps=1e-4, ema_decay=0.999)
+            loss = tr.step(lr_img.cuda(), gt.cuda())
+            torch.cuda.synchronize()
+            sp = tr.eng._last
+            chains = [a for a in sp.fw if type(a) is ops.DenseChain] + [it[1] for it in sp.bw if it[0] == "chain"]
+            assert len(chains) == (6 * num_rrdb if mode == "auto" else 0), (mode, len(chains))
+            if mode == "auto":
+                assert ops.dense_chain_giveups(torch.device("cuda", torch.cuda.current_device())) == 0
+            res[mode] = (loss.item(), tr.sr.float().cpu(), {k: v.detach().float().cpu() for k, v in g.state_dict().items()})
+    finally:
+        ops.DENSE_CHAIN = old
+    loss, sr, sd = res["auto"]
+    err_sr = (sr - want_sr).abs().max().item()
+    num = sum(((sd[k] - G[k]) ** 2).sum().item() for k in G)
+    den = sum(((G[k] - G0[k]) ** 2).sum().item() for k in G)
+    err_w = (num / den) ** 0.5
+    d_sr = (sr - res["0"][1]).abs().max().item()
+    print(f"batch {batch} {size}->{4 * size}, {num_rrdb} RRDB, {rows} x 16 tiles: loss {loss:.6f} (oracle {want_loss:.6f}), SR max err {err_sr:.2e}, "
+          f"Adam-update rel L2 err {err_w:.2e}; per-layer launches: loss {res['0'][0]:.6f}, SR diff {d_sr:.2e}")
+    assert abs(loss - want_loss) < 1e-3 * abs(want_loss) and err_sr < 1e-3 and err_w < 2e-2
+    assert d_sr < 2e-4 and abs(loss - res["0"][0]) < 1e-4 * abs(want_loss)
