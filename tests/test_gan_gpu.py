@@ -293,6 +293,40 @@ def test_gan_steps_f16_trainer_vs_reference(golden_dir):
     assert rep["optimizer_steps"] == 4 and rep["skipped"] == 0, rep
 
 
+def test_gan_iteration_at_the_bsrgan_default_crop_f16_vs_oracle():
+    """bsrgan_config.py:62,101-102: x2, LR crops of 72 x 72 (GT 144 x 144), the 23-RRDB generator -- the ragged case of every tile shape of the
+    engines (72 = 4.5 x 16 rows = 2.25 x 32 columns in the trunk, 144 = 4.5 x 32 in the tail, the discriminator and its stride-2 stages at
+    144 / 72 / 36 / 18) and the shape whose dense blocks stay on the per-layer launches.  One GAN iteration (train_bsrgan.py:387-483,
+    content term off: no VGG weights in the reference tree) in float16, the scripts' autocast dtype, against the fp32 CPU oracle; batch 4
+    instead of 16 keeps the oracle at seconds (tiles are per image: the launches differ in count only).  Asserted: every logged scalar
+    within 1e-3 relative, probed parameters after both Adam steps within 5e-3 of the tensor's range (as the fixture-based f16 test)."""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M
+    from sr_gan_fd_amd.gan import GanTrainer
+    torch.manual_seed(9)
+    lr_img, gt = torch.rand(4, 3, 72, 72), torch.rand(4, 3, 144, 144)
+    torch.manual_seed(0)
+    d = M.discriminator_unet(in_channels=3, out_channels=1, channels=64)
+    gen = M.bsrgan_x2(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
+    scaled_init(gen, 3.0, 0.5)
+    G, D = sd_to_params(gen.state_dict()), sd_to_params(d.state_dict(), d=True)
+    g_opt, d_opt = O.AdamState(G, O.g_param_names(G)), O.AdamState(D, O.d_param_names(D))
+    out = O.gan_step(G, D, g_opt, d_opt, lr_img, gt, upscale=2, g_lr=8e-5, d_lr=2e-4, betas=(0.9, 0.999), eps=1e-4, pixel_weight=20.0,
+                     content_weight=1.0, adversarial_weight=0.5)
+    d.compute_dtype = gen.compute_dtype = torch.float16
+    gen, d = gen.cuda().train(), d.cuda().train()
+    tr = GanTrainer(gen, d, None)
+    s = tr.step(lr_img.cuda(), gt.cuda()).cpu().numpy()
+    got = [s[0] + s[1], s[2], s[3], s[4], s[5]]
+    want = [out[k] for k in ("d_loss", "pixel_loss", "adversarial_loss", "d_gt_probability", "d_sr_probability")]
+    err = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want))
+    e_g, e_d = _rel(gen.conv4.bias, G["conv4.bias"]), _rel(d.conv4.weight, D["conv4.weight"])
+    print(f"f16 GAN iteration at 72 -> 144 x2, 23 RRDB: got {got} want {want} worst rel {err:.2e}; G conv4.bias {e_g:.2e}, D conv4.weight {e_d:.2e}")
+    assert err < 1e-3 and e_g < 5e-3 and e_d < 5e-3
+    rep = tr.scaler.report()
+    assert rep["optimizer_steps"] == 2 and rep["skipped"] == 0, rep
+
+
 def test_loss_scaler_skips_nonfinite_step():
     """GradScaler semantics (train_bsrgan.py:436-437,466-467): a non-finite gradient leaves parameters and Adam state untouched,
     halves the scale, and the EMA still advances; finite steps update as usual and leave the scale alone."""
