@@ -30,6 +30,7 @@ def _gen():
 def test_generator_loop_with_dropin_adam_and_ema_equals_torchs():
     from sr_gan_fd_amd import optim as O, swa_utils as S
     from torch.optim.swa_utils import AveragedModel as TorchAveraged
+    torch.manual_seed(31)       # the batches used to come from whatever state the tests before this one left the CUDA generator in
     data = [(torch.rand(2, 3, 16, 16, device="cuda"), torch.rand(2, 3, 64, 64, device="cuda")) for _ in range(4)]
     runs = {}
     for kind in ("torch", "ours"):
@@ -74,8 +75,10 @@ def test_generator_loop_with_dropin_adam_and_ema_equals_torchs():
         torch.nn.functional.l1_loss(g(x), gt).backward()        # outside autocast: f32 mode
         opt.step()
     assert back.flat_steps == 1
+    # (the two generators enter this iteration 2e-5 apart, so one L1 sign -- sign(sr - gt) / N -- can differ between them: on a bias that
+    # has moved 1e-4 in five steps that is a few 1e-7 after Adam's division, seen once with unseeded batches; 1e-6 = 1 % of one step)
     for (k, a), (_, b) in zip(gt_.state_dict().items(), go.state_dict().items()):
-        assert _close(a, b), k
+        assert _close(a, b, atol=1e-6), k
 
 
 def test_discriminator_accumulated_backwards_stay_on_the_fused_path():
