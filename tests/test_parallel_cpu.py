@@ -17,6 +17,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)          # 2-8 ranks x the host's default intra-op threads would oversubscribe its cores
     import torch.distributed as dist
     from sr_gan_fd_amd import parallel as P
     r, lr, w, pg = P.init_from_env("gloo")
@@ -91,6 +92,7 @@ def _trainer_worker(rank, world, port, q):
     values are meaningless, what is checked is that both ranks issue the same collectives in the same order on tensors of
     the same size, once per network per iteration, and that the 1/world scale reaches the optimizer)."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)          # 2-8 ranks x the host's default intra-op threads would oversubscribe its cores
     import torch.distributed as dist
     from sr_gan_fd_amd import _abi as A, model as M, parallel as P
     from sr_gan_fd_amd.gan import GanTrainer
@@ -150,7 +152,7 @@ def _world8_worker(rank, world, port, q):
     sequence of collectives (sizes and order), the buckets of a network cover its flat gradient exactly once, the discriminator's
     exchange comes before the generator's, the SyncBatchNorm table reduce sits inside the discriminator passes, 1/8 reaches Adam."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.set_num_threads(1)
+    torch.set_num_threads(1)          # 2-8 ranks x the host's default intra-op threads would oversubscribe its cores
     import torch.distributed as dist
     from sr_gan_fd_amd import _abi as A, model as M, parallel as P
     from sr_gan_fd_amd.gan import GanTrainer
