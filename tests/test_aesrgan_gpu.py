@@ -304,3 +304,39 @@ def test_aesrgan_discriminator_other_input_sizes(size):
     assert out.shape == want.shape == (2, 1, *size)
     assert _rel(out, want) < 1e-4
     assert _rel_l2(xin.grad, xo.grad) < 1e-2          # L2: activation-mask ties (see test_aesrgan_discriminator)
+
+
+def test_aesrgan_iteration_at_the_config_crop_f16_vs_oracle():
+    """aesrgan_config.py:62,102-103: x2, LR crops of 60 x 60 (GT 120 x 120), the 23-RRDB generator with the attention U-Net discriminator.
+    One GAN iteration (train_aesrgan.py:396-483, content term off) in float16 -- the scripts' autocast dtype -- against the fp32 CPU
+    oracle; batch 2 instead of 8 keeps the oracle at seconds.  At this crop the generator's dense blocks run through the dense-block
+    launch (8 x 16 tiles), forward and data gradient, inside the GAN trainer.  Asserted: every logged scalar within 1e-3 relative
+    (BASELINE.json's tolerance), probed parameters after both Adam steps within 5e-3 of the tensor's range."""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M, ops
+    from sr_gan_fd_amd.gan import GanTrainer
+    from tests.util import sd_to_params
+    torch.manual_seed(9)
+    lr_img, gt = torch.rand(2, 3, 60, 60), torch.rand(2, 3, 120, 120)
+    torch.manual_seed(0)
+    d = M.uNetDiscriminatorAesrgan()
+    gen = M.bsrgan_x2(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_rrdb=23)
+    scaled_init(gen, 3.0, 0.5)
+    G = sd_to_params(gen.state_dict())
+    D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    g_opt, d_opt = O.AdamState(G, O.g_param_names(G)), O.AdamState(D, O.d_param_names(D))
+    out = O.gan_step(G, D, g_opt, d_opt, lr_img, gt, upscale=2, g_lr=5e-5, d_lr=1e-5, betas=(0.9, 0.999), eps=1e-4, pixel_weight=10.0,
+                     content_weight=1.0, adversarial_weight=0.1, d_forward=O.aesrgan_unet_forward)
+    d.compute_dtype = gen.compute_dtype = torch.float16
+    gen, d = gen.cuda().train(), d.cuda().train()
+    tr = GanTrainer(gen, d, None, g_lr=5e-5, d_lr=1e-5, pixel_weight=10.0, adversarial_weight=0.1)
+    s = tr.step(lr_img.cuda(), gt.cuda()).cpu().numpy()
+    sp = tr.ge._last
+    n_chain = len([a for a in sp.fw if type(a) is ops.DenseChain]) + len([it for it in sp.bw if it[0] == "chain"])
+    assert n_chain == 6 * 23 or ops.DENSE_CHAIN == "0", n_chain
+    got = [s[0] + s[1], s[2], s[3], s[4], s[5]]
+    want = [out[k] for k in ("d_loss", "pixel_loss", "adversarial_loss", "d_gt_probability", "d_sr_probability")]
+    err = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want))
+    e_g, e_d = _rel(gen.conv4.bias, G["conv4.bias"]), _rel(d.conv9.weight, D["conv9.weight"])
+    print(f"f16 A-ESRGAN iteration at 60 -> 120 x2, 23 RRDB: got {got} want {want} worst rel {err:.2e}; G conv4.bias {e_g:.2e}, D conv9.weight {e_d:.2e}")
+    assert err < 1e-3 and e_g < 5e-3 and e_d < 5e-3
