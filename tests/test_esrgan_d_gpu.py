@@ -397,3 +397,42 @@ def test_esrgan_fused_trainer_checkpoint_resume_is_bitwise():
     assert torch.equal(tr.g_opt.ema, tr2.g_opt.ema) and torch.equal(tr.g_opt.m, tr2.g_opt.m) and torch.equal(tr.d_opt.v, tr2.d_opt.v)
     for (k, x), (_, y) in zip(d.state_dict().items(), d2.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+def test_esrgan_iteration_at_the_config_crop_f16_vs_oracle():
+    """esrgan_config.py:73-74: x4, LR crops of 32 x 32 (GT 128 x 128 -- the size the BatchNorm discriminator's classifier fixes), the
+    23-RRDB generator.  One relativistic GAN iteration (train_esrgan.py:364-431, content term off) of the fused trainer in float16 -- the
+    scripts' autocast dtype -- against the fp32 CPU oracle; batch 4 instead of 16 keeps the oracle at seconds.  The generator's dense
+    blocks run through the dense-block launch (8 x 16 tiles) in both of its passes.  Asserted: pixel loss within 1e-3 relative
+    (BASELINE.json's tolerance); the discriminator-side scalars within 5e-3 (the bound of the f16-against-f32 test above: BatchNorm
+    statistics over four images amplify one f16 rounding of the logits); SR within 1e-3."""
+    from oracle import srgan_oracle as O
+    from sr_gan_fd_amd import model as M, ops
+    from sr_gan_fd_amd.gan_esrgan import EsrganGanTrainer
+    from tests.util import scaled_init, sd_to_params
+    torch.manual_seed(9)
+    lr_img, gt = torch.rand(4, 3, 32, 32), torch.rand(4, 3, 128, 128)
+    torch.manual_seed(0)
+    d = M.discriminator()
+    gen = M.rrdbnet_x4(in_channels=3, out_channels=3, channels=64, growth_channels=32, num_blocks=23)
+    scaled_init(gen, 3.0, 0.5)
+    G = sd_to_params(gen.state_dict())
+    D = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    g_opt = O.AdamState(G, O.g_param_names(G))
+    d_opt = O.AdamState(D, [k for k in D if k.endswith((".weight", ".bias"))])
+    out = O.esrgan_gan_step(G, D, g_opt, d_opt, lr_img, gt)
+    d.compute_dtype = gen.compute_dtype = torch.float16
+    gen, d = gen.cuda().train(), d.cuda().train()
+    tr = EsrganGanTrainer(gen, d, None)
+    s = tr.step(lr_img.cuda(), gt.cuda()).cpu().numpy()
+    sp = tr.ge._last
+    n_chain = len([a for a in sp.fw if type(a) is ops.DenseChain]) + len([it for it in sp.bw if it[0] == "chain"])
+    assert n_chain == 6 * 23 or ops.DENSE_CHAIN == "0", n_chain
+    got = [s[0], s[1], s[3], s[4], s[5]]
+    want = [out[k] for k in ("d_loss", "pixel_loss", "adversarial_loss", "d_gt_probability", "d_sr_probability")]
+    rel = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want)]
+    e_sr = _rel(tr.sr, out["sr"])
+    print(f"f16 ESRGAN iteration at 32 -> 128, 23 RRDB: got {got} want {want} rel {[f'{r:.1e}' for r in rel]}; SR {e_sr:.2e}")
+    assert rel[1] < 1e-3 and max(rel) < 5e-3 and e_sr < 1e-3
+    rep = tr.scaler.report()
+    assert rep["optimizer_steps"] == 2 and rep["skipped"] == 0, rep
