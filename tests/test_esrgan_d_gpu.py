@@ -71,6 +71,11 @@ def test_batchnorm_leakyrelu_fused(c):
 def test_esrgan_discriminator(golden_dir, dtype):
     g = load_golden(golden_dir, "esrgan_discriminator.npz")
     f32 = dtype == torch.float32
+    # 16-bit bounds per dtype (measured f16 / bf16: logits 1.8e-3 / 4.1e-2; sampled weight gradients, relative L2, worst 1.2e-1 / 2.5e-1 --
+    # LeakyReLU masks of values within one 16-bit rounding of zero flip, each flip changes that element's gradient 5x; input gradient
+    # 1.1e-1 / 2.2e-1): f16 is the benchmarked dtype and gets its own, tighter, numbers
+    B16 = {torch.float16: dict(logits=5e-3, state=5e-3, loss=5e-3, grad=1.8e-1, dx=1.6e-1),
+           torch.bfloat16: dict(logits=6e-2, state=3e-2, loss=5e-2, grad=3e-1, dx=3e-1)}.get(dtype)
     d = _build()
     d.compute_dtype = dtype
     d.cuda().train()
@@ -79,14 +84,14 @@ def test_esrgan_discriminator(golden_dir, dtype):
         logits = d(x)
         e = _rel(logits, g[f"train{it}_logits"])
         print(f"ESRGAN D {dtype} train fwd {it}: logits err {e:.2e}")
-        assert e < (1e-3 if f32 else 6e-2)
+        assert e < (1e-3 if f32 else B16["logits"])
         sd = d.state_dict()
         for k, want in table(g, f"train{it}_statesum").items():
-            tol = 1e-3 if f32 else 3e-2
+            tol = 1e-3 if f32 else B16["state"]
             assert np.allclose(checksum(sd[k]), want, rtol=tol, atol=tol * abs(want[1]) + 1e-7), f"state {k}: {checksum(sd[k])} vs {want}"
     assert int(d.features[3].num_batches_tracked) == 2
     loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
-    assert abs(loss.item() - float(g["bce_ones"])) < (1e-3 if f32 else 5e-2)
+    assert abs(loss.item() - float(g["bce_ones"])) < (1e-3 if f32 else B16["loss"])
     S = 65536.0 if dtype == torch.float16 else 1.0       # f16 backward runs loss-scaled, as under the reference's GradScaler
     (loss * S).backward()
     named = dict(d.named_parameters())
@@ -108,7 +113,7 @@ def test_esrgan_discriminator(golden_dir, dtype):
         worst = max(worst, e)
         print(f"  {key}: L2 err {e:.2e}")
         deep = any(t in key for t in ("features.26", "features.27", "classifier"))
-        assert e < ((1e-4 if deep else 2e-2) if f32 else 3e-1), f"{key}: {e:.2e}"
+        assert e < ((1e-4 if deep else 2e-2) if f32 else B16["grad"]), f"{key}: {e:.2e}"
     print(f"ESRGAN D {dtype}: worst sampled grad L2 err {worst:.2e}")
     if f32:
         for k, want in table(g, "gsum").items():
@@ -116,18 +121,18 @@ def test_esrgan_discriminator(golden_dir, dtype):
             assert np.allclose(got, want, rtol=2e-2, atol=5e-3 * abs(want[1]) + 1e-6), f"grad checksum {k}: {got} vs {want}"
     d.eval()
     with torch.no_grad():
-        assert _rel(d(x), g["eval_logits"]) < (1e-3 if f32 else 6e-2)
+        assert _rel(d(x), g["eval_logits"]) < (1e-3 if f32 else B16["logits"])
     d.train()
     for p in d.parameters():
         p.requires_grad = False
     xin = x.clone().requires_grad_(True)
     lg = d(xin)
-    assert _rel(lg, g["train2_logits"]) < (1e-3 if f32 else 6e-2)
+    assert _rel(lg, g["train2_logits"]) < (1e-3 if f32 else B16["logits"])
     (F.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)) * S).backward()
     ref = torch.tensor(g["train2_dx"]).double()
     e2 = ((xin.grad.double().cpu() / S - ref).norm() / ref.norm()).item()
     print(f"ESRGAN D {dtype}: input-gradient L2 err {e2:.2e}")
-    assert e2 < (3e-2 if f32 else 3e-1)
+    assert e2 < (3e-2 if f32 else B16["dx"])
 
 
 F16_GRAD_L2 = 1.5e-1      # d/dSR of the single-node content loss in f16 vs the f16-weight oracle, relative L2 (sign flips of |sr_f - gt_f| ~ f16 error)
