@@ -190,6 +190,9 @@ def test_aesrgan_discriminator(golden_dir, dtype):
     from sr_gan_fd_amd import model as M
     g = load_golden(golden_dir, "aesrgan_discriminator.npz")
     f32 = dtype == torch.float32
+    # 16-bit bounds per dtype (measured f16 / bf16: logits 1.4e-3 / 1.0e-2, attention map 4e-5 / 4e-4, sampled weight gradients 3.5e-2 /
+    # 1.7e-1, input gradient relative L2 5.2e-2 / 1.4e-1): float16 is the benchmarked dtype and gets its own, tighter, numbers
+    B16 = {torch.float16: dict(logits=5e-3, grad=8e-2, dx=1e-1), torch.bfloat16: dict(logits=5e-2, grad=2e-1, dx=1.5e-1)}.get(dtype)
     torch.manual_seed(0)
     d = M.UNetDiscriminatorAesrgan(3)
     d.compute_dtype = dtype
@@ -199,15 +202,15 @@ def test_aesrgan_discriminator(golden_dir, dtype):
         logits = d(x)
         e = _rel(logits, g[f"train{it}_logits"])
         print(f"A-ESRGAN D {dtype} train fwd {it}: logits err {e:.2e}, attention-map err {_rel(d.ly3, g[f'train{it}_attn3']):.2e}")
-        assert e < (1e-3 if f32 else 5e-2)
-        assert _rel(d.ly3, g[f"train{it}_attn3"]) < (1e-3 if f32 else 5e-2)
+        assert e < (1e-3 if f32 else B16["logits"])
+        assert _rel(d.ly3, g[f"train{it}_attn3"]) < (1e-3 if f32 else B16["logits"])
         sd = d.state_dict()
         for k, want in table(g, f"train{it}_statesum").items():
             tol = 1e-3 if (f32 or k.endswith(("_u", "_v"))) else 3e-2     # BN statistics see bf16 activations
             assert np.allclose(checksum(sd[k]), want, rtol=tol, atol=tol * abs(want[1]) + 1e-7), f"state {k}: {checksum(sd[k])} vs {want}"
     assert int(d.attn_1.W[1].num_batches_tracked) == 2
     loss = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
-    assert abs(loss.item() - float(g["bce_ones"])) < (1e-3 if f32 else 5e-2)
+    assert abs(loss.item() - float(g["bce_ones"])) < (1e-3 if f32 else B16["logits"])
     S = 65536.0 if dtype == torch.float16 else 1.0       # f16 backward runs loss-scaled, as under the reference's GradScaler
     (loss * S).backward()
     named = dict(d.named_parameters())
@@ -216,7 +219,7 @@ def test_aesrgan_discriminator(golden_dir, dtype):
               "attn_2.theta.weight", "attn_3.phi.bias", "gating.weight_orig"):
         e = _rel(named[k].grad / S, g[f"grad/{k}"])
         worst = max(worst, e)
-        assert e < (2e-3 if f32 else 2e-1), f"grad {k}: {e:.2e}"
+        assert e < (2e-3 if f32 else B16["grad"]), f"grad {k}: {e:.2e}"
     print(f"A-ESRGAN D {dtype}: worst sampled grad err {worst:.2e}")
     if f32:
         for k, want in table(g, "gsum").items():
@@ -224,13 +227,13 @@ def test_aesrgan_discriminator(golden_dir, dtype):
             assert np.allclose(got, want, rtol=2e-2, atol=2e-3 * abs(want[1]) + 1e-6), f"grad checksum {k}: {got} vs {want}"
     d.eval()
     with torch.no_grad():
-        assert _rel(d(x), g["eval_logits"]) < (1e-3 if f32 else 5e-2)
+        assert _rel(d(x), g["eval_logits"]) < (1e-3 if f32 else B16["logits"])
     d.train()
     for p in d.parameters():
         p.requires_grad = False
     xin = x.clone().requires_grad_(True)
     lg = d(xin)
-    assert _rel(lg, g["train2_logits"]) < (1e-3 if f32 else 5e-2)
+    assert _rel(lg, g["train2_logits"]) < (1e-3 if f32 else B16["logits"])
     (F.binary_cross_entropy_with_logits(lg, torch.ones_like(lg)) * S).backward()
     dxin = xin.grad / S
     e, e2 = _rel(dxin, g["train2_dx"]), _rel_l2(dxin, g["train2_dx"])
@@ -246,7 +249,7 @@ def test_aesrgan_discriminator(golden_dir, dtype):
         # many values may sit outside the north_star tolerance, not the raw maximum.
         assert e2 < 1e-3 and frac < 5e-3 and e < 2e-2
     else:
-        assert e2 < 1.5e-1
+        assert e2 < B16["dx"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -269,9 +272,13 @@ def test_aesrgan_gan_steps_fused_trainer(golden_dir, dtype):
         s = tr.step(torch.tensor(g[f"it{it}_lr"]).cuda(), torch.tensor(g[f"it{it}_gt"]).cuda()).cpu().numpy()
         want = g[f"it{it}_scalars"]  # d_loss, pixel, content, adv, D(gt), D(sr)
         got = [s[0] + s[1], s[2], 0.0, s[3], s[4], s[5]]
-        print(f"A-ESRGAN GAN {dtype} it{it}: got {got} want {list(want)}")
-        assert np.allclose(got, want, rtol=1e-3 if f32 else 3e-2, atol=1e-5)
-        assert _rel(tr.sr, g[f"it{it}_sr"]) < (1e-3 if f32 else 3e-2)
+        e_sr = _rel(tr.sr, g[f"it{it}_sr"])
+        print(f"A-ESRGAN GAN {dtype} it{it}: got {got} want {list(want)} SR err {e_sr:.2e}")
+        # float16 (the benchmarked dtype) is held to BASELINE.json's 1e-3 on the logged scalars and SR like f32 (measured 2e-5 / see print);
+        # bfloat16 (8 mantissa bits) to 3e-2
+        tol16 = 1e-3 if dtype == torch.float16 else 3e-2
+        assert np.allclose(got, want, rtol=1e-3 if f32 else tol16, atol=1e-5)
+        assert e_sr < (1e-3 if f32 else tol16)
         if not f32:
             continue
         assert _rel(gen.conv4.bias, g[f"it{it}_g_conv4_bias"]) < 1e-3
